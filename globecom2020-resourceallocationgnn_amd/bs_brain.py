@@ -1,0 +1,194 @@
+"""Drop-in mirror of the reference's `BS` Q-network wrapper (BS_brain.py:90-239) and of the part
+of the Keras `Model` API its callers use (`fit`, `predict`, `get_weights`, `set_weights`,
+`save_weights`, `load_weights`; call sites BS_brain.py:221,229,231,239,863,869,1254,1256).
+
+Same constructor, attributes, dict-keyed inputs / outputs and History keys as the reference;
+the arithmetic runs in the gfx950 kernels behind include/v2xgnn.h.  `Agent` (BS_brain.py:280-)
+can use this class unchanged:  `self.brain = BS(num_d2d, 3, 1, num_feedback, num_neighbor, num_ch)`.
+"""
+import numpy as np
+
+from .engine import GnnEngine
+from .packing import PackedBatch, feed_to_arrays, keras_list_shapes
+from .spec import GnnSpec
+
+
+class History(object):
+    """What `Model.fit` returns; the caller reads history['D{k}_Decide_Output_loss'][0]
+    (BS_brain.py:835-837)."""
+
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+
+def _glorot_list(spec, rng):
+    """glorot_uniform kernels / zero biases like GNNLayer.build (BS_brain.py:26-41) and Dense."""
+    out = []
+    for shp in keras_list_shapes(spec):
+        if len(shp) == 1:
+            out.append(np.zeros(shp, np.float32))
+        else:
+            lim = np.sqrt(6.0 / (shp[0] + shp[1]))
+            out.append(rng.uniform(-lim, lim, size=shp).astype(np.float32))
+    return out
+
+
+class GnnQModel(object):
+    """Keras-`Model`-like object over one GnnEngine."""
+
+    def __init__(self, spec: GnnSpec, device=0, seed=None, use_graph=False, validate_adjacency=True,
+                 lr=1e-3, beta_1=0.5, beta_2=0.999, epsilon=1e-7):
+        self.spec = spec
+        self.engine = GnnEngine(spec, device=device, use_graph=use_graph, lr=lr, beta_1=beta_1, beta_2=beta_2,
+                                epsilon=epsilon)             # Adam(lr=0.001, beta_1=0.5, beta_2=0.999) BS_brain.py:212
+        self.validate_adjacency = validate_adjacency
+        N = spec.n_nodes
+        self.input_names = []
+        for k in range(1, N + 1):                            # order of Model(inputs=[...]) BS_brain.py:203-207
+            self.input_names += ['D%d_Node_Input' % k, 'D%d_Edge_Input' % k, 'D%d_Neighbor_Input' % k]
+        self.input_names.append('Adjacency_Matrix')
+        self.output_names = ['D%d_Decide_Output' % k for k in range(1, N + 1)]       # :208
+        self.engine.set_weights(_glorot_list(spec, np.random.default_rng(seed)))
+
+    # ------------------------------------------------------------------ data plumbing
+    def _named(self, x, names, what):
+        if isinstance(x, dict):
+            return x
+        if isinstance(x, (list, tuple)):
+            if len(x) != len(names):
+                raise ValueError("Error when checking model %s: expected %d arrays but got %d" % (what, len(names), len(x)))
+            return dict(zip(names, x))
+        raise ValueError("Error when checking model %s: expected a dict or list of arrays" % what)
+
+    def _pack(self, x):
+        feed = self._named(x, self.input_names, "input")
+        xs, es, nbr, adj = feed_to_arrays(self.spec, feed, self.validate_adjacency)
+        return xs, es, nbr, adj
+
+    def _targets(self, y, B):
+        yd = self._named(y, self.output_names, "target")
+        cols = []
+        for name in self.output_names:
+            if name not in yd:
+                raise ValueError('No data provided for "%s". Need data for each key' % name)
+            a = np.asarray(yd[name])
+            if a.shape != (B, self.spec.n_channels):
+                raise ValueError('Error when checking target: expected %s to have shape (%d,) but got array with '
+                                 'shape %r' % (name, self.spec.n_channels, a.shape[1:]))
+            cols.append(a)
+        return np.stack(cols, axis=1)        # [B, N, C]
+
+    # ------------------------------------------------------------------ Keras surface
+    def predict(self, x, batch_size=None, verbose=0):
+        """-> list of N fresh, writable float32 arrays [B, C] (the caller mutates them in place,
+        BS_brain.py:684-692)."""
+        xs, es, nbr, adj = self._pack(x)
+        B, N, Cc = xs.shape[0], self.spec.n_nodes, self.spec.n_channels
+        q = self.engine.forward(PackedBatch.from_dense(xs, es, adj, nbr)).reshape(B, N, Cc)
+        return [np.ascontiguousarray(q[:, k, :]) for k in range(N)]
+
+    def fit(self, x, y, batch_size=None, epochs=1, verbose=0, shuffle=True):
+        """Model.fit: `epochs` passes of minibatch Adam steps.  The reference always calls it with
+        batch_size == len(x), i.e. exactly one step (BS_brain.py:218-223)."""
+        xs, es, nbr, adj = self._pack(x)
+        B, N = xs.shape[0], self.spec.n_nodes
+        yt = self._targets(y, B)
+        batch_size = int(batch_size or 32)       # Keras default
+        hist = History()
+        keys = ['loss'] + [n + '_loss' for n in self.output_names]
+        for k in keys:
+            hist.history[k] = []
+        for ep in range(int(epochs)):
+            idx = np.arange(B)
+            if shuffle and B > 1:
+                np.random.shuffle(idx)           # Keras shuffles with the global numpy RNG
+            tot = np.zeros(N, np.float64)
+            for s in range(0, B, batch_size):
+                sel = idx[s:s + batch_size]
+                if len(sel) == B:
+                    # whole data set in one minibatch: sample order inside the batch only changes
+                    # the fp32 summation order, so skip the gather
+                    bx, be, bn, ba, by = xs, es, nbr, adj, yt
+                else:
+                    bx, be, ba, by = xs[sel], es[sel], adj[sel], yt[sel]
+                    bn = None if nbr is None else nbr[sel]
+                pb = PackedBatch.from_dense(bx, be, ba, bn)
+                loss = self.engine.train_step(pb, by.reshape(-1, self.spec.n_channels))
+                tot += np.asarray(loss, np.float64) * len(sel)
+            tot /= B
+            hist.epoch.append(ep)
+            hist.history['loss'].append(float(tot.sum()))              # sum of per-output losses (:214)
+            for k, name in enumerate(self.output_names):
+                hist.history[name + '_loss'].append(float(tot[k]))
+        return hist
+
+    def train_on_batch(self, x, y):
+        h = self.fit(x, y, batch_size=len(next(iter(self._named(x, self.input_names, "input").values()))),
+                     epochs=1, shuffle=False)
+        return [h.history['loss'][0]] + [h.history[n + '_loss'][0] for n in self.output_names]
+
+    def get_weights(self):
+        return self.engine.get_weights()
+
+    def set_weights(self, weights):
+        self.engine.set_weights(weights)
+
+    def save_weights(self, filepath, overwrite=True):
+        """Weights only, like Keras `save_weights` (no optimizer state: BS_brain.py:853-870).
+        h5py is not available on the target image, so the container is NumPy's .npz written
+        under exactly the name the caller gives (including the reference's '.h5' names)."""
+        arrays = {('w%03d' % i): w for i, w in enumerate(self.get_weights())}
+        with open(filepath, 'wb') as f:
+            np.savez(f, **arrays)
+
+    def load_weights(self, filepath):
+        with np.load(filepath) as z:
+            self.set_weights([z['w%03d' % i] for i in range(len(z.files))])
+
+
+class BS(object):
+    """Same constructor / attributes / methods as the reference class (BS_brain.py:90-239)."""
+
+    def __init__(self, num_d2d, input_node_info, input_edge_info, num_d2d_feedback, num_d2d_neighbor, num_ch,
+                 device=0, seed=None, n_mp_layers=2, share_weights=False, use_graph=False):
+        self.num_D2D = num_d2d
+        self.num_Neighbor = num_d2d_neighbor
+        self.num_CH = num_ch
+        self.num_Feedback = num_d2d_feedback
+        self.input_node_Info = input_node_info
+        self.input_edge_Info = input_edge_info
+        self.num_One_Node_Input = ((input_node_info - 1) * self.num_CH + 1) * self.num_Neighbor
+        self.num_One_Edge_Input = input_edge_info * self.num_CH
+        self.num_One_D2D_Input = self.num_One_Node_Input + self.num_One_Edge_Input
+        self.num_D2D_Input = num_d2d * self.num_One_D2D_Input + self.num_D2D ** 2
+        self._spec = GnnSpec(n_nodes=num_d2d, n_channels=num_ch, feat_dim=num_d2d_feedback,
+                             n_mp_layers=n_mp_layers, share_weights=share_weights,
+                             input_node_info=input_node_info, input_edge_info=input_edge_info,
+                             n_neighbor=num_d2d_neighbor)
+        self._device, self._use_graph = device, use_graph
+        ss = np.random.SeedSequence(seed).spawn(2)
+        self._seeds = [int(s.generate_state(1)[0]) for s in ss]
+        self.model = self._create_model()
+        self.target_model = self._create_model()
+
+    def _create_model(self):
+        seed = self._seeds.pop(0) if self._seeds else None
+        return GnnQModel(self._spec, device=self._device, seed=seed, use_graph=self._use_graph)
+
+    def train_dnn(self, data_train, labels, batch_size):
+        epochs = 1
+        Train_Result = self.model.fit(data_train, labels, batch_size=batch_size, epochs=epochs, verbose=0)
+        return Train_Result
+
+    def predict(self, data_test, target=False):
+        if target:
+            return self.target_model.predict(data_test)
+        return self.model.predict(data_test)
+
+    def predict_one_step(self, data_test, target=False):
+        return self.predict(data_test, target=target)
+
+    def update_target_model(self):
+        # one device-to-device copy instead of get_weights()/set_weights() through the host
+        self.target_model.engine.copy_weights_from(self.model.engine)

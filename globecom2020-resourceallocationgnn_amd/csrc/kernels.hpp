@@ -1,0 +1,755 @@
+// CDNA4 (gfx950) device kernels of the V2X GNN Q-network engine.
+//
+// What each kernel replaces in the reference (/root/reference/BS_brain.py):
+//   k_agg          AggLayer.call  :69-76   out[q] = sum_{p in N(q)} h[p]  (CSR gather, LDS-staged
+//                                           graph tiles) and its transpose for the backward pass
+//   k_gemm_rows    GNNLayer.call  :44-51   act([h|x]W1 + eW2 + aggW3 + b)  (fp32 MFMA 16x16x4)
+//                                           + the data-gradient of the same layer
+//   k_mlp_fwd/bwd  Dense x4       :176-179 80-40-20-C decision MLP, register-chained MFMA;
+//                                           bwd fuses tf.losses.huber_loss (:86-87)
+//   k_wgrad        TF autodiff of the K.dot's (weight gradients), fp32 MFMA over node rows
+//   k_reduce_adam  keras.optimizers.Adam (:212), Keras 2.2.4 epsilon placement
+//
+// MFMA operand convention used everywhere ("swapped" GEMM, wave = 64 lanes):
+//   v_mfma_f32_16x16x4_f32:  D[i][j] += sum_k A[i][k] B[k][j];  lane l supplies A[l&15][l>>4],
+//   B[l>>4][l&15] and holds D[4*(l>>4)+r][l&15], r=0..3.
+//   We put the WEIGHTS in A (i = output feature) and the ACTIVATIONS in B (j = node row), so a
+//   lane ends up with 4 consecutive output features of ONE node row: a 16-byte store, and --
+//   because the 16 k-values of a block are relabelled k = 4*(l>>4)+s for MFMA step s -- exactly
+//   the B operand of the next layer.  The decision MLP therefore chains through registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace v2x {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define V2X_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int XE = 16;          // packed [x|e|pad] width
+constexpr int H1 = 80, H2 = 40, H3 = 20;   // Dense widths (BS_brain.py:176-178)
+constexpr int H2P = 48, H3P = 32, CP = 16; // padded to MFMA tiles
+constexpr int LD1 = H1 + 4, LD2 = H2P + 4, LD3 = H3P + 4, LD4 = CP + 4;  // LDS strides = 4 mod 8
+
+// padded-row -> real-row map of a weight matrix image: rows [pad_at, pad_at+n_pad) are zero pad
+struct RowPad { int pad_at, n_pad, k_real; };
+__device__ __forceinline__ int real_row(const RowPad& p, int rp) {
+  int rr = rp < p.pad_at ? rp : (rp < p.pad_at + p.n_pad ? -1 : rp - p.n_pad);
+  return rr < p.k_real ? rr : -1;
+}
+
+// copy W[k_real][n_real] (global, row-major) into an LDS image [kp][ld] with zero padding
+__device__ __forceinline__ void fill_weight_image(float* sW, int ld, int kp, int np, const float* Wg,
+                                                  RowPad pad, int n_real) {
+  const int c4n = np >> 2;
+  for (int i = threadIdx.x; i < kp * c4n; i += blockDim.x) {
+    const int rp = i / c4n, c = (i - rp * c4n) << 2;
+    const int rr = real_row(pad, rp);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rr >= 0 && c < n_real) v = *reinterpret_cast<const float4*>(Wg + (int64_t)rr * n_real + c);
+    *reinterpret_cast<float4*>(sW + rp * ld + c) = v;
+  }
+}
+__device__ __forceinline__ void fill_bias(float* sB, int np, const float* bg, int n_real) {
+  for (int i = threadIdx.x; i < np; i += blockDim.x) sB[i] = i < n_real ? bg[i] : 0.f;
+}
+
+// =====================================================================================
+// k_agg : neighbour gather + segment sum over CSR, one LDS tile per graph
+// =====================================================================================
+struct AggArgs {
+  const float* src; int src_stride;     // rows to aggregate (width F at column 0 of src)
+  const float* add; int add_stride;     // optional: out += add
+  const float* mask;                    // optional [R][F]: out = mask > 0 ? out : 0 (ReLU')
+  float* out;                           // [R][F]
+  const int32_t* graph_off;             // [B+1] or null (fixed n_nodes)
+  const int32_t* row_ptr;               // [R+1]
+  const int32_t* col_idx;               // [E]
+  int n_graphs, n_nodes, F, lpr_shift;  // lanes per row = F/4 = 1 << lpr_shift
+  int gpw;                              // graphs per workgroup (power of two)
+  int rows_cap, edges_cap, mask_words;  // LDS capacities
+  int transpose;                        // 0: out[q] = sum_{p->q} src[p];  1: out[p] = sum_{p->q} src[q]
+};
+
+__global__ __launch_bounds__(256) void k_agg(AggArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sT = smem;                                         // [rows_cap][F]
+  int* sRp = reinterpret_cast<int*>(sT + a.rows_cap * a.F); // [rows_cap+1]
+  int* sG = sRp + a.rows_cap + 1;                           // [gpw+1] local first row of each graph
+  int* sCol = sG + a.gpw + 1;                               // [edges_cap]
+  unsigned* sM = reinterpret_cast<unsigned*>(sCol + a.edges_cap);  // [rows_cap][mask_words]
+
+  const int tid = threadIdx.x;
+  const int g0 = blockIdx.x * a.gpw;
+  const int g1 = min(g0 + a.gpw, a.n_graphs);
+  const int r_begin = a.graph_off ? a.graph_off[g0] : g0 * a.n_nodes;
+  const int r_end = a.graph_off ? a.graph_off[g1] : g1 * a.n_nodes;
+  const int nrows = r_end - r_begin;
+  const int e_begin = a.row_ptr[r_begin];
+  const int nedges = a.row_ptr[r_end] - e_begin;
+  const int LPR = 1 << a.lpr_shift;
+
+  // ---- stage: the WG's graphs are contiguous rows / contiguous edges => coalesced reads
+  for (int i = tid; i < (nrows << a.lpr_shift); i += 256) {
+    const int r = i >> a.lpr_shift, c = (i & (LPR - 1)) << 2;
+    *reinterpret_cast<float4*>(sT + r * a.F + c) =
+        *reinterpret_cast<const float4*>(a.src + (int64_t)(r_begin + r) * a.src_stride + c);
+  }
+  for (int i = tid; i <= nrows; i += 256) sRp[i] = a.row_ptr[r_begin + i] - e_begin;
+  for (int i = tid; i < nedges; i += 256) sCol[i] = a.col_idx[e_begin + i];
+  for (int i = tid; i <= a.gpw; i += 256) {
+    const int g = min(g0 + i, g1);
+    sG[i] = (a.graph_off ? a.graph_off[g] : g * a.n_nodes) - r_begin;
+  }
+  if (a.transpose)
+    for (int i = tid; i < nrows * a.mask_words; i += 256) sM[i] = 0u;
+  __syncthreads();
+
+  if (a.transpose) {
+    // transposed adjacency as per-source bit masks (integer atomics: order-independent result)
+    for (int r = tid; r < nrows; r += 256) {
+      int gi = 0;
+      while (gi + 1 < a.gpw && sG[gi + 1] <= r) ++gi;
+      const int gb = sG[gi], ql = r - gb;
+      for (int e = sRp[r]; e < sRp[r + 1]; ++e)
+        atomicOr(&sM[(gb + sCol[e]) * a.mask_words + (ql >> 5)], 1u << (ql & 31));
+    }
+    __syncthreads();
+  }
+
+  // ---- compute: a "worker" = LPR lanes owning one destination row at a time (float4 per lane)
+  const int worker = tid >> a.lpr_shift, li4 = (tid & (LPR - 1)) << 2;
+  const int nworkers = 256 >> a.lpr_shift;
+  const int wpg = nworkers / a.gpw;            // workers per graph (>= 1 by host choice)
+  const int gi = worker / wpg, wr = worker - gi * wpg;
+  if (g0 + gi >= g1) return;
+  const int gb = sG[gi], ng = sG[gi + 1] - gb;
+  for (int q = wr; q < ng; q += wpg) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!a.transpose) {
+      const int e1 = sRp[gb + q + 1];
+      int e = sRp[gb + q];
+      for (; e + 4 <= e1; e += 4) {   // 4 independent LDS gathers in flight
+        const int p0 = sCol[e], p1 = sCol[e + 1], p2 = sCol[e + 2], p3 = sCol[e + 3];
+        const float4 v0 = *reinterpret_cast<const float4*>(sT + (gb + p0) * a.F + li4);
+        const float4 v1 = *reinterpret_cast<const float4*>(sT + (gb + p1) * a.F + li4);
+        const float4 v2 = *reinterpret_cast<const float4*>(sT + (gb + p2) * a.F + li4);
+        const float4 v3 = *reinterpret_cast<const float4*>(sT + (gb + p3) * a.F + li4);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+      }
+      for (; e < e1; ++e) {
+        const float4 v = *reinterpret_cast<const float4*>(sT + (gb + sCol[e]) * a.F + li4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    } else {
+      for (int wd = 0; wd < a.mask_words; ++wd) {
+        unsigned mbits = sM[(gb + q) * a.mask_words + wd];
+        while (mbits) {
+          const int b = __builtin_ctz(mbits);
+          mbits &= mbits - 1;
+          const float4 v = *reinterpret_cast<const float4*>(sT + (gb + (wd << 5) + b) * a.F + li4);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+      }
+    }
+    const int64_t row = r_begin + gb + q;
+    if (a.add) {
+      const float4 v = *reinterpret_cast<const float4*>(a.add + row * a.add_stride + li4);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (a.mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(a.mask + row * a.F + li4);
+      acc.x = mk.x > 0.f ? acc.x : 0.f; acc.y = mk.y > 0.f ? acc.y : 0.f;
+      acc.z = mk.z > 0.f ? acc.z : 0.f; acc.w = mk.w > 0.f ? acc.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(a.out + row * a.F + li4) = acc;
+  }
+}
+
+// =====================================================================================
+// k_gemm_rows : node update  out = act(sum_seg in_seg . W_seg + b)  and its data-gradient
+// =====================================================================================
+struct GemmArgs {
+  const float* seg0; int seg0_stride;   // h_prev (fwd) or dpre (dgrad), width F
+  const float* xe;                      // [R][16]
+  const float* seg2; int seg2_stride;   // agg_prev / neighbour-init, width F
+  const float* W; int64_t slot_stride;  // layer base in the flat parameter buffer
+  RowPad pad;
+  float* out; int out_stride;
+  int relu;
+  int n_idx, row_stride, base_mul;      // row(idx) = idx*row_stride + slot*base_mul
+};
+
+template <int F, bool HAS0, bool HAS2, bool DGRAD, int RT>
+__global__ __launch_bounds__(256) void k_gemm_rows(GemmArgs a) {
+  constexpr int FB = F / 16;
+  constexpr int KB = DGRAD ? FB : ((HAS0 ? FB : 0) + 1 + (HAS2 ? FB : 0));
+  constexpr int NT = DGRAD ? 2 * FB : FB;
+  constexpr int KP = DGRAD ? (2 * F + XE) : KB * 16;
+  constexpr int LDW = F + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sW = smem;              // [KP][LDW]
+  float* sB = smem + KP * LDW;   // [F]
+
+  const int slot = blockIdx.y;
+  const float* Wg = a.W + slot * a.slot_stride;
+  fill_weight_image(sW, LDW, KP, F, Wg, a.pad, F);
+  if (!DGRAD) fill_bias(sB, F, Wg + (int64_t)a.pad.k_real * F, F);
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+
+  // ---- B operand (activations): one float4 per 16-wide K block, straight from HBM
+  float4 bf[RT][KB];
+  int64_t rows[RT];
+  bool valid[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int idx = blockIdx.x * (64 * RT) + wv * (16 * RT) + rt * 16 + j;
+    valid[rt] = idx < a.n_idx;
+    const int64_t row = (int64_t)min(idx, a.n_idx - 1) * a.row_stride + slot * a.base_mul;
+    rows[rt] = row;
+    int kb = 0;
+    if (HAS0 || DGRAD) {
+#pragma unroll
+      for (int b = 0; b < FB; ++b)
+        bf[rt][kb++] = *reinterpret_cast<const float4*>(a.seg0 + row * a.seg0_stride + b * 16 + 4 * kg);
+    }
+    if (!DGRAD) {
+      bf[rt][kb++] = *reinterpret_cast<const float4*>(a.xe + row * XE + 4 * kg);
+      if (HAS2) {
+#pragma unroll
+        for (int b = 0; b < FB; ++b)
+          bf[rt][kb++] = *reinterpret_cast<const float4*>(a.seg2 + row * a.seg2_stride + b * 16 + 4 * kg);
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[RT][NT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      float w[4];
+      if (!DGRAD) {
+        // A[i = out feature nt*16+j][k = kb*16 + 4*kg + s]  = W[k][i]  (column of the image)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) w[s] = sW[(kb * 16 + 4 * kg + s) * LDW + nt * 16 + j];
+      } else {
+        // A[i = input feature][k = out feature]  = W[i][k]  (row of the image, skipping the xe rows)
+        const int orow = nt < FB ? nt * 16 : F + XE + (nt - FB) * 16;
+        const float4 t = *reinterpret_cast<const float4*>(sW + (orow + j) * LDW + kb * 16 + 4 * kg);
+        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        acc[rt][nt] = V2X_MFMA(w[0], bf[rt][kb].x, acc[rt][nt]);
+        acc[rt][nt] = V2X_MFMA(w[1], bf[rt][kb].y, acc[rt][nt]);
+        acc[rt][nt] = V2X_MFMA(w[2], bf[rt][kb].z, acc[rt][nt]);
+        acc[rt][nt] = V2X_MFMA(w[3], bf[rt][kb].w, acc[rt][nt]);
+      }
+    }
+  }
+
+  // ---- epilogue: lane holds out[row j][nt*16 + 4*kg .. +3]
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    if (!valid[rt]) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      f32x4 v = acc[rt][nt];
+      if (!DGRAD) {
+        const float4 b = *reinterpret_cast<const float4*>(sB + nt * 16 + 4 * kg);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        if (a.relu) {
+          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        }
+      }
+      *reinterpret_cast<float4*>(a.out + rows[rt] * a.out_stride + nt * 16 + 4 * kg) =
+          make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// =====================================================================================
+// decision MLP  (Dense 80 relu, 40 relu, 20 relu, C linear)  -- register-chained MFMA
+// =====================================================================================
+struct MlpArgs {
+  const float* h; const float* xe; const float* agg;   // z0 = [h | x | agg]  (rows of Dense-0 permuted)
+  const float* W[4]; int64_t slot_stride[4];            // flat-parameter bases of the 4 Dense layers
+  int C;
+  float* z1; float* z2; float* z3; float* q;            // [R][80], [R][40], [R][20], [R][C]
+  // backward only
+  const float* y; float inv_denom;
+  float* dq; float* dz1; float* dz2; float* dz3; float* gha;   // gha[R][2F] = [dh | dagg]
+  float* rowloss;                                       // [R] sum_c huber(y - q)
+  int n_idx, row_stride, base_mul;
+};
+
+template <int F>
+struct MlpLds {
+  static constexpr int K1P = 2 * F + XE;
+  static constexpr int W1 = 0;
+  static constexpr int W2 = W1 + K1P * LD1;
+  static constexpr int W3 = W2 + H1 * LD2;
+  static constexpr int W4 = W3 + H2P * LD3;
+  static constexpr int B1 = W4 + H3P * LD4;
+  static constexpr int B2 = B1 + H1;
+  static constexpr int B3 = B2 + H2P;
+  static constexpr int B4 = B3 + H3P;
+  static constexpr int TOTAL = B4 + CP;   // floats
+};
+
+template <int F>
+__device__ __forceinline__ void mlp_fill_lds(float* smem, const MlpArgs& a, int slot, bool with_bias) {
+  using L = MlpLds<F>;
+  const int C = a.C;
+  const float* w1 = a.W[0] + slot * a.slot_stride[0];
+  const float* w2 = a.W[1] + slot * a.slot_stride[1];
+  const float* w3 = a.W[2] + slot * a.slot_stride[2];
+  const float* w4 = a.W[3] + slot * a.slot_stride[3];
+  const int k1 = 2 * F + (2 * C + 1);
+  // Dense-0 rows [h(F) | x(2C+1) | agg(F)]: the image keeps xe's 16 columns; the edge-feature
+  // and pad rows are ZERO so the packed xe block can be used as-is (BS_brain.py:175 feeds
+  // only the node features to the decision DNN).
+  fill_weight_image(smem + L::W1, LD1, L::K1P, H1, w1, RowPad{F + 2 * C + 1, XE - (2 * C + 1), k1}, H1);
+  fill_weight_image(smem + L::W2, LD2, H1, H2P, w2, RowPad{H1, 0, H1}, H2);
+  fill_weight_image(smem + L::W3, LD3, H2P, H3P, w3, RowPad{H2, H2P - H2, H2}, H3);
+  fill_weight_image(smem + L::W4, LD4, H3P, CP, w4, RowPad{H3, H3P - H3, H3}, C);
+  if (with_bias) {
+    fill_bias(smem + L::B1, H1, w1 + (int64_t)k1 * H1, H1);
+    fill_bias(smem + L::B2, H2P, w2 + H1 * H2, H2);
+    fill_bias(smem + L::B3, H3P, w3 + H2 * H3, H3);
+    fill_bias(smem + L::B4, CP, w4 + H3 * C, C);
+  }
+}
+
+// acc[nt] (+)= W^T-tile x act-block  for one K block (column reads of the weight image)
+template <int RT, int NT>
+__device__ __forceinline__ void mfma_cols(const float* sW, int ld, int kb, int j, int kg,
+                                          const f32x4 (&bblk)[RT], f32x4 (&acc)[RT][NT]) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float w[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) w[s] = sW[(kb * 16 + 4 * kg + s) * ld + nt * 16 + j];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      acc[rt][nt] = V2X_MFMA(w[0], bblk[rt][0], acc[rt][nt]);
+      acc[rt][nt] = V2X_MFMA(w[1], bblk[rt][1], acc[rt][nt]);
+      acc[rt][nt] = V2X_MFMA(w[2], bblk[rt][2], acc[rt][nt]);
+      acc[rt][nt] = V2X_MFMA(w[3], bblk[rt][3], acc[rt][nt]);
+    }
+  }
+}
+
+// acc (+)= W-tile(rows orow..orow+15) x grad-block  for one K block (row reads of the image)
+template <int RT>
+__device__ __forceinline__ void mfma_rows(const float* sW, int ld, int orow, int kb, int j, int kg,
+                                          const f32x4 (&bblk)[RT], f32x4 (&acc)[RT]) {
+  const float4 t = *reinterpret_cast<const float4*>(sW + (orow + j) * ld + kb * 16 + 4 * kg);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    acc[rt] = V2X_MFMA(t.x, bblk[rt][0], acc[rt]);
+    acc[rt] = V2X_MFMA(t.y, bblk[rt][1], acc[rt]);
+    acc[rt] = V2X_MFMA(t.z, bblk[rt][2], acc[rt]);
+    acc[rt] = V2X_MFMA(t.w, bblk[rt][3], acc[rt]);
+  }
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) {
+  const float4 t = *reinterpret_cast<const float4*>(p);
+  return (f32x4){t.x, t.y, t.z, t.w};
+}
+__device__ __forceinline__ void st4(float* p, f32x4 v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+  return (f32x4){fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+}
+__device__ __forceinline__ f32x4 gate4(f32x4 g, f32x4 z) {   // g * (z > 0)
+  return (f32x4){z[0] > 0.f ? g[0] : 0.f, z[1] > 0.f ? g[1] : 0.f, z[2] > 0.f ? g[2] : 0.f,
+                 z[3] > 0.f ? g[3] : 0.f};
+}
+
+template <int F, int RT>
+__global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
+  using L = MlpLds<F>;
+  constexpr int FB = F / 16, KB1 = 2 * FB + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int slot = blockIdx.y;
+  mlp_fill_lds<F>(smem, a, slot, true);
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  int64_t rows[RT];
+  bool valid[RT];
+  f32x4 z0[KB1][RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int idx = blockIdx.x * (64 * RT) + wv * (16 * RT) + rt * 16 + j;
+    valid[rt] = idx < a.n_idx;
+    const int64_t row = (int64_t)min(idx, a.n_idx - 1) * a.row_stride + slot * a.base_mul;
+    rows[rt] = row;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) z0[b][rt] = ld4(a.h + row * F + b * 16 + 4 * kg);
+    z0[FB][rt] = ld4(a.xe + row * XE + 4 * kg);
+#pragma unroll
+    for (int b = 0; b < FB; ++b) z0[FB + 1 + b][rt] = ld4(a.agg + row * F + b * 16 + 4 * kg);
+  }
+  __syncthreads();
+
+  // ---- Dense 0: [2F+9] -> 80, relu
+  f32x4 z1[RT][5];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) z1[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < KB1; ++kb) mfma_cols<RT, 5>(smem + L::W1, LD1, kb, j, kg, z0[kb], z1);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      z1[rt][nt] = relu4(z1[rt][nt] + ld4(smem + L::B1 + nt * 16 + 4 * kg));
+      if (valid[rt]) st4(a.z1 + rows[rt] * H1 + nt * 16 + 4 * kg, z1[rt][nt]);
+    }
+  // ---- Dense 1: 80 -> 40 (48 padded), relu
+  f32x4 z2[RT][3];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) z2[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 5; ++kb) {
+    f32x4 blk[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) blk[rt] = z1[rt][kb];
+    mfma_cols<RT, 3>(smem + L::W2, LD2, kb, j, kg, blk, z2);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      z2[rt][nt] = relu4(z2[rt][nt] + ld4(smem + L::B2 + nt * 16 + 4 * kg));
+      if (valid[rt] && nt * 16 + 4 * kg < H2) st4(a.z2 + rows[rt] * H2 + nt * 16 + 4 * kg, z2[rt][nt]);
+    }
+  // ---- Dense 2: 40 -> 20 (32 padded), relu
+  f32x4 z3[RT][2];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) z3[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 3; ++kb) {
+    f32x4 blk[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) blk[rt] = z2[rt][kb];
+    mfma_cols<RT, 2>(smem + L::W3, LD3, kb, j, kg, blk, z3);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      z3[rt][nt] = relu4(z3[rt][nt] + ld4(smem + L::B3 + nt * 16 + 4 * kg));
+      if (valid[rt] && nt * 16 + 4 * kg < H3) st4(a.z3 + rows[rt] * H3 + nt * 16 + 4 * kg, z3[rt][nt]);
+    }
+  // ---- Dense 3: 20 -> C (16 padded), linear
+  f32x4 qa[RT][1];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) qa[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    f32x4 blk[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) blk[rt] = z3[rt][kb];
+    mfma_cols<RT, 1>(smem + L::W4, LD4, kb, j, kg, blk, qa);
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const f32x4 v = qa[rt][0] + ld4(smem + L::B4 + 4 * kg);
+    if (valid[rt] && 4 * kg < a.C) st4(a.q + rows[rt] * a.C + 4 * kg, v);
+  }
+}
+
+// Huber (delta = 1, tf.losses.huber_loss BS_brain.py:86-87) + reverse chain through the MLP.
+// Writes the pre-activation gradients dq, dz3, dz2, dz1 (for k_wgrad) and [dh | dagg].
+template <int F, int RT>
+__global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
+  using L = MlpLds<F>;
+  constexpr int FB = F / 16;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int slot = blockIdx.y;
+  mlp_fill_lds<F>(smem, a, slot, false);
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  int64_t rows[RT];
+  bool valid[RT];
+  f32x4 g4[RT];        // dq block (16 wide, only channels < C non-zero)
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int idx = blockIdx.x * (64 * RT) + wv * (16 * RT) + rt * 16 + j;
+    valid[rt] = idx < a.n_idx;
+    const int64_t row = (int64_t)min(idx, a.n_idx - 1) * a.row_stride + slot * a.base_mul;
+    rows[rt] = row;
+    g4[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (4 * kg < a.C) {
+      const f32x4 qv = ld4(a.q + row * a.C + 4 * kg), yv = ld4(a.y + row * a.C + 4 * kg);
+      float ls = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float err = qv[c] - yv[c];
+        const float ab = fabsf(err), quad = fminf(ab, 1.f);
+        ls += 0.5f * quad * quad + (ab - quad);
+        g4[rt][c] = fminf(fmaxf(err, -1.f), 1.f) * a.inv_denom;
+      }
+      if (valid[rt]) {
+        st4(a.dq + row * a.C + 4 * kg, g4[rt]);
+        a.rowloss[row] = ls;      // C == 4: exactly one lane (kg == 0) per row
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- Dense 3 backward: dz3 = (dq . W4^T) * (z3 > 0)
+  f32x4 d3[2][RT];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) d3[nt][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows<RT>(smem + L::W4, LD4, nt * 16, 0, j, kg, g4, d3[nt]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool in = nt * 16 + 4 * kg < H3;
+      const f32x4 z = in ? ld4(a.z3 + rows[rt] * H3 + nt * 16 + 4 * kg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      d3[nt][rt] = gate4(d3[nt][rt], z);
+      if (valid[rt] && in) st4(a.dz3 + rows[rt] * H3 + nt * 16 + 4 * kg, d3[nt][rt]);
+    }
+  }
+  // ---- Dense 2 backward: dz2 = (dz3 . W3^T) * (z2 > 0)
+  f32x4 d2[3][RT];
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) d2[nt][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) mfma_rows<RT>(smem + L::W3, LD3, nt * 16, kb, j, kg, d3[kb], d2[nt]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const bool in = nt * 16 + 4 * kg < H2;
+      const f32x4 z = in ? ld4(a.z2 + rows[rt] * H2 + nt * 16 + 4 * kg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      d2[nt][rt] = gate4(d2[nt][rt], z);
+      if (valid[rt] && in) st4(a.dz2 + rows[rt] * H2 + nt * 16 + 4 * kg, d2[nt][rt]);
+    }
+  }
+  // ---- Dense 1 backward: dz1 = (dz2 . W2^T) * (z1 > 0)
+  f32x4 d1[5][RT];
+#pragma unroll
+  for (int nt = 0; nt < 5; ++nt) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) d1[nt][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) mfma_rows<RT>(smem + L::W2, LD2, nt * 16, kb, j, kg, d2[kb], d1[nt]);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x4 z = ld4(a.z1 + rows[rt] * H1 + nt * 16 + 4 * kg);
+      d1[nt][rt] = gate4(d1[nt][rt], z);
+      if (valid[rt]) st4(a.dz1 + rows[rt] * H1 + nt * 16 + 4 * kg, d1[nt][rt]);
+    }
+  }
+  // ---- Dense 0 backward (data): [dh | dagg] = dz1 . W1^T   (h rows and agg rows of the image)
+#pragma unroll
+  for (int nt = 0; nt < 2 * FB; ++nt) {
+    const int orow = nt < FB ? nt * 16 : F + XE + (nt - FB) * 16;
+    f32x4 o[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) o[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) mfma_rows<RT>(smem + L::W1, LD1, orow, kb, j, kg, d1[kb], o);
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+      if (valid[rt]) st4(a.gha + rows[rt] * (2 * F) + nt * 16 + 4 * kg, o[rt]);
+  }
+}
+
+// =====================================================================================
+// k_wgrad : dW[k][n] = sum_rows in[row][k] * dpre[row][n],  db[n] = sum_rows dpre[row][n]
+//           per (row-chunk, slot) partial written to a slab; k_reduce_adam sums the slabs
+// =====================================================================================
+struct WgSeg { const float* ptr; int stride; int width; int col; };   // width real cols, col = padded K offset
+struct WgradArgs {
+  WgSeg seg[3]; int n_seg;
+  const float* dpre; int d_stride; int n_real;    // dpre[R][n_real]
+  int kp, np;                                     // padded K and N_out (multiples of 16)
+  RowPad pad;                                     // padded K row -> real row of the weight
+  float* slab; int64_t slab_stride;               // slab[chunk][P]
+  int64_t layer_off; int64_t slot_stride;         // where this layer's (slot 0) block starts in P
+  int n_idx, row_stride, base_mul, chunk;         // idx range of chunk c: [c*chunk, (c+1)*chunk)
+};
+
+constexpr int WG_TR = 64;   // rows per LDS tile
+
+template <int TPW>
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int ldi = a.kp + 4, ldd = a.np + 4;
+  float* sIn = smem;                    // [WG_TR][ldi]
+  float* sD = smem + WG_TR * ldi;       // [WG_TR][ldd]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int slot = blockIdx.y;
+  const int KT = a.kp >> 4, NT = a.np >> 4, ntiles = KT * NT;
+  const int i_begin = blockIdx.x * a.chunk, i_end = min(i_begin + a.chunk, a.n_idx);
+
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int kc4 = a.kp >> 2, nc4 = a.np >> 2;
+  for (int i0 = i_begin; i0 < i_end; i0 += WG_TR) {
+    // ---- stage the input tile [64][kp] (zero padded) and the dpre tile [64][np]
+    for (int i = tid; i < WG_TR * kc4; i += 256) {
+      const int r = i / kc4, c = (i - r * kc4) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i0 + r < i_end) {
+        const int64_t row = (int64_t)(i0 + r) * a.row_stride + slot * a.base_mul;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          if (s < a.n_seg && c >= a.seg[s].col && c < a.seg[s].col + a.seg[s].width && a.seg[s].ptr)
+            v = *reinterpret_cast<const float4*>(a.seg[s].ptr + row * a.seg[s].stride + (c - a.seg[s].col));
+      }
+      *reinterpret_cast<float4*>(sIn + r * ldi + c) = v;
+    }
+    for (int i = tid; i < WG_TR * nc4; i += 256) {
+      const int r = i / nc4, c = (i - r * nc4) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i0 + r < i_end && c < a.n_real) {
+        const int64_t row = (int64_t)(i0 + r) * a.row_stride + slot * a.base_mul;
+        v = *reinterpret_cast<const float4*>(a.dpre + row * a.d_stride + c);
+      }
+      *reinterpret_cast<float4*>(sD + r * ldd + c) = v;
+    }
+    __syncthreads();
+    if (tid < a.np) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < WG_TR; ++r) s += sD[r * ldd + tid];
+      bsum += s;
+    }
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tile = wv + 4 * t;
+      if (tile < ntiles) {
+        const int kt = tile / NT, nt = tile - kt * NT;
+        const float* pa = sIn + (4 * kg) * ldi + kt * 16 + j;
+        const float* pb = sD + (4 * kg) * ldd + nt * 16 + j;
+#pragma unroll
+        for (int r0 = 0; r0 < WG_TR; r0 += 16) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            acc[t] = V2X_MFMA(pa[(r0 + s) * ldi], pb[(r0 + s) * ldd], acc[t]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write this WG's partial: lane holds dW[kt*16 + 4*kg + r][nt*16 + j]
+  float* dst = a.slab + blockIdx.x * a.slab_stride + a.layer_off + slot * a.slot_stride;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = wv + 4 * t;
+    if (tile < ntiles) {
+      const int kt = tile / NT, nt = tile - kt * NT;
+      const int col = nt * 16 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = real_row(a.pad, kt * 16 + 4 * kg + r);
+        if (rr >= 0 && col < a.n_real) dst[(int64_t)rr * a.n_real + col] = acc[t][r];
+      }
+    }
+  }
+  if (tid < a.n_real) dst[(int64_t)a.pad.k_real * a.n_real + tid] = bsum;
+}
+
+// =====================================================================================
+// slab reduction + Keras Adam
+// =====================================================================================
+struct AdamArgs {
+  float* param; float* grad; float* mom; float* vel;
+  const float* slab; int64_t slab_stride; int n_slabs;   // grad = sum of slabs (if slab != null)
+  int64_t n4;                                            // P / 4
+  float lr_t, beta1, beta2, eps;
+  int do_adam;
+};
+
+__global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * 256) {
+    float4 g;
+    if (a.slab) {
+      g = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int c = 0; c < a.n_slabs; ++c) {
+        const float4 t = reinterpret_cast<const float4*>(a.slab + c * a.slab_stride)[i];
+        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+      }
+      reinterpret_cast<float4*>(a.grad)[i] = g;
+    } else {
+      g = reinterpret_cast<const float4*>(a.grad)[i];
+    }
+    if (a.do_adam) {
+      float4 m = reinterpret_cast<float4*>(a.mom)[i], v = reinterpret_cast<float4*>(a.vel)[i];
+      float4 p = reinterpret_cast<float4*>(a.param)[i];
+      const float b1 = a.beta1, b2 = a.beta2, ob1 = 1.f - a.beta1, ob2 = 1.f - a.beta2;
+      m.x = b1 * m.x + ob1 * g.x; m.y = b1 * m.y + ob1 * g.y; m.z = b1 * m.z + ob1 * g.z; m.w = b1 * m.w + ob1 * g.w;
+      v.x = b2 * v.x + ob2 * (g.x * g.x); v.y = b2 * v.y + ob2 * (g.y * g.y);
+      v.z = b2 * v.z + ob2 * (g.z * g.z); v.w = b2 * v.w + ob2 * (g.w * g.w);
+      p.x -= a.lr_t * m.x / (sqrtf(v.x) + a.eps); p.y -= a.lr_t * m.y / (sqrtf(v.y) + a.eps);
+      p.z -= a.lr_t * m.z / (sqrtf(v.z) + a.eps); p.w -= a.lr_t * m.w / (sqrtf(v.w) + a.eps);
+      reinterpret_cast<float4*>(a.mom)[i] = m;
+      reinterpret_cast<float4*>(a.vel)[i] = v;
+      reinterpret_cast<float4*>(a.param)[i] = p;
+    }
+  }
+}
+
+// scalar tail-safe Adam for arbitrary n (v2x_adam_step entry point)
+__global__ __launch_bounds__(256) void k_adam_scalar(float* p, const float* g, float* m, float* v,
+                                                     int64_t n, float lr_t, float b1, float b2, float eps) {
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * (gi * gi);
+    m[i] = mi; v[i] = vi;
+    p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// per-output Huber mean: loss[k] = sum_b rowloss[b*N + k]   (already scaled by 1/(B*C) here)
+__global__ __launch_bounds__(256) void k_loss_reduce(const float* rowloss, float* loss, int n_idx,
+                                                     int row_stride, float inv_denom) {
+  __shared__ float red[256];
+  const int slot = blockIdx.x;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_idx; i += 256) s += rowloss[(int64_t)i * row_stride + slot];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[slot] = red[0] * inv_denom;
+}
+
+}  // namespace v2x

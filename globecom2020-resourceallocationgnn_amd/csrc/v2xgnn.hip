@@ -1,0 +1,924 @@
+// Host side of libv2xgnn.so: the C ABI declared in include/v2xgnn.h.
+// Owns parameters, optimizer state and activation workspaces in HBM, sequences the kernels of
+// kernels.hpp for Model.predict / Model.fit (BS_brain.py:218-235), optionally as a hipGraph.
+#include "../../include/v2xgnn.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace v2x;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct LayerDesc {
+  int64_t off;          // offset of slot 0 in the flat parameter buffer
+  int64_t slot_stride;  // floats per slot: k_real*n_out + n_out
+  int k_real, n_out;    // real weight shape
+  int kp, np;           // padded (multiples of 16)
+  RowPad pad;           // padded K row -> real row
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct ProfRec { int id; hipEvent_t ev0, ev1; };
+
+struct GraphKey {
+  int kind; const void* ptrs[8]; int sizes[6];
+  bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+};
+
+}  // namespace
+
+struct v2x_model {
+  v2x_config cfg;
+  int S, Dn, De, L, F, N, C;
+  std::vector<LayerDesc> gnn, dense;
+  int64_t P = 0;
+  float *params = nullptr, *grads = nullptr, *mom = nullptr, *vel = nullptr;
+  int64_t iterations = 0;
+  // activation workspace (capacity in rows)
+  int64_t cap_rows = 0;
+  std::vector<float*> h, a;
+  float *z1 = nullptr, *z2 = nullptr, *z3 = nullptr, *q = nullptr;
+  float *dq = nullptr, *dz1 = nullptr, *dz2 = nullptr, *dz3 = nullptr, *gha = nullptr, *dpre = nullptr,
+        *rowloss = nullptr;
+  float* loss_dev = nullptr;
+  float* slab = nullptr; int slab_cap = 0;
+  // staging for host-side inputs
+  DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
+  bool have_fwd = false;
+  std::string err;
+  // profiling
+  bool prof = false;
+  std::vector<std::string> prof_names;
+  std::vector<ProfRec> prof_recs;
+  // hipGraph cache
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  bool capturing = false;
+};
+
+namespace {
+
+#define FAIL(m, code, ...)                                   \
+  do {                                                       \
+    char _b[512];                                            \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);                   \
+    if (m) (m)->err = _b; else g_err = _b;                   \
+    return code;                                             \
+  } while (0)
+
+#define HIPCHK(m, call)                                                                     \
+  do {                                                                                      \
+    hipError_t _e = (call);                                                                 \
+    if (_e != hipSuccess) FAIL(m, V2X_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define CHK(x)                 \
+  do {                         \
+    int _r = (x);              \
+    if (_r != V2X_OK) return _r; \
+  } while (0)
+
+int ensure(v2x_model* m, DevBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return V2X_OK;
+  if (m->capturing) FAIL(m, V2X_ESTATE, "buffer growth during graph capture");
+  if (b.p) HIPCHK(m, hipFree(b.p));
+  b.p = nullptr; b.cap = 0;
+  HIPCHK(m, hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return V2X_OK;
+}
+
+template <typename T>
+int dev_alloc(v2x_model* m, T** p, size_t n) {
+  HIPCHK(m, hipMalloc(reinterpret_cast<void**>(p), n * sizeof(T)));
+  return V2X_OK;
+}
+
+int prof_id(v2x_model* m, const char* name) {
+  for (size_t i = 0; i < m->prof_names.size(); ++i)
+    if (m->prof_names[i] == name) return (int)i;
+  m->prof_names.push_back(name);
+  return (int)m->prof_names.size() - 1;
+}
+
+// launch wrapper: optional HIP-event bracket per kernel for in-situ timing
+#define LAUNCH(m, kname, kern, grid, lds, stream, args)                                  \
+  do {                                                                                  \
+    ProfRec _r;                                                                         \
+    const bool _p = (m) && (m)->prof && !(m)->capturing;                                \
+    if (_p) {                                                                           \
+      _r.id = prof_id(m, kname);                                                          \
+      hipEventCreate(&_r.ev0); hipEventCreate(&_r.ev1);                                     \
+      hipEventRecord(_r.ev0, stream);                                                     \
+    }                                                                                   \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, args);                       \
+    if (_p) { hipEventRecord(_r.ev1, stream); (m)->prof_recs.push_back(_r); }             \
+    hipError_t _e = hipGetLastError();                                                  \
+    if (_e != hipSuccess) FAIL(m, V2X_EHIP, "launch %s failed: %s", kname, hipGetErrorString(_e)); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------ layout
+void build_layout(v2x_model* m) {
+  const int F = m->F, Dn = m->Dn, De = m->De, C = m->C;
+  const int xr = Dn + De;   // real rows of the packed xe block
+  int64_t off = 0;
+  auto push = [&](std::vector<LayerDesc>& v, int k_real, int n_out, int kp, int np, RowPad pad) {
+    LayerDesc d;
+    d.off = off; d.k_real = k_real; d.n_out = n_out; d.kp = kp; d.np = np; d.pad = pad;
+    d.slot_stride = (int64_t)k_real * n_out + n_out;
+    off += d.slot_stride * m->S;
+    v.push_back(d);
+  };
+  push(m->gnn, xr + F, F, XE + F, F, RowPad{xr, XE - xr, xr + F});
+  for (int s = 1; s <= m->L; ++s)
+    push(m->gnn, 2 * F + xr, F, 2 * F + XE, F, RowPad{F + xr, XE - xr, 2 * F + xr});
+  push(m->dense, 2 * F + Dn, H1, 2 * F + XE, H1, RowPad{F + Dn, XE - Dn, 2 * F + Dn});
+  push(m->dense, H1, H2, H1, H2P, RowPad{H1, 0, H1});
+  push(m->dense, H2, H3, H2P, H3P, RowPad{H2, H2P - H2, H2});
+  push(m->dense, H3, C, H3P, CP, RowPad{H3, H3P - H3, H3});
+  m->P = off;
+}
+
+// dynamic LDS above 64 KiB has to be opted into per kernel; done once per model at create time so
+// that nothing but kernel launches happens inside a stream capture
+void allow_big_lds(const void* f) { hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
+
+template <int F>
+void set_attrs_f() {
+  allow_big_lds((const void*)k_gemm_rows<F, false, false, false, 1>);
+  allow_big_lds((const void*)k_gemm_rows<F, false, false, false, 2>);
+  allow_big_lds((const void*)k_gemm_rows<F, false, true, false, 1>);
+  allow_big_lds((const void*)k_gemm_rows<F, false, true, false, 2>);
+  allow_big_lds((const void*)k_gemm_rows<F, true, true, false, 1>);
+  allow_big_lds((const void*)k_gemm_rows<F, true, true, false, 2>);
+  allow_big_lds((const void*)k_gemm_rows<F, true, false, true, 1>);
+  allow_big_lds((const void*)k_gemm_rows<F, true, false, true, 2>);
+  allow_big_lds((const void*)k_mlp_fwd<F, 1>);
+  allow_big_lds((const void*)k_mlp_fwd<F, 2>);
+  allow_big_lds((const void*)k_mlp_bwd<F, 1>);
+  allow_big_lds((const void*)k_mlp_bwd<F, 2>);
+}
+
+void set_attrs(int F) {
+  allow_big_lds((const void*)k_agg);
+  allow_big_lds((const void*)k_wgrad<1>); allow_big_lds((const void*)k_wgrad<2>);
+  allow_big_lds((const void*)k_wgrad<3>); allow_big_lds((const void*)k_wgrad<4>);
+  allow_big_lds((const void*)k_wgrad<5>); allow_big_lds((const void*)k_wgrad<7>);
+  allow_big_lds((const void*)k_wgrad<9>); allow_big_lds((const void*)k_wgrad<12>);
+  if (F == 16) set_attrs_f<16>();
+  if (F == 32) set_attrs_f<32>();
+  if (F == 64) set_attrs_f<64>();
+}
+
+struct RowMapH { int n_idx, row_stride, base_mul, grid_y; };
+RowMapH row_map(const v2x_model* m, int n_rows) {
+  RowMapH r;
+  if (m->S == 1) { r.n_idx = n_rows; r.row_stride = 1; r.base_mul = 0; r.grid_y = 1; }
+  else { r.n_idx = n_rows / m->N; r.row_stride = m->N; r.base_mul = 1; r.grid_y = m->N; }
+  return r;
+}
+
+int ensure_rows(v2x_model* m, int64_t R) {
+  if (R <= m->cap_rows) return V2X_OK;
+  if (m->capturing) FAIL(m, V2X_ESTATE, "workspace growth during graph capture");
+  auto re = [&](float*& p, int64_t w) -> int {
+    if (p) HIPCHK(m, hipFree(p));
+    p = nullptr;
+    HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&p), (size_t)(R * w) * sizeof(float)));
+    return V2X_OK;
+  };
+  const int F = m->F;
+  for (int s = 0; s <= m->L; ++s) { CHK(re(m->h[s], F)); CHK(re(m->a[s], F)); }
+  CHK(re(m->z1, H1)); CHK(re(m->z2, H2)); CHK(re(m->z3, H3)); CHK(re(m->q, m->C));
+  CHK(re(m->dq, m->C)); CHK(re(m->dz1, H1)); CHK(re(m->dz2, H2)); CHK(re(m->dz3, H3));
+  CHK(re(m->gha, 2 * F)); CHK(re(m->dpre, F)); CHK(re(m->rowloss, 1));
+  m->cap_rows = R;
+  return V2X_OK;
+}
+
+constexpr int WG_ROWS_PER_CHUNK = 256;
+constexpr int WG_MAX_CHUNKS = 512;
+
+int wgrad_chunks(int n_idx, int* chunk_out) {
+  int nc = (n_idx + WG_ROWS_PER_CHUNK - 1) / WG_ROWS_PER_CHUNK;
+  if (nc < 1) nc = 1;
+  if (nc > WG_MAX_CHUNKS) nc = WG_MAX_CHUNKS;
+  int chunk = (n_idx + nc - 1) / nc;
+  chunk = (chunk + WG_TR - 1) / WG_TR * WG_TR;
+  if (chunk < WG_TR) chunk = WG_TR;
+  nc = (n_idx + chunk - 1) / chunk;
+  if (nc < 1) nc = 1;
+  *chunk_out = chunk;
+  return nc;
+}
+
+int ensure_slabs(v2x_model* m, int nc) {
+  if (nc <= m->slab_cap) return V2X_OK;
+  if (m->capturing) FAIL(m, V2X_ESTATE, "slab growth during graph capture");
+  if (m->slab) HIPCHK(m, hipFree(m->slab));
+  m->slab = nullptr;
+  HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->slab), (size_t)nc * m->P * sizeof(float)));
+  HIPCHK(m, hipMemset(m->slab, 0, (size_t)nc * m->P * sizeof(float)));
+  m->slab_cap = nc;
+  return V2X_OK;
+}
+
+// ------------------------------------------------------------------------------------ batches
+struct DevBatch {
+  int B, R, E, max_nodes, max_edges;
+  const float* xe; const float* nbr;
+  const int32_t* goff; const int32_t* rp; const int32_t* ci;
+};
+
+int resolve_batch(v2x_model* m, const v2x_batch* b, DevBatch* d, hipStream_t st) {
+  if (!b || b->n_graphs <= 0 || b->n_rows <= 0 || !b->xe || !b->row_ptr || (b->n_edges > 0 && !b->col_idx))
+    FAIL(m, V2X_EINVAL, "batch: null pointer or non-positive size");
+  if (!m->cfg.variable_graphs && b->n_rows != b->n_graphs * m->N)
+    FAIL(m, V2X_EINVAL, "batch: n_rows (%d) != n_graphs*n_nodes (%d*%d)", b->n_rows, b->n_graphs, m->N);
+  if (m->cfg.variable_graphs && !b->graph_off) FAIL(m, V2X_EINVAL, "batch: variable_graphs needs graph_off");
+  if (b->max_nodes <= 0 || b->max_edges < 0) FAIL(m, V2X_EINVAL, "batch: max_nodes/max_edges not set");
+  d->B = b->n_graphs; d->R = b->n_rows; d->E = b->n_edges;
+  d->max_nodes = b->max_nodes; d->max_edges = b->max_edges;
+  if (b->on_device) {
+    d->xe = b->xe; d->nbr = b->nbr_init; d->goff = b->graph_off; d->rp = b->row_ptr; d->ci = b->col_idx;
+    return V2X_OK;
+  }
+  const size_t R = b->n_rows;
+  CHK(ensure(m, m->st_xe, R * XE * sizeof(float)));
+  HIPCHK(m, hipMemcpyAsync(m->st_xe.p, b->xe, R * XE * sizeof(float), hipMemcpyHostToDevice, st));
+  d->xe = (const float*)m->st_xe.p;
+  d->nbr = nullptr;
+  if (b->nbr_init) {
+    CHK(ensure(m, m->st_nbr, R * m->F * sizeof(float)));
+    HIPCHK(m, hipMemcpyAsync(m->st_nbr.p, b->nbr_init, R * m->F * sizeof(float), hipMemcpyHostToDevice, st));
+    d->nbr = (const float*)m->st_nbr.p;
+  }
+  d->goff = nullptr;
+  if (b->graph_off) {
+    CHK(ensure(m, m->st_goff, (size_t)(b->n_graphs + 1) * 4));
+    HIPCHK(m, hipMemcpyAsync(m->st_goff.p, b->graph_off, (size_t)(b->n_graphs + 1) * 4, hipMemcpyHostToDevice, st));
+    d->goff = (const int32_t*)m->st_goff.p;
+  }
+  CHK(ensure(m, m->st_rp, (R + 1) * 4));
+  HIPCHK(m, hipMemcpyAsync(m->st_rp.p, b->row_ptr, (R + 1) * 4, hipMemcpyHostToDevice, st));
+  d->rp = (const int32_t*)m->st_rp.p;
+  CHK(ensure(m, m->st_ci, (size_t)(b->n_edges > 0 ? b->n_edges : 1) * 4));
+  if (b->n_edges > 0)
+    HIPCHK(m, hipMemcpyAsync(m->st_ci.p, b->col_idx, (size_t)b->n_edges * 4, hipMemcpyHostToDevice, st));
+  d->ci = (const int32_t*)m->st_ci.p;
+  return V2X_OK;
+}
+
+// ------------------------------------------------------------------------------------ launchers
+int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, int N, int F, const float* src, int src_stride,
+               const float* add, int add_stride, const float* mask, float* out, int transpose) {
+  if (F < 16 || F > 256 || (F & (F - 1))) FAIL(m, V2X_EINVAL, "agg: feat_dim must be a power of two in [16,256]");
+  AggArgs a;
+  a.src = src; a.src_stride = src_stride; a.add = add; a.add_stride = add_stride; a.mask = mask; a.out = out;
+  a.graph_off = d.goff; a.row_ptr = d.rp; a.col_idx = d.ci;
+  a.n_graphs = d.B; a.n_nodes = N; a.F = F;
+  int sh = 0; while ((4 << sh) < F) ++sh;
+  a.lpr_shift = sh;
+  a.mask_words = (d.max_nodes + 31) / 32;
+  a.transpose = transpose;
+  const int nworkers = 256 >> sh;
+  const size_t per_graph = (size_t)d.max_nodes * F * 4 + (size_t)(d.max_nodes + 1) * 4 + (size_t)d.max_edges * 4 +
+                           (transpose ? (size_t)d.max_nodes * a.mask_words * 4 : 0);
+  int gpw = 1;
+  while (gpw * 2 <= nworkers && gpw * 2 <= 16 && (size_t)(gpw * 2) * per_graph <= 48 * 1024 && gpw * 2 <= d.B) gpw *= 2;
+  a.gpw = gpw;
+  a.rows_cap = gpw * d.max_nodes;
+  a.edges_cap = gpw * d.max_edges;
+  const size_t lds = (size_t)a.rows_cap * F * 4 + (size_t)(a.rows_cap + 1) * 4 + (size_t)(gpw + 1) * 4 +
+                     (size_t)a.edges_cap * 4 + (transpose ? (size_t)a.rows_cap * a.mask_words * 4 : 0);
+  if (lds > 160 * 1024) FAIL(m, V2X_EINVAL, "agg: graph tile (%zu B) exceeds the 160 KiB LDS", lds);
+  const dim3 grid((d.B + gpw - 1) / gpw);
+  LAUNCH(m, transpose ? "k_agg_bwd" : "k_agg_fwd", k_agg, grid, lds, st, a);
+  return V2X_OK;
+}
+
+template <int F, bool HAS0, bool HAS2, bool DGRAD>
+int launch_gemm_t(v2x_model* m, hipStream_t st, GemmArgs& a, int grid_y, const char* name) {
+  constexpr int FB = F / 16;
+  constexpr int KB = DGRAD ? FB : ((HAS0 ? FB : 0) + 1 + (HAS2 ? FB : 0));
+  constexpr int KP = DGRAD ? (2 * F + XE) : KB * 16;
+  const size_t lds = (size_t)(KP * (F + 4) + F) * 4;
+  if (a.n_idx >= 4096) {
+    auto k = k_gemm_rows<F, HAS0, HAS2, DGRAD, 2>;LAUNCH(m, name, k, dim3((a.n_idx + 127) / 128, grid_y), lds, st, a);
+  } else {
+    auto k = k_gemm_rows<F, HAS0, HAS2, DGRAD, 1>;LAUNCH(m, name, k, dim3((a.n_idx + 63) / 64, grid_y), lds, st, a);
+  }
+  return V2X_OK;
+}
+
+template <int F>
+int launch_node_fwd_f(v2x_model* m, hipStream_t st, int stage, GemmArgs& a, int grid_y) {
+  if (stage == 0) {
+    if (a.seg2) return launch_gemm_t<F, false, true, false>(m, st, a, grid_y, "k_node_fwd_embed");
+    return launch_gemm_t<F, false, false, false>(m, st, a, grid_y, "k_node_fwd_embed");
+  }
+  return launch_gemm_t<F, true, true, false>(m, st, a, grid_y, "k_node_fwd");
+}
+
+// GNNLayer forward of `stage` over n_rows
+int launch_node_fwd(v2x_model* m, hipStream_t st, int stage, int n_rows, const float* xe, const float* h_prev,
+                    const float* agg_prev, float* out) {
+  const LayerDesc& ld = m->gnn[stage];
+  const RowMapH rm = row_map(m, n_rows);
+  GemmArgs a;
+  a.seg0 = h_prev; a.seg0_stride = m->F; a.xe = xe; a.seg2 = agg_prev; a.seg2_stride = m->F;
+  a.W = m->params + ld.off; a.slot_stride = ld.slot_stride; a.pad = ld.pad;
+  a.out = out; a.out_stride = m->F; a.relu = stage < m->L ? 1 : 0;
+  a.n_idx = rm.n_idx; a.row_stride = rm.row_stride; a.base_mul = rm.base_mul;
+  if (stage > 0 && (!h_prev || !agg_prev)) FAIL(m, V2X_EINVAL, "node_update: stage>0 needs h_prev and agg_prev");
+  switch (m->F) {
+    case 16: return launch_node_fwd_f<16>(m, st, stage, a, rm.grid_y);
+    case 32: return launch_node_fwd_f<32>(m, st, stage, a, rm.grid_y);
+    case 64: return launch_node_fwd_f<64>(m, st, stage, a, rm.grid_y);
+  }
+  FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
+}
+
+// data gradient of stage >= 1: gha[R][2F] = [dpre.W1h^T | dpre.W3^T]
+int launch_dgrad(v2x_model* m, hipStream_t st, int stage, int n_rows, const float* dpre, float* gha) {
+  const LayerDesc& ld = m->gnn[stage];
+  const RowMapH rm = row_map(m, n_rows);
+  GemmArgs a;
+  a.seg0 = dpre; a.seg0_stride = m->F; a.xe = nullptr; a.seg2 = nullptr; a.seg2_stride = 0;
+  a.W = m->params + ld.off; a.slot_stride = ld.slot_stride; a.pad = ld.pad;
+  a.out = gha; a.out_stride = 2 * m->F; a.relu = 0;
+  a.n_idx = rm.n_idx; a.row_stride = rm.row_stride; a.base_mul = rm.base_mul;
+  switch (m->F) {
+    case 16: return launch_gemm_t<16, true, false, true>(m, st, a, rm.grid_y, "k_node_dgrad");
+    case 32: return launch_gemm_t<32, true, false, true>(m, st, a, rm.grid_y, "k_node_dgrad");
+    case 64: return launch_gemm_t<64, true, false, true>(m, st, a, rm.grid_y, "k_node_dgrad");
+  }
+  FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
+}
+
+void mlp_args(v2x_model* m, MlpArgs& a, int n_rows, const float* xe, const float* h, const float* agg) {
+  const RowMapH rm = row_map(m, n_rows);
+  memset(&a, 0, sizeof(a));
+  a.h = h; a.xe = xe; a.agg = agg;
+  for (int i = 0; i < 4; ++i) { a.W[i] = m->params + m->dense[i].off; a.slot_stride[i] = m->dense[i].slot_stride; }
+  a.C = m->C;
+  a.z1 = m->z1; a.z2 = m->z2; a.z3 = m->z3; a.q = m->q;
+  a.dq = m->dq; a.dz1 = m->dz1; a.dz2 = m->dz2; a.dz3 = m->dz3; a.gha = m->gha; a.rowloss = m->rowloss;
+  a.n_idx = rm.n_idx; a.row_stride = rm.row_stride; a.base_mul = rm.base_mul;
+}
+
+template <int F>
+int launch_mlp_f(v2x_model* m, hipStream_t st, MlpArgs& a, int grid_y, bool bwd) {
+  const size_t lds = (size_t)MlpLds<F>::TOTAL * 4;
+  const bool big = a.n_idx >= 4096;
+#define V2X_MLP_CASE(KERN, RT, NAME)                                                                      \
+  {                                                                                                       \
+    auto k = KERN<F, RT>;                                                                                 \
+    LAUNCH(m, NAME, k, dim3((a.n_idx + 64 * RT - 1) / (64 * RT), grid_y), lds, st, a);                    \
+  }
+  if (!bwd) { if (big) V2X_MLP_CASE(k_mlp_fwd, 2, "k_mlp_fwd") else V2X_MLP_CASE(k_mlp_fwd, 1, "k_mlp_fwd") }
+  else      { if (big) V2X_MLP_CASE(k_mlp_bwd, 2, "k_mlp_bwd") else V2X_MLP_CASE(k_mlp_bwd, 1, "k_mlp_bwd") }
+#undef V2X_MLP_CASE
+  return V2X_OK;
+}
+
+int launch_mlp(v2x_model* m, hipStream_t st, MlpArgs& a, bool bwd) {
+  const int gy = m->S == 1 ? 1 : m->N;
+  switch (m->F) {
+    case 16: return launch_mlp_f<16>(m, st, a, gy, bwd);
+    case 32: return launch_mlp_f<32>(m, st, a, gy, bwd);
+    case 64: return launch_mlp_f<64>(m, st, a, gy, bwd);
+  }
+  FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
+}
+
+// weight gradient of one layer into the slabs
+int launch_wgrad(v2x_model* m, hipStream_t st, const LayerDesc& ld, int n_rows, const WgSeg* segs, int n_seg,
+                 const float* dpre, int d_stride, const char* name) {
+  const RowMapH rm = row_map(m, n_rows);
+  int chunk;
+  const int nc = wgrad_chunks(rm.n_idx, &chunk);
+  CHK(ensure_slabs(m, nc));
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int i = 0; i < n_seg; ++i) a.seg[i] = segs[i];
+  a.n_seg = n_seg;
+  a.dpre = dpre; a.d_stride = d_stride; a.n_real = ld.n_out;
+  a.kp = ld.kp; a.np = ld.np; a.pad = ld.pad;
+  a.slab = m->slab; a.slab_stride = m->P; a.layer_off = ld.off; a.slot_stride = ld.slot_stride;
+  a.n_idx = rm.n_idx; a.row_stride = rm.row_stride; a.base_mul = rm.base_mul; a.chunk = chunk;
+  const int ntiles = (ld.kp / 16) * (ld.np / 16);
+  const int tpw = (ntiles + 3) / 4;
+  const size_t lds = (size_t)WG_TR * (ld.kp + 4 + ld.np + 4) * 4;
+  const dim3 grid(nc, rm.grid_y);
+#define V2X_WG_CASE(T)                                                                                   \
+  if (tpw <= T) {                                                                                        \
+    auto k = k_wgrad<T>;                                                                                 \
+    LAUNCH(m, name, k, grid, lds, st, a);                                                                \
+    return V2X_OK;                                                                                       \
+  }
+  V2X_WG_CASE(1) V2X_WG_CASE(2) V2X_WG_CASE(3) V2X_WG_CASE(4) V2X_WG_CASE(5) V2X_WG_CASE(7) V2X_WG_CASE(9) V2X_WG_CASE(12)
+#undef V2X_WG_CASE
+  FAIL(m, V2X_EINVAL, "wgrad: %d tiles per wave unsupported", tpw);
+}
+
+int wgrad_gnn(v2x_model* m, hipStream_t st, int stage, int n_rows, const float* xe, const float* h_prev,
+              const float* agg_prev, const float* dpre) {
+  const int F = m->F;
+  WgSeg s[3];
+  int n = 0;
+  if (stage > 0) { s[n++] = WgSeg{h_prev, F, F, 0}; s[n++] = WgSeg{xe, XE, XE, F}; s[n++] = WgSeg{agg_prev, F, F, F + XE}; }
+  else { s[n++] = WgSeg{xe, XE, XE, 0}; s[n++] = WgSeg{agg_prev /* neighbour-init or null */, F, F, XE}; }
+  return launch_wgrad(m, st, m->gnn[stage], n_rows, s, n, dpre, F, stage ? "k_wgrad_gnn" : "k_wgrad_embed");
+}
+
+int wgrad_mlp(v2x_model* m, hipStream_t st, int n_rows, const float* xe, const float* h, const float* agg) {
+  const int F = m->F;
+  WgSeg s0[3] = {WgSeg{h, F, F, 0}, WgSeg{xe, XE, XE, F}, WgSeg{agg, F, F, F + XE}};
+  CHK(launch_wgrad(m, st, m->dense[0], n_rows, s0, 3, m->dz1, H1, "k_wgrad_dense0"));
+  WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0}};
+  CHK(launch_wgrad(m, st, m->dense[1], n_rows, s1, 1, m->dz2, H2, "k_wgrad_dense1"));
+  WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0}};
+  CHK(launch_wgrad(m, st, m->dense[2], n_rows, s2, 1, m->dz3, H3, "k_wgrad_dense2"));
+  WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0}};
+  CHK(launch_wgrad(m, st, m->dense[3], n_rows, s3, 1, m->dq, m->C, "k_wgrad_dense3"));
+  return V2X_OK;
+}
+
+int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_rows, bool from_slabs, bool do_adam, float* grad_dst) {
+  AdamArgs a;
+  memset(&a, 0, sizeof(a));
+  a.param = m->params; a.grad = grad_dst ? grad_dst : m->grads; a.mom = m->mom; a.vel = m->vel;
+  if (from_slabs) {
+    int chunk;
+    a.n_slabs = wgrad_chunks(row_map(m, n_rows).n_idx, &chunk);
+    a.slab = m->slab; a.slab_stride = m->P;
+  }
+  a.n4 = m->P / 4;
+  a.do_adam = do_adam ? 1 : 0;
+  if (do_adam) {
+    m->iterations += 1;
+    const double t = (double)m->iterations;
+    a.lr_t = (float)(m->cfg.lr * std::sqrt(1.0 - std::pow((double)m->cfg.beta2, t)) / (1.0 - std::pow((double)m->cfg.beta1, t)));
+    a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
+  }
+  int blocks = (int)((a.n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  LAUNCH(m, do_adam ? (from_slabs ? "k_reduce_adam" : "k_adam") : "k_grad_reduce", k_reduce_adam, dim3(blocks), 0, st, a);
+  return V2X_OK;
+}
+
+// ------------------------------------------------------------------------------------ passes
+int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d) {
+  const int F = m->F, L = m->L, R = d.R;
+  CHK(launch_node_fwd(m, st, 0, R, d.xe, nullptr, d.nbr, m->h[0]));
+  CHK(launch_agg(m, st, d, m->N, F, m->h[0], F, nullptr, 0, nullptr, m->a[0], 0));
+  for (int s = 1; s <= L; ++s) {
+    CHK(launch_node_fwd(m, st, s, R, d.xe, m->h[s - 1], m->a[s - 1], m->h[s]));
+    CHK(launch_agg(m, st, d, m->N, F, m->h[s], F, nullptr, 0, nullptr, m->a[s], 0));
+  }
+  MlpArgs a;
+  mlp_args(m, a, R, d.xe, m->h[L], m->a[L]);
+  CHK(launch_mlp(m, st, a, false));
+  return V2X_OK;
+}
+
+float loss_denominator(const v2x_model* m, int n_global) {
+  // fixed-N: per-output mean over (B_global, C)  (tf.losses.huber_loss per output, BS_brain.py:214)
+  // variable graphs: n_global counts node rows; single mean over (rows_global, C)
+  return (float)((double)n_global * m->C);
+}
+
+int run_backward(v2x_model* m, hipStream_t st, const DevBatch& d, const float* y_dev, int n_global) {
+  const int F = m->F, L = m->L, R = d.R;
+  MlpArgs a;
+  mlp_args(m, a, R, d.xe, m->h[L], m->a[L]);
+  a.y = y_dev;
+  a.inv_denom = 1.0f / loss_denominator(m, n_global);
+  CHK(launch_mlp(m, st, a, true));
+  CHK(wgrad_mlp(m, st, R, d.xe, m->h[L], m->a[L]));
+  for (int s = L; s >= 1; --s) {
+    // dpre_s = (dh_direct + Agg^T(dagg)) * relu'(h_s)
+    CHK(launch_agg(m, st, d, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, s < L ? m->h[s] : nullptr, m->dpre, 1));
+    CHK(wgrad_gnn(m, st, s, R, d.xe, m->h[s - 1], m->a[s - 1], m->dpre));
+    CHK(launch_dgrad(m, st, s, R, m->dpre, m->gha));
+  }
+  CHK(launch_agg(m, st, d, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, m->h[0], m->dpre, 1));
+  CHK(wgrad_gnn(m, st, 0, R, d.xe, nullptr, d.nbr, m->dpre));
+  // per-output Huber means
+  if (m->cfg.variable_graphs) {
+    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, m->rowloss, m->loss_dev, R, 1, a.inv_denom);
+  } else {
+    hipLaunchKernelGGL(k_loss_reduce, dim3(m->N), dim3(256), 0, st, m->rowloss, m->loss_dev, d.B, m->N, a.inv_denom);
+  }
+  return V2X_OK;
+}
+
+int resolve_y(v2x_model* m, const float* y, int y_on_device, int R, hipStream_t st, const float** out) {
+  if (!y) FAIL(m, V2X_EINVAL, "targets y are null");
+  if (y_on_device) { *out = y; return V2X_OK; }
+  CHK(ensure(m, m->st_y, (size_t)R * m->C * sizeof(float)));
+  HIPCHK(m, hipMemcpyAsync(m->st_y.p, y, (size_t)R * m->C * sizeof(float), hipMemcpyHostToDevice, st));
+  *out = (const float*)m->st_y.p;
+  return V2X_OK;
+}
+
+int emit_loss(v2x_model* m, float* loss_out, int loss_on_device, hipStream_t st) {
+  if (!loss_out) return V2X_OK;
+  const int n = m->cfg.variable_graphs ? 1 : m->N;
+  if (loss_on_device) {
+    HIPCHK(m, hipMemcpyAsync(loss_out, m->loss_dev, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    HIPCHK(m, hipMemcpyAsync(loss_out, m->loss_dev, n * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIPCHK(m, hipStreamSynchronize(st));
+  }
+  return V2X_OK;
+}
+
+// Run `body` either eagerly or through a cached hipGraph keyed on the pointers / sizes it bakes in.
+template <typename Body>
+int run_maybe_graph(v2x_model* m, hipStream_t st, const GraphKey& key, Body body) {
+  const bool want = m->cfg.use_graph && !m->prof && st != nullptr;
+  if (!want) return body();
+  auto it = m->graphs.find(key);
+  if (it != m->graphs.end()) {
+    HIPCHK(m, hipGraphLaunch(it->second, st));
+    return V2X_OK;
+  }
+  // make sure every lazily-sized buffer and function attribute exists before capture: run once eagerly
+  // is not possible without side effects on optimizer state, so callers pre-size buffers (see below).
+  hipGraph_t g = nullptr;
+  HIPCHK(m, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  m->capturing = true;
+  const int r = body();
+  m->capturing = false;
+  hipError_t e = hipStreamEndCapture(st, &g);
+  if (r != V2X_OK) { if (g) hipGraphDestroy(g); return r; }
+  if (e != hipSuccess) FAIL(m, V2X_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+  hipGraphExec_t ge = nullptr;
+  e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess) FAIL(m, V2X_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  if (m->graphs.size() >= 16) {
+    for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+    m->graphs.clear();
+  }
+  m->graphs[key] = ge;
+  HIPCHK(m, hipGraphLaunch(ge, st));
+  return V2X_OK;
+}
+
+GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
+  GraphKey k;
+  memset(&k, 0, sizeof(k));
+  k.kind = kind;
+  k.ptrs[0] = d.xe; k.ptrs[1] = d.nbr; k.ptrs[2] = d.goff; k.ptrs[3] = d.rp; k.ptrs[4] = d.ci; k.ptrs[5] = y;
+  k.sizes[0] = d.B; k.sizes[1] = d.R; k.sizes[2] = d.E; k.sizes[3] = d.max_nodes; k.sizes[4] = d.max_edges;
+  k.sizes[5] = n_global;
+  return k;
+}
+
+int presize(v2x_model* m, const DevBatch& d) {
+  CHK(ensure_rows(m, d.R));
+  int chunk;
+  CHK(ensure_slabs(m, wgrad_chunks(row_map(m, d.R).n_idx, &chunk)));
+  return V2X_OK;
+}
+
+}  // namespace
+
+// ======================================================================================= C ABI
+extern "C" {
+
+const char* v2x_version(void) { return "v2xgnn 0.1 (gfx950)"; }
+
+const char* v2x_last_error(const v2x_model* m) { return m ? m->err.c_str() : g_err.c_str(); }
+
+int v2x_create(const v2x_config* cfg, v2x_model** out) {
+  v2x_model* nullm = nullptr;
+  if (!cfg || !out) FAIL(nullm, V2X_EINVAL, "v2x_create: null argument");
+  *out = nullptr;
+  if (cfg->n_channels != 4) FAIL(nullm, V2X_EINVAL, "n_channels must be 4 in this build (got %d)", cfg->n_channels);
+  if (cfg->feat_dim != 16 && cfg->feat_dim != 32 && cfg->feat_dim != 64)
+    FAIL(nullm, V2X_EINVAL, "feat_dim must be 16, 32 or 64 in this build (got %d)", cfg->feat_dim);
+  if (cfg->n_nodes < 1) FAIL(nullm, V2X_EINVAL, "n_nodes must be >= 1");
+  if (cfg->n_mp_layers < 1 || cfg->n_mp_layers > 8) FAIL(nullm, V2X_EINVAL, "n_mp_layers must be in [1,8]");
+  if (cfg->variable_graphs && !cfg->share_weights)
+    FAIL(nullm, V2X_EINVAL, "variable_graphs requires share_weights (per-node weights need a fixed node count)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    FAIL(nullm, V2X_EHIP, "no HIP device available: the v2xgnn engine has no CPU fallback");
+  if (cfg->device < 0 || cfg->device >= ndev) FAIL(nullm, V2X_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
+  if (hipSetDevice(cfg->device) != hipSuccess) FAIL(nullm, V2X_EHIP, "hipSetDevice(%d) failed", cfg->device);
+
+  v2x_model* m = new v2x_model();
+  m->cfg = *cfg;
+  if (m->cfg.lr <= 0.f) m->cfg.lr = 1e-3f;
+  if (m->cfg.beta1 <= 0.f) m->cfg.beta1 = 0.5f;      // BS_brain.py:212
+  if (m->cfg.beta2 <= 0.f) m->cfg.beta2 = 0.999f;
+  if (m->cfg.eps <= 0.f) m->cfg.eps = 1e-7f;         // K.epsilon()
+  m->N = cfg->n_nodes; m->C = cfg->n_channels; m->F = cfg->feat_dim; m->L = cfg->n_mp_layers;
+  m->S = cfg->share_weights ? 1 : cfg->n_nodes;
+  m->Dn = 2 * m->C + 1; m->De = m->C;               // BS_brain.py:101-102 with node_info=3, edge_info=1
+  build_layout(m);
+  set_attrs(m->F);
+  m->h.assign(m->L + 1, nullptr);
+  m->a.assign(m->L + 1, nullptr);
+  auto fail = [&](const char* what) {
+    g_err = std::string("v2x_create: ") + what + ": " + m->err;
+    v2x_destroy(m);
+    return V2X_EHIP;
+  };
+  const size_t pb = (size_t)m->P * sizeof(float);
+  if (dev_alloc(m, &m->params, m->P) || dev_alloc(m, &m->grads, m->P) || dev_alloc(m, &m->mom, m->P) ||
+      dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1))
+    return fail("allocation");
+  if (hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
+    return fail("memset");
+  *out = m;
+  return V2X_OK;
+}
+
+void v2x_destroy(v2x_model* m) {
+  if (!m) return;
+  hipSetDevice(m->cfg.device);
+  hipDeviceSynchronize();
+  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& r : m->prof_recs) { hipEventDestroy(r.ev0); hipEventDestroy(r.ev1); }
+  float* ptrs[] = {m->params, m->grads, m->mom, m->vel, m->z1, m->z2, m->z3, m->q, m->dq, m->dz1, m->dz2, m->dz3,
+                   m->gha, m->dpre, m->rowloss, m->loss_dev, m->slab};
+  for (float* p : ptrs) if (p) hipFree(p);
+  for (float* p : m->h) if (p) hipFree(p);
+  for (float* p : m->a) if (p) hipFree(p);
+  DevBuf* bufs[] = {&m->st_xe, &m->st_nbr, &m->st_goff, &m->st_rp, &m->st_ci, &m->st_y, &m->st_q};
+  for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+  delete m;
+}
+
+int64_t v2x_param_count(const v2x_model* m) { return m ? m->P : 0; }
+float* v2x_param_ptr(v2x_model* m) { return m ? m->params : nullptr; }
+float* v2x_grad_ptr(v2x_model* m) { return m ? m->grads : nullptr; }
+
+int v2x_get_weights(v2x_model* m, float* host_out, void* stream) {
+  if (!m || !host_out) FAIL(m, V2X_EINVAL, "get_weights: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(m, hipMemcpyAsync(host_out, m->params, (size_t)m->P * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(m, hipStreamSynchronize(st));
+  return V2X_OK;
+}
+
+int v2x_set_weights(v2x_model* m, const float* host_in, void* stream) {
+  if (!m || !host_in) FAIL(m, V2X_EINVAL, "set_weights: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(m, hipMemcpyAsync(m->params, host_in, (size_t)m->P * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(m, hipStreamSynchronize(st));
+  return V2X_OK;
+}
+
+int v2x_copy_weights(v2x_model* dst, const v2x_model* src, void* stream) {
+  if (!dst || !src) FAIL(dst, V2X_EINVAL, "copy_weights: null argument");
+  if (dst->P != src->P || dst->F != src->F || dst->N != src->N || dst->S != src->S || dst->L != src->L)
+    FAIL(dst, V2X_EINVAL, "copy_weights: models have different shapes");
+  HIPCHK(dst, hipMemcpyAsync(dst->params, src->params, (size_t)dst->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return V2X_OK;
+}
+
+int v2x_get_optimizer_state(v2x_model* m, float* host_m, float* host_v, int64_t* iterations, void* stream) {
+  if (!m) FAIL(m, V2X_EINVAL, "null model");
+  hipStream_t st = (hipStream_t)stream;
+  if (host_m) HIPCHK(m, hipMemcpyAsync(host_m, m->mom, (size_t)m->P * 4, hipMemcpyDeviceToHost, st));
+  if (host_v) HIPCHK(m, hipMemcpyAsync(host_v, m->vel, (size_t)m->P * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(m, hipStreamSynchronize(st));
+  if (iterations) *iterations = m->iterations;
+  return V2X_OK;
+}
+
+int v2x_set_optimizer_state(v2x_model* m, const float* host_m, const float* host_v, int64_t iterations, void* stream) {
+  if (!m) FAIL(m, V2X_EINVAL, "null model");
+  hipStream_t st = (hipStream_t)stream;
+  if (host_m) HIPCHK(m, hipMemcpyAsync(m->mom, host_m, (size_t)m->P * 4, hipMemcpyHostToDevice, st));
+  if (host_v) HIPCHK(m, hipMemcpyAsync(m->vel, host_v, (size_t)m->P * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(m, hipStreamSynchronize(st));
+  m->iterations = iterations;
+  return V2X_OK;
+}
+
+int v2x_forward(v2x_model* m, const v2x_batch* b, float* q_out, int q_on_device, void* stream) {
+  if (!m || !q_out) FAIL(m, V2X_EINVAL, "forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  DevBatch d;
+  CHK(resolve_batch(m, b, &d, st));
+  CHK(presize(m, d));
+  CHK(run_maybe_graph(m, st, make_key(1, d, nullptr, 0), [&]() { return run_forward(m, st, d); }));
+  m->have_fwd = true;
+  const size_t qb = (size_t)d.R * m->C * sizeof(float);
+  if (q_on_device) {
+    HIPCHK(m, hipMemcpyAsync(q_out, m->q, qb, hipMemcpyDeviceToDevice, st));
+  } else {
+    HIPCHK(m, hipMemcpyAsync(q_out, m->q, qb, hipMemcpyDeviceToHost, st));
+    HIPCHK(m, hipStreamSynchronize(st));
+  }
+  return V2X_OK;
+}
+
+static int fwd_bwd(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device, int32_t n_global,
+                   float* loss_out, int loss_on_device, void* stream, bool with_adam) {
+  if (!m) FAIL(m, V2X_EINVAL, "null model");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  DevBatch d;
+  CHK(resolve_batch(m, b, &d, st));
+  if (n_global <= 0) n_global = m->cfg.variable_graphs ? d.R : d.B;
+  const float* yd;
+  CHK(resolve_y(m, y, y_on_device, d.R, st, &yd));
+  CHK(presize(m, d));
+  if (with_adam) {
+    // lr_t depends on the iteration count, so the Adam node stays outside the replayed graph
+    CHK(run_maybe_graph(m, st, make_key(2, d, yd, n_global), [&]() {
+      CHK(run_forward(m, st, d));
+      return run_backward(m, st, d, yd, n_global);
+    }));
+    CHK(launch_reduce_adam(m, st, d.R, true, true, nullptr));
+  } else {
+    CHK(run_maybe_graph(m, st, make_key(3, d, yd, n_global), [&]() {
+      CHK(run_forward(m, st, d));
+      CHK(run_backward(m, st, d, yd, n_global));
+      return launch_reduce_adam(m, st, d.R, true, false, nullptr);
+    }));
+  }
+  m->have_fwd = true;
+  return emit_loss(m, loss_out, loss_on_device, st);
+}
+
+int v2x_train_step(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device, int32_t n_graphs_global,
+                   float* loss_out, int loss_on_device, void* stream) {
+  return fwd_bwd(m, b, y, y_on_device, n_graphs_global, loss_out, loss_on_device, stream, true);
+}
+
+int v2x_forward_backward(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device, int32_t n_graphs_global,
+                         float* loss_out, int loss_on_device, void* stream) {
+  return fwd_bwd(m, b, y, y_on_device, n_graphs_global, loss_out, loss_on_device, stream, false);
+}
+
+int v2x_apply_gradients(v2x_model* m, void* stream) {
+  if (!m) FAIL(m, V2X_EINVAL, "null model");
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  return launch_reduce_adam(m, (hipStream_t)stream, 0, false, true, nullptr);
+}
+
+// ---------------------------------------------------------------------------- per-kernel entry points
+static int batch_dev_only(const v2x_batch* b, DevBatch* d) {
+  v2x_model* nullm = nullptr;
+  if (!b || !b->on_device) FAIL(nullm, V2X_EINVAL, "per-kernel entry points take device-resident batches");
+  if (!b->row_ptr || b->n_graphs <= 0 || b->n_rows <= 0 || b->max_nodes <= 0) FAIL(nullm, V2X_EINVAL, "batch: bad sizes");
+  d->B = b->n_graphs; d->R = b->n_rows; d->E = b->n_edges; d->max_nodes = b->max_nodes; d->max_edges = b->max_edges;
+  d->xe = b->xe; d->nbr = b->nbr_init; d->goff = b->graph_off; d->rp = b->row_ptr; d->ci = b->col_idx;
+  return V2X_OK;
+}
+
+int v2x_agg_fwd(const v2x_batch* b, int32_t n_nodes, int32_t feat_dim, const float* h, float* out, void* stream) {
+  DevBatch d;
+  CHK(batch_dev_only(b, &d));
+  return launch_agg(nullptr, (hipStream_t)stream, d, n_nodes, feat_dim, h, feat_dim, nullptr, 0, nullptr, out, 0);
+}
+
+int v2x_agg_bwd(const v2x_batch* b, int32_t n_nodes, int32_t feat_dim, const float* g, float* out, void* stream) {
+  DevBatch d;
+  CHK(batch_dev_only(b, &d));
+  return launch_agg(nullptr, (hipStream_t)stream, d, n_nodes, feat_dim, g, feat_dim, nullptr, 0, nullptr, out, 1);
+}
+
+int v2x_node_update_fwd(v2x_model* m, int32_t stage, int32_t n_rows, const float* xe, const float* h_prev,
+                        const float* agg_prev, float* out, void* stream) {
+  if (!m || !xe || !out || stage < 0 || stage > m->L || n_rows <= 0) FAIL(m, V2X_EINVAL, "node_update_fwd: bad argument");
+  if (m->S > 1 && n_rows % m->N) FAIL(m, V2X_EINVAL, "node_update_fwd: n_rows not a multiple of n_nodes");
+  return launch_node_fwd(m, (hipStream_t)stream, stage, n_rows, xe, h_prev, agg_prev, out);
+}
+
+static int copy_cols(v2x_model* m, float* dst, int dst_w, const float* src, int src_w, int col, int rows, hipStream_t st) {
+  HIPCHK(m, hipMemcpy2DAsync(dst, (size_t)dst_w * 4, src + col, (size_t)src_w * 4, (size_t)dst_w * 4, rows,
+                             hipMemcpyDeviceToDevice, st));
+  return V2X_OK;
+}
+
+int v2x_node_update_bwd(v2x_model* m, int32_t stage, int32_t n_rows, const float* xe, const float* h_prev,
+                        const float* agg_prev, const float* dpre, float* dh_prev, float* dagg_prev, float* grad_out,
+                        void* stream) {
+  if (!m || !xe || !dpre || stage < 0 || stage > m->L || n_rows <= 0) FAIL(m, V2X_EINVAL, "node_update_bwd: bad argument");
+  if (m->S > 1 && n_rows % m->N) FAIL(m, V2X_EINVAL, "node_update_bwd: n_rows not a multiple of n_nodes");
+  hipStream_t st = (hipStream_t)stream;
+  CHK(ensure_rows(m, n_rows));
+  CHK(wgrad_gnn(m, st, stage, n_rows, xe, h_prev, agg_prev, dpre));
+  if (grad_out) CHK(launch_reduce_adam(m, st, n_rows, true, false, grad_out));
+  if (stage > 0 && (dh_prev || dagg_prev)) {
+    CHK(launch_dgrad(m, st, stage, n_rows, dpre, m->gha));
+    if (dh_prev) CHK(copy_cols(m, dh_prev, m->F, m->gha, 2 * m->F, 0, n_rows, st));
+    if (dagg_prev) CHK(copy_cols(m, dagg_prev, m->F, m->gha, 2 * m->F, m->F, n_rows, st));
+  }
+  return V2X_OK;
+}
+
+int v2x_mlp_fwd(v2x_model* m, int32_t n_rows, const float* xe, const float* h, const float* agg, float* q_out, void* stream) {
+  if (!m || !xe || !h || !agg || !q_out || n_rows <= 0) FAIL(m, V2X_EINVAL, "mlp_fwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  CHK(ensure_rows(m, n_rows));
+  MlpArgs a;
+  mlp_args(m, a, n_rows, xe, h, agg);
+  CHK(launch_mlp(m, st, a, false));
+  HIPCHK(m, hipMemcpyAsync(q_out, m->q, (size_t)n_rows * m->C * 4, hipMemcpyDeviceToDevice, st));
+  return V2X_OK;
+}
+
+int v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_global, const float* xe, const float* h, const float* agg,
+                      const float* y, float* dh, float* dagg, float* grad_out, float* loss_out, void* stream) {
+  if (!m || !xe || !h || !agg || !y || n_rows <= 0) FAIL(m, V2X_EINVAL, "mlp_huber_bwd: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  CHK(ensure_rows(m, n_rows));
+  const RowMapH rm = row_map(m, n_rows);
+  if (n_global <= 0) n_global = m->cfg.variable_graphs ? n_rows : n_rows / m->N;
+  MlpArgs a;
+  mlp_args(m, a, n_rows, xe, h, agg);
+  CHK(launch_mlp(m, st, a, false));
+  a.y = y;
+  a.inv_denom = 1.0f / loss_denominator(m, n_global);
+  CHK(launch_mlp(m, st, a, true));
+  CHK(wgrad_mlp(m, st, n_rows, xe, h, agg));
+  if (grad_out) CHK(launch_reduce_adam(m, st, n_rows, true, false, grad_out));
+  if (dh) CHK(copy_cols(m, dh, m->F, m->gha, 2 * m->F, 0, n_rows, st));
+  if (dagg) CHK(copy_cols(m, dagg, m->F, m->gha, 2 * m->F, m->F, n_rows, st));
+  if (loss_out) {
+    if (m->cfg.variable_graphs)
+      hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, m->rowloss, m->loss_dev, n_rows, 1, a.inv_denom);
+    else
+      hipLaunchKernelGGL(k_loss_reduce, dim3(m->N), dim3(256), 0, st, m->rowloss, m->loss_dev, rm.n_idx, m->N, a.inv_denom);
+    HIPCHK(m, hipMemcpyAsync(loss_out, m->loss_dev, (m->cfg.variable_graphs ? 1 : m->N) * sizeof(float),
+                             hipMemcpyDeviceToDevice, st));
+  }
+  return V2X_OK;
+}
+
+int v2x_adam_step(float* param, const float* grad, float* mom, float* vel, int64_t n, int64_t iteration, float lr,
+                  float beta1, float beta2, float eps, void* stream) {
+  v2x_model* nullm = nullptr;
+  if (!param || !grad || !mom || !vel || n <= 0 || iteration < 1) FAIL(nullm, V2X_EINVAL, "adam_step: bad argument");
+  const double t = (double)iteration;
+  const float lr_t = (float)(lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_adam_scalar, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, mom, vel, n, lr_t,
+                     beta1, beta2, eps);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) FAIL(nullm, V2X_EHIP, "adam launch failed: %s", hipGetErrorString(e));
+  return V2X_OK;
+}
+
+// ---------------------------------------------------------------------------- measurement
+int v2x_profile_enable(v2x_model* m, int enable) {
+  if (!m) FAIL(m, V2X_EINVAL, "null model");
+  m->prof = enable != 0;
+  if (!enable) {
+    for (auto& r : m->prof_recs) { hipEventDestroy(r.ev0); hipEventDestroy(r.ev1); }
+    m->prof_recs.clear();
+  }
+  return V2X_OK;
+}
+
+int v2x_profile_read(v2x_model* m, char* names_out, int names_cap, double* ms_out, int64_t* calls_out, int max_entries) {
+  if (!m || !names_out || !ms_out || !calls_out) FAIL(m, V2X_EINVAL, "profile_read: null argument");
+  HIPCHK(m, hipDeviceSynchronize());
+  std::vector<double> ms(m->prof_names.size(), 0.0);
+  std::vector<int64_t> calls(m->prof_names.size(), 0);
+  for (auto& r : m->prof_recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.ev0, r.ev1) == hipSuccess) { ms[r.id] += t; calls[r.id] += 1; }
+    hipEventDestroy(r.ev0); hipEventDestroy(r.ev1);
+  }
+  m->prof_recs.clear();
+  std::string names;
+  int n = 0;
+  for (size_t i = 0; i < m->prof_names.size() && n < max_entries; ++i) {
+    if (!calls[i]) continue;
+    if ((int)(names.size() + m->prof_names[i].size() + 2) > names_cap) break;
+    names += m->prof_names[i]; names += '\n';
+    ms_out[n] = ms[i]; calls_out[n] = calls[i];
+    ++n;
+  }
+  snprintf(names_out, names_cap, "%s", names.c_str());
+  return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+"""Batched data parallelism over independent graph instances.
+
+One process per GPU; every rank holds a full replica of the weights and Adam state and a
+contiguous shard of B/G whole graphs of the replay minibatch (AggLayer only contracts inside a
+sample, BS_brain.py:73, so forward and backward need no communication).  The only collective
+is ONE all-reduce (sum) of the flat fp32 gradient buffer per step -- RCCL over xGMI through
+`torch.distributed` (backend "nccl" is RCCL on ROCm; "gloo" in the CPU tests).  Each rank
+differentiates its shard of the GLOBAL Huber mean (n_global = B), so the sum of the per-rank
+gradients is exactly the single-GPU gradient and no rescale is needed.  The target-network
+sync stays a local device-to-device copy.
+"""
+
+
+class DataParallelTrainer(object):
+    """`backend` implements forward_backward(batch, y, n_global, want_loss) -> loss tensor,
+    grad_tensor() -> flat torch tensor aliasing the gradient buffer, apply_gradients().
+    `GnnEngine` is the GPU backend."""
+
+    def __init__(self, backend, process_group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.backend = backend
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self._grad = None
+
+    def shard(self, batch, y):
+        """Contiguous shard of whole graphs for this rank.  y is [R, C] for the full batch."""
+        if self.world == 1:
+            return batch, y
+        sh = batch.shard(self.rank, self.world)
+        rows = batch.n_rows // self.world
+        return sh, y[self.rank * rows:(self.rank + 1) * rows]
+
+    def train_step(self, local_batch, local_y, n_graphs_global, want_loss=True):
+        """forward+backward on the local shard, all-reduce the gradient, Adam on every rank."""
+        loss = self.backend.forward_backward(local_batch, local_y, n_global=n_graphs_global, want_loss=want_loss)
+        if self.world > 1:
+            if self._grad is None:
+                self._grad = self.backend.grad_tensor()
+            self.dist.all_reduce(self._grad, op=self.dist.ReduceOp.SUM, group=self.group)
+            if want_loss and loss is not None:
+                import torch
+                if not torch.is_tensor(loss):
+                    loss_t = torch.as_tensor(loss)
+                    self.dist.all_reduce(loss_t, op=self.dist.ReduceOp.SUM, group=self.group)
+                    loss = loss_t.numpy()
+                else:
+                    self.dist.all_reduce(loss, op=self.dist.ReduceOp.SUM, group=self.group)
+        self.backend.apply_gradients()
+        return loss

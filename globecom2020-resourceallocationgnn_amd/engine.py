@@ -1,0 +1,209 @@
+"""GnnEngine: one Q-network (weights + Adam state + workspaces) resident in the HBM of one
+MI355X, driven through the C ABI (include/v2xgnn.h).  PyTorch is used only as plumbing:
+device tensors for batches that stay resident, the current HIP stream, torch.distributed.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .packing import PackedBatch, keras_list_to_flat, flat_to_keras_list
+from .spec import GnnSpec
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def current_stream_ptr(device_index):
+    """hipStream_t of torch's current stream on the device (0 when torch has no GPU)."""
+    try:
+        torch = _torch()
+        if torch.cuda.is_available():
+            return int(torch.cuda.current_stream(device_index).cuda_stream)
+    except ImportError:
+        pass
+    return 0
+
+
+class DeviceBatch(object):
+    """A PackedBatch whose arrays live in HBM (torch tensors own the memory)."""
+
+    def __init__(self, host: PackedBatch, device):
+        torch = _torch()
+        self.n_graphs, self.n_nodes, self.n_rows, self.n_edges = host.n_graphs, host.n_nodes, host.n_rows, host.n_edges
+        self.max_nodes, self.max_edges = host.max_nodes, host.max_edges
+        self.device = torch.device(device)
+        t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+        self.xe, self.nbr = t(host.xe), t(host.nbr)
+        self.row_ptr, self.col_idx, self.graph_off = t(host.row_ptr), t(host.col_idx), t(host.graph_off)
+        if self.col_idx is not None and self.col_idx.numel() == 0:
+            self.col_idx = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+
+def _batch_struct(b):
+    s = _lib.Batch()
+    s.n_graphs, s.n_rows, s.n_edges = b.n_graphs, b.n_rows, b.n_edges
+    s.max_nodes, s.max_edges = b.max_nodes, b.max_edges
+    if isinstance(b, DeviceBatch):
+        s.on_device = 1
+        p = lambda t: None if t is None else t.data_ptr()
+    else:
+        s.on_device = 0
+        p = lambda a: None if a is None else a.ctypes.data
+    s.xe, s.nbr_init, s.graph_off = p(b.xe), p(b.nbr), p(b.graph_off)
+    s.row_ptr, s.col_idx = p(b.row_ptr), p(b.col_idx)
+    return s
+
+
+class GnnEngine(object):
+    def __init__(self, spec: GnnSpec, device=0, use_graph=False, lr=1e-3, beta_1=0.5, beta_2=0.999,
+                 epsilon=1e-7):
+        self.spec = spec
+        self.device = int(device)
+        self._lib = _lib.load_library()          # raises if the HIP extension is missing
+        cfg = _lib.Config(spec.n_nodes, spec.n_channels, spec.feat_dim, spec.n_mp_layers,
+                          int(spec.share_weights), int(spec.variable_graphs), self.device, int(use_graph),
+                          lr, beta_1, beta_2, epsilon)
+        h = C.c_void_p()
+        rc = self._lib.v2x_create(C.byref(cfg), C.byref(h))
+        _lib.check(self._lib, rc, None)
+        self._h = h
+        self.n_params = int(self._lib.v2x_param_count(self._h))
+        if self.n_params != spec.n_params:
+            raise _lib.V2XError("parameter count mismatch: library %d vs spec %d" % (self.n_params, spec.n_params))
+        self.n_outputs = 1 if spec.variable_graphs else spec.n_nodes
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.v2x_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return current_stream_ptr(self.device)
+
+    def _check(self, rc):
+        _lib.check(self._lib, rc, self._h)
+
+    # ------------------------------------------------------------------ parameters
+    def get_flat(self):
+        out = np.empty(self.n_params, np.float32)
+        self._check(self._lib.v2x_get_weights(self._h, out.ctypes.data, self._stream()))
+        return out
+
+    def set_flat(self, flat):
+        flat = np.ascontiguousarray(flat, np.float32)
+        if flat.size != self.n_params:
+            raise ValueError("expected %d parameters, got %d" % (self.n_params, flat.size))
+        self._check(self._lib.v2x_set_weights(self._h, flat.ctypes.data, self._stream()))
+
+    def get_weights(self):
+        return flat_to_keras_list(self.spec, self.get_flat())
+
+    def set_weights(self, weights):
+        self.set_flat(keras_list_to_flat(self.spec, weights))
+
+    def copy_weights_from(self, other):
+        """update_target_model (BS_brain.py:237-239) as ONE device-to-device copy."""
+        self._check(self._lib.v2x_copy_weights(self._h, other._h, self._stream()))
+
+    def get_optimizer_state(self):
+        m = np.empty(self.n_params, np.float32)
+        v = np.empty(self.n_params, np.float32)
+        it = C.c_int64()
+        self._check(self._lib.v2x_get_optimizer_state(self._h, m.ctypes.data, v.ctypes.data, C.byref(it), self._stream()))
+        return m, v, int(it.value)
+
+    def set_optimizer_state(self, m, v, iterations):
+        m = np.ascontiguousarray(m, np.float32)
+        v = np.ascontiguousarray(v, np.float32)
+        self._check(self._lib.v2x_set_optimizer_state(self._h, m.ctypes.data, v.ctypes.data, int(iterations), self._stream()))
+
+    def grad_tensor(self):
+        """torch view (no copy) of the flat gradient buffer in HBM, for the RCCL all-reduce."""
+        torch = _torch()
+        ptr = int(self._lib.v2x_grad_ptr(self._h))
+
+        class _Holder(object):
+            pass
+        hld = _Holder()
+        hld.__cuda_array_interface__ = {"shape": (self.n_params,), "typestr": "<f4", "data": (ptr, False),
+                                        "version": 2, "strides": None}
+        t = torch.as_tensor(hld, device="cuda:%d" % self.device)
+        t._v2x_owner = self
+        return t
+
+    def get_grad_flat(self):
+        return self.grad_tensor().cpu().numpy()
+
+    # ------------------------------------------------------------------ hot path
+    def to_device(self, batch: PackedBatch):
+        return DeviceBatch(batch, "cuda:%d" % self.device)
+
+    def forward(self, batch, out=None):
+        """Model.predict on a packed batch.  Returns q[R,C]: numpy for host batches, or fills /
+        returns a torch tensor for device batches."""
+        s = _batch_struct(batch)
+        if isinstance(batch, DeviceBatch):
+            torch = _torch()
+            if out is None:
+                out = torch.empty((batch.n_rows, self.spec.n_channels), dtype=torch.float32, device=batch.device)
+            self._check(self._lib.v2x_forward(self._h, C.byref(s), out.data_ptr(), 1, self._stream()))
+            return out
+        q = np.empty((batch.n_rows, self.spec.n_channels), np.float32)
+        self._check(self._lib.v2x_forward(self._h, C.byref(s), q.ctypes.data, 0, self._stream()))
+        return q
+
+    def _step(self, fn, batch, y, n_global, want_loss):
+        s = _batch_struct(batch)
+        n_global = int(n_global or 0)
+        if isinstance(batch, DeviceBatch):
+            torch = _torch()
+            if not (hasattr(y, "is_cuda") and y.is_cuda):
+                y = torch.as_tensor(np.ascontiguousarray(y, np.float32)).to(batch.device)
+            loss = torch.empty(self.n_outputs, dtype=torch.float32, device=batch.device) if want_loss else None
+            self._check(fn(self._h, C.byref(s), y.data_ptr(), 1, n_global,
+                           None if loss is None else loss.data_ptr(), 1, self._stream()))
+            return loss
+        y = np.ascontiguousarray(y, np.float32)
+        if y.size != batch.n_rows * self.spec.n_channels:
+            raise ValueError("targets have %d entries, expected %d" % (y.size, batch.n_rows * self.spec.n_channels))
+        loss = np.empty(self.n_outputs, np.float32) if want_loss else None
+        self._check(fn(self._h, C.byref(s), y.ctypes.data, 0, n_global,
+                       None if loss is None else loss.ctypes.data, 0, self._stream()))
+        return loss
+
+    def train_step(self, batch, y, n_global=None, want_loss=True):
+        """One Model.fit step (forward + Huber + backward + Keras Adam).  y is [R,C]."""
+        return self._step(self._lib.v2x_train_step, batch, y, n_global, want_loss)
+
+    def forward_backward(self, batch, y, n_global=None, want_loss=True):
+        """Forward + backward only: the local gradient is left in grad_tensor()."""
+        return self._step(self._lib.v2x_forward_backward, batch, y, n_global, want_loss)
+
+    def apply_gradients(self):
+        self._check(self._lib.v2x_apply_gradients(self._h, self._stream()))
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, enable):
+        self._check(self._lib.v2x_profile_enable(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """{kernel name: (calls, total ms)} measured with HIP events around every launch."""
+        cap, n = 4096, 64
+        names = C.create_string_buffer(cap)
+        ms = (C.c_double * n)()
+        calls = (C.c_int64 * n)()
+        k = self._lib.v2x_profile_read(self._h, names, cap, ms, calls, n)
+        if k < 0:
+            self._check(k)
+        nm = names.value.decode().split("\n")
+        return {nm[i]: (int(calls[i]), float(ms[i])) for i in range(k)}

@@ -1,0 +1,170 @@
+/*
+ * v2xgnn.h -- C ABI of the MI355X (gfx950) GNN message-passing engine that replaces the
+ * Keras/TF1 Q-network of the reference (`/root/reference/BS_brain.py`).
+ *
+ * This is the drop-in boundary.  The reference has no FFI of its own
+ * (it is pure Python on Keras); the entry points below are what a `ctypes` binding of the
+ * reference's `BS` class needs, one per reference call site:
+ *
+ *   v2x_create / v2x_destroy      <- BS._create_model            BS_brain.py:108-216
+ *   v2x_forward                   <- Model.predict               BS_brain.py:225-235
+ *   v2x_train_step                <- Model.fit (1 step)          BS_brain.py:218-223
+ *   v2x_copy_weights              <- BS.update_target_model      BS_brain.py:237-239
+ *   v2x_get_weights/set_weights   <- get_weights / set_weights / save_weights / load_weights
+ *                                                                BS_brain.py:239,863,869,1254
+ *   v2x_agg_* / v2x_node_update_* / v2x_mlp_* / v2x_adam_step
+ *                                 <- the implicit TF op set of GNNLayer.call (:44-51),
+ *                                    AggLayer.call (:69-76), Dense (:176-179), huber (:86-87),
+ *                                    Adam (:212); exported so each kernel is parity-testable
+ *                                    on its own.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns 0 on success or a negative V2X_E* code;
+ *     `v2x_last_error(model)` (or `v2x_last_error(NULL)` for create failures) gives text.
+ *   - all arithmetic is fp32 (Keras floatx), edge indices int32.
+ *   - pointers marked [dev] are device (HBM) pointers, [host] host pointers, [any] either,
+ *     selected by the `on_device` flag next to them.  The caller owns every buffer it
+ *     passes; the engine never retains input pointers beyond the call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *     asynchronous on that stream except where host buffers are read or written.
+ *   - one model handle per (network, device); a handle is not thread-safe; distinct
+ *     handles are independent (online and target networks are two handles).
+ *
+ * Data layout (DESIGN.md "Data layout in HBM")
+ *   A batch of B graphs is R node rows, graph-major; node order inside a graph is the
+ *   reference's D1..DN order.  Features are packed per row as
+ *       xe[R][16] = [ node features (Dn = 2C+1) | edge features (De = C) | zero pad ]
+ *   (the reference's `D{k}_Node_Input` / `D{k}_Edge_Input`, BS_brain.py:461-467).
+ *   Adjacency is CSR by DESTINATION row: sources of global row q are the graph-local node
+ *   ids col_idx[row_ptr[q] .. row_ptr[q+1]) , ascending, no duplicates; this is
+ *   Adj[p,q] == 1  (BS_brain.py:441-445) and  agg_q = sum_p Adj[p,q] h_p  (:72-76).
+ *   graph_off[B+1] gives the first row of every graph (NULL => fixed n_nodes per graph).
+ *
+ * Flat parameter layout (v2x_get_weights / v2x_set_weights / gradient buffer), fp32:
+ *   stage-major, slot-minor.  S = n_nodes weight sets (reference: one per node) or 1 when
+ *   share_weights.  For every layer, for every slot:  W[K][N_out] row-major, then bias[N_out].
+ *     GNN stage 0      K rows = [ x(Dn) | e(De) | neighbor(F) ]            (W1 ; W2 ; W3 of :121)
+ *     GNN stage s>=1   K rows = [ h(F) | x(Dn) | e(De) | agg(F) ]         (W1 ; W2 ; W3 of :154/:161)
+ *     Dense 0          K rows = [ h(F) | x(Dn) | agg(F) ]   N_out = 80     (:176, rows permuted
+ *                                                                          from Keras' [x|h|agg])
+ *     Dense 1..3       [80][40], [40][20], [20][C]                         (:177-179)
+ */
+#ifndef V2XGNN_H
+#define V2XGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2X_OK            0
+#define V2X_EINVAL       -1   /* bad argument / unsupported configuration */
+#define V2X_EHIP         -2   /* a HIP runtime call failed                */
+#define V2X_ENOMEM       -3
+#define V2X_ESTATE       -4   /* call order violated (e.g. backward before forward) */
+
+#define V2X_XE_WIDTH     16   /* packed [x|e|pad] row width */
+
+typedef struct v2x_model v2x_model;
+
+typedef struct v2x_config {
+  int32_t n_nodes;        /* N: nodes per graph (num_D2D, BS_brain.py:95); >=1             */
+  int32_t n_channels;     /* C: num_CH (:97); this build supports C == 4                     */
+  int32_t feat_dim;       /* F: num_Feedback (:98); 16, 32 or 64 in this build               */
+  int32_t n_mp_layers;    /* L: message-passing stages after the embed (reference: 2)        */
+  int32_t share_weights;  /* 0 = one weight set per node slot (reference), 1 = shared        */
+  int32_t variable_graphs;/* 1 = graphs of different sizes (needs share_weights)             */
+  int32_t device;         /* HIP device ordinal                                              */
+  int32_t use_graph;      /* 1 = capture/replay the step as a hipGraph when shapes repeat    */
+  float   lr, beta1, beta2, eps;   /* Keras Adam (:212): 1e-3, 0.5, 0.999, 1e-7             */
+} v2x_config;
+
+typedef struct v2x_batch {
+  int32_t n_graphs;        /* B */
+  int32_t n_rows;          /* R = sum of nodes                                              */
+  int32_t n_edges;         /* E = row_ptr[R]                                                */
+  int32_t max_nodes;       /* max nodes of any graph in the batch                           */
+  int32_t max_edges;       /* max edges of any graph in the batch                           */
+  int32_t on_device;       /* 1: all pointers below are [dev]; 0: [host] (copied per call)  */
+  const float*   xe;        /* [R][16]                                                      */
+  const float*   nbr_init;  /* [R][F] or NULL (reference always feeds zeros, :478-490)      */
+  const int32_t* graph_off; /* [B+1] or NULL when every graph has n_nodes rows              */
+  const int32_t* row_ptr;   /* [R+1] global edge offsets                                    */
+  const int32_t* col_idx;   /* [E] graph-local source node                                  */
+} v2x_batch;
+
+/* ---- model lifetime -------------------------------------------------------------------- */
+int  v2x_create(const v2x_config* cfg, v2x_model** out);
+void v2x_destroy(v2x_model* m);
+const char* v2x_last_error(const v2x_model* m);
+const char* v2x_version(void);
+
+/* ---- parameters ------------------------------------------------------------------------ */
+int64_t v2x_param_count(const v2x_model* m);
+int  v2x_get_weights(v2x_model* m, float* host_out, void* stream);        /* [host] P floats */
+int  v2x_set_weights(v2x_model* m, const float* host_in, void* stream);   /* [host] P floats */
+int  v2x_copy_weights(v2x_model* dst, const v2x_model* src, void* stream);/* device-to-device */
+int  v2x_get_optimizer_state(v2x_model* m, float* host_m, float* host_v, int64_t* iterations, void* stream);
+int  v2x_set_optimizer_state(v2x_model* m, const float* host_m, const float* host_v, int64_t iterations, void* stream);
+/* device pointers of the flat fp32 buffers (length v2x_param_count): for RCCL all-reduce of
+ * the gradient by the host framework, and for zero-copy inspection.                        */
+float* v2x_param_ptr(v2x_model* m);
+float* v2x_grad_ptr(v2x_model* m);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* forward only: q_out[R][C]  (Model.predict, BS_brain.py:225-231)                           */
+int  v2x_forward(v2x_model* m, const v2x_batch* b, float* q_out, int q_on_device, void* stream);
+
+/* one fit step = forward + Huber + backward + Keras-Adam (Model.fit, BS_brain.py:218-223).
+ *   y[R][C] targets;  loss_out[n_nodes] per-output Huber means (History 'D{k}_Decide_Output_loss'),
+ *   may be NULL.  n_graphs_global: B of the GLOBAL batch (== b->n_graphs on one GPU): the
+ *   Huber mean is taken over it, so per-rank gradients SUM to the global-batch gradient.   */
+int  v2x_train_step(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device,
+                    int32_t n_graphs_global, float* loss_out, int loss_on_device, void* stream);
+
+/* the same step split for data parallelism: (1) forward+backward leaves the local gradient
+ * in v2x_grad_ptr(); the host all-reduces (sum) it over ranks; (2) apply the Adam update.  */
+int  v2x_forward_backward(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device,
+                          int32_t n_graphs_global, float* loss_out, int loss_on_device, void* stream);
+int  v2x_apply_gradients(v2x_model* m, void* stream);
+
+/* ---- per-kernel entry points (parity tests; all pointers [dev]) ------------------------ */
+/* AggLayer.call forward: out[q] = sum_{p in N(q)} h[p]            (BS_brain.py:69-76)      */
+int  v2x_agg_fwd(const v2x_batch* b, int32_t n_nodes, int32_t feat_dim,
+                 const float* h, float* out, void* stream);
+/* its transpose (backward):   out[p] = sum_{q : p in N(q)} g[q]                            */
+int  v2x_agg_bwd(const v2x_batch* b, int32_t n_nodes, int32_t feat_dim,
+                 const float* g, float* out, void* stream);
+/* GNNLayer.call of stage `stage` with the model's weights (BS_brain.py:44-51):
+ *   out = act( [h_prev|x]W1 + e W2 + agg_prev W3 + b ), act = relu for stage < L.          */
+int  v2x_node_update_fwd(v2x_model* m, int32_t stage, int32_t n_rows, const float* xe,
+                         const float* h_prev, const float* agg_prev, float* out, void* stream);
+/* backward of the same: given dpre[R][F] (gradient at the pre-activation) writes
+ * dh_prev[R][F], dagg_prev[R][F] (either may be NULL for stage 0) and ACCUMULATES nothing:
+ * the layer's weight gradient is written to grad_out (flat layout, only this layer's range). */
+int  v2x_node_update_bwd(v2x_model* m, int32_t stage, int32_t n_rows, const float* xe,
+                         const float* h_prev, const float* agg_prev, const float* dpre,
+                         float* dh_prev, float* dagg_prev, float* grad_out, void* stream);
+/* decision MLP (Dense 80-40-20-C, :176-179) forward and Huber+backward.                    */
+int  v2x_mlp_fwd(v2x_model* m, int32_t n_rows, const float* xe, const float* h, const float* agg,
+                 float* q_out, void* stream);
+int  v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_graphs_global, const float* xe,
+                       const float* h, const float* agg, const float* y,
+                       float* dh, float* dagg, float* grad_out, float* loss_out, void* stream);
+/* Keras Adam on arbitrary flat device buffers (BS_brain.py:212)     */
+int  v2x_adam_step(float* param, const float* grad, float* mom, float* vel, int64_t n,
+                   int64_t iteration /* 1-based t */, float lr, float beta1, float beta2, float eps,
+                   void* stream);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* When enabled, every kernel launch of this model is bracketed by HIP events on its stream
+ * (eager, no graph); v2x_profile_read returns per-kernel-name call counts and total ms.    */
+int  v2x_profile_enable(v2x_model* m, int enable);
+int  v2x_profile_read(v2x_model* m, char* names_out, int names_cap, double* ms_out, int64_t* calls_out,
+                      int max_entries);   /* returns number of entries, names '\n'-separated */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2XGNN_H */

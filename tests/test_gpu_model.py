@@ -1,0 +1,234 @@
+"""End-to-end parity of the drop-in boundary (BS / GnnQModel / GnnEngine) on the GPU:
+golden vectors produced by the reference's own model code, oracle forward / backward / Adam,
+the Keras-like call surface and its error behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+import v2xgnn
+from v2xgnn import GnnSpec, PackedBatch, GnnEngine, BS
+from oracle import compact as oc
+from util import (ospec, random_inputs, f32_params, assert_close, assert_grad_close, FWD_RTOL, FWD_ATOL,
+                  golden_forward_cases, golden_keras_list, golden_feed, GOLDEN)
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # N, F, L, shared, B
+    (4, 16, 2, False, 1),
+    (4, 16, 2, False, 512),       # the reference's own training configuration (RL_Train_main.py:29-31)
+    (20, 64, 2, False, 96),
+    (20, 64, 2, True, 96),
+    (6, 32, 3, False, 50),
+]
+
+
+def test_golden_forward_through_bs_predict():
+    """Outputs of the reference's own `_create_model` code (tests/golden/make_golden.py) for the
+    same injected weights and the same dict payload, through `BS.predict` (online and target)."""
+    f, cases = golden_forward_cases()
+    brain = BS(4, 3, 1, 16, 1, 4, seed=0)
+    for case in cases:
+        feed = golden_feed(f, case)
+        for tag, target in (("online", False), ("target", True)):
+            model = brain.target_model if target else brain.model
+            # cast the float64 golden weights to the fp32 the engine stores
+            model.set_weights(golden_keras_list(f, case, tag))
+            out = brain.predict(feed, target=target)
+            assert isinstance(out, list) and len(out) == 4
+            for k in range(4):
+                ref = f['%s/%s/out/%d' % (case, tag, k)]
+                assert out[k].dtype == np.float32 and out[k].flags.writeable
+                # golden is float64 arithmetic on float64 weights: allow fp32 rounding of both
+                assert_close(out[k], ref, 5e-4, 5e-5, "golden %s/%s out %d" % (case, tag, k))
+
+
+@pytest.mark.parametrize("N,F,L,shared,B", CASES)
+def test_forward_and_gradients_vs_oracle(N, F, L, shared, B):
+    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=shared)
+    rng = np.random.default_rng(100 + N + F + B)
+    P = f32_params(spec, rng)
+    x, e, adj = random_inputs(rng, B, N)
+    eng = GnnEngine(spec)
+    eng.set_weights(oc.params_to_list(P))
+    pb = PackedBatch.from_dense(x, e, adj)
+    graph = ((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
+    M = oc.csr_to_matrix(*graph, dtype=np.float64)
+    os_ = ospec(spec)
+    q_ref, cache = oc.forward(os_, P, x.reshape(B * N, -1).astype(np.float64), e.reshape(B * N, -1).astype(np.float64), M)
+    q = eng.forward(pb)
+    assert_close(q, q_ref, FWD_RTOL, FWD_ATOL, "forward q")
+    # device-resident batch gives the same bits as the host batch
+    db = eng.to_device(pb)
+    q2 = eng.forward(db).cpu().numpy()
+    assert np.array_equal(q, q2)
+
+    y = (q_ref + rng.normal(0, 1.2, size=q_ref.shape)).astype(np.float32)
+    loss_ref, dq = oc.huber_loss_and_grad(os_, q_ref, y.astype(np.float64))
+    g_ref = oc.backward(os_, P, cache, dq)
+    loss = eng.forward_backward(pb, y)
+    assert_close(loss, loss_ref, 2e-4, 1e-6, "per-output huber loss")
+    got = v2xgnn.flat_to_keras_list(spec, eng.get_grad_flat())
+    ref = oc.params_to_list(g_ref)
+    assert len(got) == len(ref)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert_grad_close(a, b, "gradient array %d" % i)
+
+
+def test_gradient_shards_sum_to_global_gradient():
+    """Data-parallel contract: per-shard gradients taken with the GLOBAL batch size
+    in the Huber mean SUM to the full-batch gradient."""
+    N, F, B = 20, 64, 64
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(7)
+    P = f32_params(spec, rng)
+    x, e, adj = random_inputs(rng, B, N)
+    eng = GnnEngine(spec)
+    eng.set_weights(oc.params_to_list(P))
+    pb = PackedBatch.from_dense(x, e, adj)
+    y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+    full_loss = eng.forward_backward(pb, y)
+    g_full = eng.get_grad_flat().astype(np.float64)
+    acc = np.zeros_like(g_full)
+    loss_acc = np.zeros(N)
+    for r in range(4):
+        sh = pb.shard(r, 4)
+        ys = y.reshape(B, N, 4)[r * 16:(r + 1) * 16].reshape(-1, 4)
+        loss_acc += eng.forward_backward(sh, ys, n_global=B)
+        acc += eng.get_grad_flat()
+    assert_grad_close(acc, g_full, "sum of shard gradients")
+    assert_close(loss_acc, full_loss, 1e-5, 1e-7, "sum of shard losses")
+
+
+@pytest.mark.parametrize("N,F,L,shared,B", [(4, 16, 2, False, 512), (20, 64, 2, False, 64), (20, 64, 2, True, 64)])
+def test_train_steps_vs_oracle(N, F, L, shared, B):
+    """3 x Model.fit(one batch) == 3 x (forward, Huber, backward, Keras Adam) of the oracle."""
+    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=shared)
+    rng = np.random.default_rng(5 + N + B)
+    P = f32_params(spec, rng)
+    eng = GnnEngine(spec)
+    eng.set_weights(oc.params_to_list(P))
+    om = oc.OracleModel(ospec(spec), P, dtype=np.float64)
+    for step in range(3):
+        x, e, adj = random_inputs(rng, B, N)
+        pb = PackedBatch.from_dense(x, e, adj)
+        graph = ((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
+        y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+        # oracle gradient BEFORE its update, to know which entries Adam's sign-like first steps
+        # make ill-conditioned (|g| ~ eps)
+        _, g_ref, _ = om.loss_and_grads(x.reshape(B * N, -1), e.reshape(B * N, -1), graph, y)
+        loss_ref = om.train_step(x.reshape(B * N, -1), e.reshape(B * N, -1), graph, y)
+        loss = eng.train_step(pb, y)
+        assert_close(loss, loss_ref, 5e-4, 1e-6, "loss at step %d" % step)
+        got = eng.get_weights()
+        ref = oc.params_to_list(om.params)
+        gl = oc.params_to_list(g_ref)
+        for i, (a, b, g) in enumerate(zip(got, ref, gl)):
+            # Adam divides by sqrt(v)+1e-7: where |g| is at rounding-noise level the update direction is
+            # not determined by fp32 arithmetic; compare those entries to within one full step (lr)
+            scale = np.abs(g).max() or 1.0
+            tight = np.abs(g) > 1e-4 * scale
+            err = np.abs(a.astype(np.float64) - b)
+            assert (err[tight] <= 2e-5 + 2e-4 * np.abs(b[tight])).all(), ("weights", i, step, err[tight].max())
+            assert (err[~tight] <= 1.1e-3 * (step + 1)).all(), ("weights(ill-cond)", i, step, err[~tight].max())
+    m, v, it = eng.get_optimizer_state()
+    assert it == 3
+
+
+def test_graph_replay_matches_eager_bitwise():
+    import torch
+    N, F, B = 20, 64, 128
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(2)
+    P = f32_params(spec, rng)
+    x, e, adj = random_inputs(rng, B, N)
+    y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+    pb = PackedBatch.from_dense(x, e, adj)
+    res = []
+    for use_graph in (False, True):
+        eng = GnnEngine(spec, use_graph=use_graph)
+        eng.set_weights(oc.params_to_list(P))
+        db = eng.to_device(pb)
+        yd = torch.from_numpy(y).cuda()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for _ in range(4):
+                loss = eng.train_step(db, yd)
+            q = eng.forward(db)
+        st.synchronize()
+        res.append((eng.get_flat(), loss.cpu().numpy(), q.cpu().numpy()))
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+
+
+def test_bs_call_surface_and_errors(tmp_path):
+    """Constructor attributes (BS_brain.py:95-104), fit History keys (:835-837), target sync (:237-239),
+    save/load_weights round trip (:863,:1254), ValueError on malformed payloads like Keras."""
+    brain = BS(4, 3, 1, 16, 1, 4, seed=3)
+    assert (brain.num_D2D, brain.num_CH, brain.num_Feedback, brain.num_Neighbor) == (4, 4, 16, 1)
+    assert (brain.num_One_Node_Input, brain.num_One_Edge_Input, brain.num_One_D2D_Input, brain.num_D2D_Input) == (9, 4, 13, 68)
+    a = np.load(os.path.join(GOLDEN, "golden_agent_n4.npz"))
+    x = {k[len('fit_x/'):]: a[k] for k in a.files if k.startswith('fit_x/')}
+    y = {k[len('fit_y/'):]: a[k] for k in a.files if k.startswith('fit_y/')}
+    w0 = brain.model.get_weights()
+    assert len(w0) == 80
+    p_online = brain.predict(x)
+    p_target = brain.predict(x, target=True)
+    assert not np.allclose(p_online[0], p_target[0])          # independently initialised (BS_brain.py:105-106)
+    hist = brain.train_dnn(x, y, 32)
+    for k in range(1, 5):
+        v = hist.history['D%d_Decide_Output_loss' % k]
+        assert len(v) == 1 and np.isfinite(v[0]) and v[0] > 0
+    assert abs(hist.history['loss'][0] - sum(hist.history['D%d_Decide_Output_loss' % k][0] for k in range(1, 5))) < 1e-6
+    w1 = brain.model.get_weights()
+    assert any(not np.array_equal(u, v) for u, v in zip(w0, w1))
+    brain.update_target_model()
+    for u, v in zip(brain.model.get_weights(), brain.target_model.get_weights()):
+        assert np.array_equal(u, v)
+    path = str(tmp_path / "Q-Network_model_weights-Episode-5-Step-20-Batch-512.h5")
+    brain.model.save_weights(path)
+    other = BS(4, 3, 1, 16, 1, 4, seed=99)
+    other.model.load_weights(path)
+    for u, v in zip(brain.model.get_weights(), other.model.get_weights()):
+        assert np.array_equal(u, v)
+    q1 = brain.predict_one_step({k[len('init/'):]: a[k] for k in a.files if k.startswith('init/')})
+    assert len(q1) == 4 and q1[0].shape == (1, 4)
+    # malformed payloads
+    bad = dict(x)
+    del bad['D2_Edge_Input']
+    with pytest.raises(ValueError):
+        brain.predict(bad)
+    bad = dict(x)
+    bad['D1_Node_Input'] = bad['D1_Node_Input'][:, :5]
+    with pytest.raises(ValueError):
+        brain.predict(bad)
+    bad = dict(x)
+    A = bad['Adjacency_Matrix'].copy()
+    A[0, 0, 5] = 1.0            # not kron(Adj, I_F)
+    bad['Adjacency_Matrix'] = A
+    with pytest.raises(ValueError):
+        brain.predict(bad)
+    with pytest.raises(ValueError):
+        brain.model.set_weights(w0[:-1])
+
+
+def test_replay_targets_from_captured_agent_payload():
+    """The x/y payload the reference's Agent.replay hands to fit (captured with the real simulator)
+    trains the engine the same way it trains the oracle (one Adam step, same losses)."""
+    a = np.load(os.path.join(GOLDEN, "golden_agent_n4.npz"))
+    x = {k[len('fit_x/'):]: a[k] for k in a.files if k.startswith('fit_x/')}
+    y = {k[len('fit_y/'):]: a[k] for k in a.files if k.startswith('fit_y/')}
+    spec = GnnSpec()
+    brain = BS(4, 3, 1, 16, 1, 4, seed=1)
+    P = oc.params_from_list(ospec(spec), [w.astype(np.float64) for w in brain.model.get_weights()], np.float64)
+    om = oc.OracleModel(ospec(spec), P, dtype=np.float64)
+    xs, es, nbr, adj = v2xgnn.feed_to_arrays(spec, x)
+    B = xs.shape[0]
+    pb = PackedBatch.from_dense(xs, es, adj)
+    graph = ((np.arange(B + 1) * 4).astype(np.int32), pb.row_ptr, pb.col_idx)
+    yt = np.stack([y['D%d_Decide_Output' % k] for k in range(1, 5)], axis=1).reshape(-1, 4)
+    loss_ref = om.train_step(xs.reshape(B * 4, -1).astype(np.float32), es.reshape(B * 4, -1).astype(np.float32), graph,
+                             yt.astype(np.float32))
+    hist = brain.train_dnn(x, y, B)
+    got = [hist.history['D%d_Decide_Output_loss' % k][0] for k in range(1, 5)]
+    assert_close(got, loss_ref, 5e-4, 1e-6, "losses on the captured replay payload")

@@ -1,0 +1,154 @@
+"""CPU: host-side logic of the product package (packing, weight layout, error behaviour) and the
+C-ABI shared library: it loads, exports every symbol include/v2xgnn.h declares, and refuses to
+run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import v2xgnn
+from v2xgnn import GnnSpec, PackedBatch
+from v2xgnn import lib as vlib
+from oracle import compact as oc, literal as ol
+from oracle.spec import GnnSpec as OSpec
+from util import GOLDEN, golden_forward_cases, golden_feed, random_inputs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'v2xgnn.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(v2x_[a-z_0-9]+)\s*\(', hdr))
+    assert len(declared) >= 20
+    assert os.path.exists(vlib.library_path()), "build the HIP extension first (__graft_entry__.build())"
+    lib = C.CDLL(vlib.library_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libv2xgnn.so does not export %s" % name
+    bound = {n for n, _, _ in vlib.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    assert b'gfx950' in vlib.load_library().v2x_version()
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(vlib.V2XError, match="no CPU fallback"):
+        v2xgnn.GnnEngine(GnnSpec())
+    with pytest.raises(vlib.V2XError):
+        v2xgnn.BS(4, 3, 1, 16, 1, 4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'globecom2020-resourceallocationgnn_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.hip', '.hpp', '.h', '.cpp')):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
+                assert 'oracle/' not in src.replace('SURVEY', ''), fn
+
+
+def test_spec_matches_reference_size_bookkeeping():
+    s = GnnSpec()
+    assert (s.node_in, s.edge_in, s.n_params) == (9, 4, 37824)
+    assert GnnSpec(n_nodes=20, feat_dim=64).n_params == 767040
+    assert GnnSpec(n_nodes=20, feat_dim=64, share_weights=True).n_params == 38352
+    assert len(v2xgnn.keras_list_shapes(s)) == 80
+
+
+def test_weight_layout_roundtrip_and_dense0_permutation():
+    spec = GnnSpec(n_nodes=3, feat_dim=16)
+    rng = np.random.default_rng(0)
+    ws = [rng.normal(size=s).astype(np.float32) for s in v2xgnn.keras_list_shapes(spec)]
+    flat = v2xgnn.keras_list_to_flat(spec, ws)
+    back = v2xgnn.flat_to_keras_list(spec, flat)
+    assert all(np.array_equal(a, b) for a, b in zip(ws, back))
+    # flat layout as documented in include/v2xgnn.h: stage 0, slot 0 = vstack(W1, W2, W3), bias
+    n0 = (9 + 4 + 16) * 16
+    assert np.array_equal(flat[:n0].reshape(29, 16), np.vstack(ws[0:3]))
+    assert np.array_equal(flat[n0:n0 + 16], ws[3])
+    # Dense-0 rows are stored [h | x | agg]
+    S = spec.n_slots
+    off = sum((spec.stage_in_a(s) + 4 + 16) * 16 + 16 for s in range(3)) * S
+    W = ws[3 * S * 4]                      # Keras order [x(9) | h(16) | agg(16)]
+    got = flat[off:off + 41 * 80].reshape(41, 80)
+    assert np.array_equal(got[:16], W[9:25]) and np.array_equal(got[16:25], W[:9]) and np.array_equal(got[25:], W[25:])
+    with pytest.raises(ValueError):
+        v2xgnn.keras_list_to_flat(spec, ws[:-1])
+    bad = list(ws)
+    bad[0] = bad[0][:, :5]
+    with pytest.raises(ValueError):
+        v2xgnn.keras_list_to_flat(spec, bad)
+
+
+def test_pack_and_csr_match_reference_adjacency_semantics():
+    rng = np.random.default_rng(1)
+    B, N, F = 5, 4, 16
+    x, e, adj = random_inputs(rng, B, N)
+    pb = PackedBatch.from_dense(x, e, adj)
+    assert pb.xe.shape == (B * N, 16) and pb.xe.dtype == np.float32
+    assert np.array_equal(pb.xe[:, :9], x.reshape(-1, 9)) and np.array_equal(pb.xe[:, 9:13], e.reshape(-1, 4))
+    assert not pb.xe[:, 13:].any()
+    # CSR by destination == AggLayer with kron(Adj, I_F)  (BS_brain.py:72-76)
+    h = rng.normal(size=(B, N, F))
+    ref = ol.agg_layer([h[:, k] for k in range(N)], np.kron(adj, np.eye(F)), F)
+    M = oc.csr_to_matrix((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx, np.float64)
+    got = (M @ h.reshape(B * N, F)).reshape(B, N, F)
+    for k in range(N):
+        assert np.allclose(got[:, k], ref[k], atol=1e-13)
+    assert pb.max_edges == 8 and pb.n_edges == B * 8
+    # oracle's own CSR builder agrees with the product's
+    g = oc.adj_to_csr(adj)
+    assert np.array_equal(g[1], pb.row_ptr) and np.array_equal(g[2], pb.col_idx)
+    with pytest.raises(ValueError):
+        v2xgnn.adj_to_csr(adj * 2.0)
+
+
+def test_feed_to_arrays_on_reference_payloads_and_errors():
+    f, cases = golden_forward_cases()
+    spec = GnnSpec()
+    for case in cases:
+        feed = golden_feed(f, case)
+        x, e, nbr, adj = v2xgnn.feed_to_arrays(spec, feed)
+        assert x.shape[1:] == (4, 9) and e.shape[1:] == (4, 4) and adj.shape[1:] == (4, 4)
+        assert (nbr is None) == (case != 'synthetic_b6')
+        # inverse: compact arrays rebuild the reference's dict payload exactly
+        back = ol.feed_from_compact(OSpec(), x, e, adj, nbr)
+        for k, v in feed.items():
+            assert np.array_equal(back[k], v), k
+    feed = golden_feed(f, 'env_b1')
+    for mutate in ('drop', 'shape', 'kron', 'adjshape'):
+        bad = dict(feed)
+        if mutate == 'drop':
+            del bad['D3_Neighbor_Input']
+        elif mutate == 'shape':
+            bad['D1_Edge_Input'] = np.zeros((1, 5))
+        elif mutate == 'kron':
+            A = bad['Adjacency_Matrix'].copy()
+            A[0, 1, 0] = 1
+            bad['Adjacency_Matrix'] = A
+        else:
+            bad['Adjacency_Matrix'] = np.zeros((1, 32, 32))
+        with pytest.raises(ValueError):
+            v2xgnn.feed_to_arrays(spec, bad)
+
+
+def test_batch_shard_partitions_graphs():
+    rng = np.random.default_rng(2)
+    B, N = 8, 5
+    x, e, adj = random_inputs(rng, B, N, ref_topology=False)
+    pb = PackedBatch.from_dense(x, e, adj)
+    parts = [pb.shard(r, 4) for r in range(4)]
+    assert sum(p.n_graphs for p in parts) == B and sum(p.n_edges for p in parts) == pb.n_edges
+    assert np.array_equal(np.concatenate([p.xe for p in parts]), pb.xe)
+    assert np.array_equal(np.concatenate([p.col_idx for p in parts]), pb.col_idx)
+    for r, p in enumerate(parts):
+        assert p.row_ptr[0] == 0 and p.row_ptr[-1] == p.n_edges
+        sub = PackedBatch.from_dense(x[2 * r:2 * r + 2], e[2 * r:2 * r + 2], adj[2 * r:2 * r + 2])
+        assert np.array_equal(sub.row_ptr, p.row_ptr) and sub.max_edges == p.max_edges
+    with pytest.raises(ValueError):
+        pb.shard(0, 3)

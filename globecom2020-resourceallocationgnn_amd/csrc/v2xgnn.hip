@@ -848,7 +848,6 @@ int v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_global, const floa
   if (!m || !xe || !h || !agg || !y || n_rows <= 0) FAIL(m, V2X_EINVAL, "mlp_huber_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
   CHK(ensure_rows(m, n_rows));
-  const RowMapH rm = row_map(m, n_rows);
   if (n_global <= 0) n_global = m->cfg.variable_graphs ? n_rows : n_rows / m->N;
   MlpArgs a;
   mlp_args(m, a, n_rows, xe, h, agg);
@@ -864,7 +863,7 @@ int v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_global, const floa
     if (m->cfg.variable_graphs)
       hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, m->rowloss, m->loss_dev, n_rows, 1, a.inv_denom);
     else
-      hipLaunchKernelGGL(k_loss_reduce, dim3(m->N), dim3(256), 0, st, m->rowloss, m->loss_dev, rm.n_idx, m->N, a.inv_denom);
+      hipLaunchKernelGGL(k_loss_reduce, dim3(m->N), dim3(256), 0, st, m->rowloss, m->loss_dev, n_rows / m->N, m->N, a.inv_denom);
     HIPCHK(m, hipMemcpyAsync(loss_out, m->loss_dev, (m->cfg.variable_graphs ? 1 : m->N) * sizeof(float),
                              hipMemcpyDeviceToDevice, st));
   }

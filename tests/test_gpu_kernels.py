@@ -10,7 +10,7 @@ from v2xgnn import lib as vlib
 from v2xgnn.engine import DeviceBatch, _batch_struct
 from oracle import compact as oc
 from oracle.keras_semantics import KerasAdam
-from util import (ospec, random_inputs, f32_params, assert_close, assert_grad_close, FWD_RTOL, FWD_ATOL)
+from util import (ospec, random_inputs, f32_params, assert_close, assert_fwd_close, assert_grad_close)
 
 pytestmark = pytest.mark.gpu
 
@@ -161,7 +161,7 @@ def test_node_update_fwd_bwd(N, F, L, shared, B, with_nbr):
         p = lambda t: None if t is None else t.data_ptr()
         vlib.check(lib, lib.v2x_node_update_fwd(eng._h, s, R, xe.data_ptr(), p(hp), p(ap), out.data_ptr(), None), eng._h)
         _sync()
-        assert_close(out.cpu().numpy(), ref, FWD_RTOL, FWD_ATOL, "node_update fwd stage %d" % s)
+        assert_fwd_close(out.cpu().numpy(), ref, "node_update fwd stage %d" % s)
 
         # backward of the same layer
         dpre = rng.normal(size=(R, F)).astype(np.float32)
@@ -209,7 +209,7 @@ def test_mlp_fwd_and_huber_bwd(N, F, L, shared, B):
     q = torch.empty((R, spec.n_channels), dtype=torch.float32, device="cuda:0")
     vlib.check(lib, lib.v2x_mlp_fwd(eng._h, R, xe.data_ptr(), hd.data_ptr(), ad.data_ptr(), q.data_ptr(), None), eng._h)
     _sync()
-    assert_close(q.cpu().numpy(), z[4], FWD_RTOL, FWD_ATOL, "mlp fwd")
+    assert_fwd_close(q.cpu().numpy(), z[4], "mlp fwd")
 
     # targets: some inside the quadratic zone of Huber, some in the linear zone
     y = (z[4] + rng.normal(0, 1.5, size=z[4].shape)).astype(np.float32)

@@ -9,7 +9,7 @@ import pytest
 import v2xgnn
 from v2xgnn import GnnSpec, PackedBatch, GnnEngine, BS
 from oracle import compact as oc
-from util import (ospec, random_inputs, f32_params, assert_close, assert_grad_close, FWD_RTOL, FWD_ATOL,
+from util import (ospec, random_inputs, f32_params, assert_close, assert_fwd_close, assert_grad_close,
                   golden_forward_cases, golden_keras_list, golden_feed, GOLDEN)
 
 pytestmark = pytest.mark.gpu
@@ -57,14 +57,17 @@ def test_forward_and_gradients_vs_oracle(N, F, L, shared, B):
     os_ = ospec(spec)
     q_ref, cache = oc.forward(os_, P, x.reshape(B * N, -1).astype(np.float64), e.reshape(B * N, -1).astype(np.float64), M)
     q = eng.forward(pb)
-    assert_close(q, q_ref, FWD_RTOL, FWD_ATOL, "forward q")
+    assert_fwd_close(q, q_ref, "forward q")
     # device-resident batch gives the same bits as the host batch
     db = eng.to_device(pb)
     q2 = eng.forward(db).cpu().numpy()
     assert np.array_equal(q, q2)
 
     y = (q_ref + rng.normal(0, 1.2, size=q_ref.shape)).astype(np.float32)
-    loss_ref, dq = oc.huber_loss_and_grad(os_, q_ref, y.astype(np.float64))
+    # Huber's gradient is clip(q - y): with |q| in the hundreds..thousands (random weights, the constant
+    # 10 dBm power feature, 18-neighbour sums) the fp32 rounding of q itself moves q - y by ~1e-3 relative.
+    # Forward parity is asserted above; the backward is checked for the SAME q the kernels differentiate.
+    loss_ref, dq = oc.huber_loss_and_grad(os_, q.astype(np.float64), y.astype(np.float64))
     g_ref = oc.backward(os_, P, cache, dq)
     loss = eng.forward_backward(pb, y)
     assert_close(loss, loss_ref, 2e-4, 1e-6, "per-output huber loss")

@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""Headline benchmark: graph-instances/s of one Model.fit step (forward + Huber + backward + Adam,
+plus the RCCL gradient all-reduce when N > 1) of the GNN Q-network on synthetic 20-V2V-link graphs,
+feat_dim 64, 2 message-passing layers, batch 4096 per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel's algorithmic bytes / its average launch duration, measured live
+                  with HIP events around every launch of an instrumented (eager) pass of the same steps
+  cpu_baseline -- the CPU oracle (a numpy restatement of the reference formulation's math, NOT
+                  Keras/TF1) timed on this box's host cores on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+FP32_MFMA_PEAK_TF = 157.3
+
+
+def synth_batch(rng, B, N, C=4):
+    """feature statistics measured from the reference simulator at N=20; topology:
+    every link q has one receiver dest[q] != q, edge p->q iff p != q and p != dest[q] (in-degree N-2)."""
+    x = np.concatenate([rng.normal(0.84, 0.39, size=(B, N, C)), rng.normal(0.60, 0.21, size=(B, N, C)),
+                        np.full((B, N, 1), 10.0)], axis=2).astype(np.float32)
+    e = rng.normal(0.88, 0.11, size=(B, N, C)).astype(np.float32)
+    dest = rng.integers(0, N - 1, size=(B, N))
+    dest = dest + (dest >= np.arange(N)[None, :])
+    adj = np.ones((B, N, N), np.float32) - np.eye(N, dtype=np.float32)[None]
+    adj[np.repeat(np.arange(B), N), dest.reshape(-1), np.tile(np.arange(N), B)] = 0.0
+    y = rng.normal(2.5, 1.0, size=(B * N, C)).astype(np.float32)
+    return x, e, adj, y
+
+
+def algorithmic_bytes(name, B, N, F, E, C=4, Dn=9, De=4):
+    """Unique fp32/int32 bytes a kernel must move per launch (inputs read once + outputs written once;
+    weights are cache-resident and not counted) -- the per-graph terms of SURVEY.md 8(d8) x B graphs."""
+    R = B * N
+    csr = 4 * E + 4 * (R + 1)
+    table = {
+        "k_node_fwd_embed": 4 * R * (Dn + De) + 4 * R * F,
+        "k_agg_fwd": 8 * R * F + csr,
+        "k_node_fwd": 4 * R * (2 * F + Dn + De) + 4 * R * F,
+        "k_mlp_fwd": 4 * R * (Dn + 2 * F) + 4 * R * C,
+        "k_mlp_bwd": 4 * R * 2 * C + 4 * R * 2 * F,                 # q, y in; [dh|dagg] out (hidden grads stay on chip in the model)
+        "k_agg_bwd": 4 * R * 2 * F + 4 * R * F + 4 * R * F + csr,   # [dh|dagg] + mask in, dpre out
+        "k_node_dgrad": 4 * R * F + 4 * R * 2 * F,
+        "k_wgrad_gnn": 4 * R * (2 * F + Dn + De) + 4 * R * F,
+        "k_wgrad_embed": 4 * R * (Dn + De) + 4 * R * F,
+        "k_wgrad_dense0": 4 * R * (Dn + 2 * F) + 4 * R * 80,
+        "k_wgrad_dense1": 4 * R * (80 + 40),
+        "k_wgrad_dense2": 4 * R * (40 + 20),
+        "k_wgrad_dense3": 4 * R * (20 + C),
+    }
+    return table.get(name)
+
+
+def step_bytes_per_graph(N, F, L, E, C=4, Dn=9, De=4):
+    """SURVEY.md 8(d8) layer-wise model: step = 3 x forward bytes (256,596 B at cfg-2)."""
+    fwd = (4 * N * (Dn + De) + 4 * N * F + (L + 1) * (8 * N * F + 4 * E + 4 * (N + 1))
+           + L * (4 * N * (2 * F + Dn + De) + 4 * N * F) + 4 * N * (Dn + 2 * F) + 4 * N * C)
+    return 3 * fwd
+
+
+def cpu_baseline(N, F, L, share, B, budget_s=15.0):
+    """Oracle (fp32, compact CSR formulation) fit steps on the host CPU; bounded to ~budget_s seconds."""
+    from oracle import compact as oc
+    from oracle.spec import GnnSpec as OSpec
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        thr = len(os.sched_getaffinity(0))
+    spec = OSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=share)
+    rng = np.random.default_rng(1001)
+    x, e, adj, y = synth_batch(rng, B, N)
+    graph = oc.adj_to_csr(adj)
+    om = oc.OracleModel(spec, oc.init_params(spec, rng, np.float32), dtype=np.float32)
+    xr, er = x.reshape(B * N, -1), e.reshape(B * N, -1)
+    om.train_step(xr, er, graph, y)                # warm-up (BLAS init, page faults)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        om.train_step(xr, er, graph, y)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 200:
+            break
+    return {"value": round(B * n / dt, 1), "unit": "graph-instances/s", "cores": int(thr), "kind": "port",
+            "sample": "%d fit steps of B=%d (N=%d,F=%d,L=%d,%s weights), numpy fp32 CSR oracle, %.1f s; "
+                      "a CPU restatement of the reference math, not Keras/TF1"
+                      % (n, B, N, F, L, "shared" if share else "per-node", dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="graphs per GPU (weak scaling)")
+    ap.add_argument("--nodes", type=int, default=20)
+    ap.add_argument("--feat", type=int, default=64)
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--share-weights", action="store_true", help="one shared weight set instead of the reference's per-node sets")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import torch
+    import v2xgnn
+    from v2xgnn import GnnSpec, PackedBatch, GnnEngine
+    from v2xgnn.dp import DataParallelTrainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    N, F, L, B = args.nodes, args.feat, args.layers, args.batch
+    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=args.share_weights)
+    eng = GnnEngine(spec, device=local, use_graph=not args.no_graph)
+    wrng = np.random.default_rng(1001)             # identical weights on every rank
+    shapes = v2xgnn.keras_list_shapes(spec)
+    eng.set_weights([np.zeros(s, np.float32) if len(s) == 1 else
+                     wrng.uniform(-np.sqrt(6.0 / sum(s)), np.sqrt(6.0 / sum(s)), size=s).astype(np.float32) for s in shapes])
+    x, e, adj, y = synth_batch(np.random.default_rng(1001 + 7919 * rank), B, N)
+    pb = PackedBatch.from_dense(x, e, adj)
+    db = eng.to_device(pb)
+    yd = torch.from_numpy(y).to(db.device)
+    n_global = B * world
+    trainer = DataParallelTrainer(eng) if world > 1 else None
+
+    def one_step():
+        if trainer is not None:
+            trainer.train_step(db, yd, n_graphs_global=n_global, want_loss=False)
+        else:
+            eng.train_step(db, yd, n_global=n_global, want_loss=False)
+
+    stream = torch.cuda.Stream(device=local)
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            one_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = n_global * args.steps / elapsed
+
+    # sanity: the timed steps really trained (finite loss, weights moved)
+    loss = eng.forward_backward(db, yd, n_global=n_global)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(loss).all()), "non-finite loss after the timed steps"
+
+    roofline = None
+    kernels = None
+    if rank == 0 and not args.no_roofline:
+        E = pb.n_edges
+        eng.profile(True)
+        with torch.cuda.stream(stream):
+            for _ in range(min(args.steps, 50)):
+                eng.train_step(db, yd, n_global=n_global, want_loss=False)
+            torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile(False)
+        tot = sum(ms for _, ms in prof.values())
+        kernels = {k: {"calls": c, "avg_us": round(1e3 * ms / c, 2), "share": round(ms / tot, 3)} for k, (c, ms) in
+                   sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        dom = max((k for k in prof if algorithmic_bytes(k, B, N, F, E) is not None), key=lambda k: prof[k][1])
+        calls, ms = prof[dom]
+        bytes_per_launch = algorithmic_bytes(dom, B, N, F, E)
+        achieved = bytes_per_launch / (1e-3 * ms / calls) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(1e3 * ms / calls, 2),
+                    "step_hbm_frac": round(step_bytes_per_graph(N, F, L, E // B) * (value / world) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(N, F, L, args.share_weights, B, args.cpu_seconds)
+
+    if rank == 0:
+        out = {"metric": "graph-instances/sec (fwd+bwd), 20-V2V-link graphs, batch 4096",
+               "value": round(value, 1), "unit": "graph-instances/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "BASELINE.json configs[1]: %d V2V links, feat_dim=%d, %d-layer GNN, batch %d "
+                                      "synthetic graphs per GPU, fit step = fwd+Huber+bwd+Adam%s"
+                                      % (N, F, L, B, "+RCCL grad all-reduce" if world > 1 else ""),
+                          "weights": "shared" if args.share_weights else "per-node (reference semantics)",
+                          "global_batch": n_global, "n_params": eng.n_params,
+                          "launch": "eager" if args.no_graph else "hipGraph replay",
+                          "parallelism": "dp%d" % world},
+               "roofline": roofline, "cpu_baseline": cpu}
+        if kernels is not None:
+            out["kernels"] = kernels
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -235,3 +235,14 @@ def test_replay_targets_from_captured_agent_payload():
     hist = brain.train_dnn(x, y, B)
     got = [hist.history['D%d_Decide_Output_loss' % k][0] for k in range(1, 5)]
     assert_close(got, loss_ref, 5e-4, 1e-6, "losses on the captured replay payload")
+
+
+def test_grad_tensor_aliases_library_memory():
+    """The torch view handed to the RCCL all-reduce must alias (not copy) the engine's gradient buffer."""
+    import torch
+    eng = GnnEngine(GnnSpec())
+    t = eng.grad_tensor()
+    assert t.data_ptr() == int(eng._lib.v2x_grad_ptr(eng._h)) and t.numel() == eng.n_params and t.is_cuda
+    t.fill_(3.0)
+    torch.cuda.synchronize()
+    assert (eng.get_grad_flat() == 3.0).all()

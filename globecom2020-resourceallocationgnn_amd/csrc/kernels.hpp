@@ -24,6 +24,7 @@
 namespace v2x {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) float* gfloat_p;   // explicit GLOBAL pointer (global_load, counted vmcnt)
 #define V2X_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 constexpr int XE = 16;          // packed [x|e|pad] width
@@ -38,16 +39,31 @@ __device__ __forceinline__ int real_row(const RowPad& p, int rp) {
   return rr < p.k_real ? rr : -1;
 }
 
-// copy W[k_real][n_real] (global, row-major) into an LDS image [kp][ld] with zero padding
-__device__ __forceinline__ void fill_weight_image(float* sW, int ld, int kp, int np, const float* Wg,
-                                                  RowPad pad, int n_real) {
-  const int c4n = np >> 2;
-  for (int i = threadIdx.x; i < kp * c4n; i += blockDim.x) {
-    const int rp = i / c4n, c = (i - rp * c4n) << 2;
+// copy W[k_real][n_real] (global, row-major) into an LDS image [KP][LD] with zero padding.
+// Compile-time shape => constant divisors, fully unrolled; every global load is unconditional from an
+// always-valid address (masked in registers afterwards) so that all PASSES loads are in flight at once:
+// a conditional load makes hipcc branch around each one and serialises the L2 round trips.
+template <int KP, int NP, int LD>
+__device__ __forceinline__ void fill_weight_image(float* sW, const float* Wg, RowPad pad, int n_real) {
+  constexpr int C4 = NP / 4;
+  constexpr int TOTAL = KP * C4;
+  constexpr int PASSES = (TOTAL + 255) / 256;
+  float4 v[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int i = threadIdx.x + 256 * p;
+    const int rp = i / C4, c = (i - rp * C4) << 2;
     const int rr = real_row(pad, rp);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (rr >= 0 && c < n_real) v = *reinterpret_cast<const float4*>(Wg + (int64_t)rr * n_real + c);
-    *reinterpret_cast<float4*>(sW + rp * ld + c) = v;
+    const bool ok = i < TOTAL && rr >= 0 && c < n_real;
+    const float4 t = *reinterpret_cast<const float4*>(Wg + (ok ? (int64_t)rr * n_real + c : 0));
+    const float mk = ok ? 1.f : 0.f;
+    v[p] = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
+  }
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int i = threadIdx.x + 256 * p;
+    const int rp = i / C4, c = (i - rp * C4) << 2;
+    if (i < TOTAL) *reinterpret_cast<float4*>(sW + rp * LD + c) = v[p];
   }
 }
 __device__ __forceinline__ void fill_bias(float* sB, int np, const float* bg, int n_real) {
@@ -65,7 +81,8 @@ struct AggArgs {
   const int32_t* graph_off;             // [B+1] or null (fixed n_nodes)
   const int32_t* row_ptr;               // [R+1]
   const int32_t* col_idx;               // [E]
-  int n_graphs, n_nodes, F, lpr_shift;  // lanes per row = F/4 = 1 << lpr_shift
+  int g_base, g_end;                    // graphs [g_base, g_end) of the batch are processed by this launch
+  int n_nodes, F, lpr_shift;            // lanes per row = F/4 = 1 << lpr_shift
   int gpw;                              // graphs per workgroup (power of two)
   int rows_cap, edges_cap, mask_words;  // LDS capacities
   int transpose;                        // 0: out[q] = sum_{p->q} src[p];  1: out[p] = sum_{p->q} src[q]
@@ -80,8 +97,8 @@ __global__ __launch_bounds__(256) void k_agg(AggArgs a) {
   unsigned* sM = reinterpret_cast<unsigned*>(sCol + a.edges_cap);  // [rows_cap][mask_words]
 
   const int tid = threadIdx.x;
-  const int g0 = blockIdx.x * a.gpw;
-  const int g1 = min(g0 + a.gpw, a.n_graphs);
+  const int g0 = a.g_base + blockIdx.x * a.gpw;
+  const int g1 = min(g0 + a.gpw, a.g_end);
   const int r_begin = a.graph_off ? a.graph_off[g0] : g0 * a.n_nodes;
   const int r_end = a.graph_off ? a.graph_off[g1] : g1 * a.n_nodes;
   const int nrows = r_end - r_begin;
@@ -106,12 +123,15 @@ __global__ __launch_bounds__(256) void k_agg(AggArgs a) {
   __syncthreads();
 
   if (a.transpose) {
-    // transposed adjacency as per-source bit masks (integer atomics: order-independent result)
-    for (int r = tid; r < nrows; r += 256) {
+    // transposed adjacency as per-source bit masks (integer atomics: order-independent result).
+    // 32 threads per destination row, one edge each per pass: a short dependent chain instead of a
+    // per-row serial loop over the in-edges.
+    for (int i = tid; i < nrows * 32; i += 256) {
+      const int r = i >> 5, sl = i & 31;
       int gi = 0;
       while (gi + 1 < a.gpw && sG[gi + 1] <= r) ++gi;
       const int gb = sG[gi], ql = r - gb;
-      for (int e = sRp[r]; e < sRp[r + 1]; ++e)
+      for (int e = sRp[r] + sl; e < sRp[r + 1]; e += 32)
         atomicOr(&sM[(gb + sCol[e]) * a.mask_words + (ql >> 5)], 1u << (ql & 31));
     }
     __syncthreads();
@@ -124,8 +144,14 @@ __global__ __launch_bounds__(256) void k_agg(AggArgs a) {
   const int gi = worker / wpg, wr = worker - gi * wpg;
   if (g0 + gi >= g1) return;
   const int gb = sG[gi], ng = sG[gi + 1] - gb;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int q = wr; q < ng; q += wpg) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t row = r_begin + gb + q;
+    // epilogue operands first: their HBM latency overlaps the LDS gather below
+    float4 addv = zero4, mk = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a.add) addv = *reinterpret_cast<const float4*>(a.add + row * a.add_stride + li4);     // wave-uniform branch
+    if (a.mask) mk = *reinterpret_cast<const float4*>(a.mask + row * a.F + li4);
+    float4 acc = zero4;
     if (!a.transpose) {
       const int e1 = sRp[gb + q + 1];
       int e = sRp[gb + q];
@@ -147,24 +173,27 @@ __global__ __launch_bounds__(256) void k_agg(AggArgs a) {
     } else {
       for (int wd = 0; wd < a.mask_words; ++wd) {
         unsigned mbits = sM[(gb + q) * a.mask_words + wd];
-        while (mbits) {
-          const int b = __builtin_ctz(mbits);
-          mbits &= mbits - 1;
-          const float4 v = *reinterpret_cast<const float4*>(sT + (gb + (wd << 5) + b) * a.F + li4);
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        const float* base = sT + (gb + (wd << 5)) * a.F + li4;
+        while (mbits) {               // ascending q; up to 4 independent LDS gathers in flight
+          const int b0 = __builtin_ctz(mbits); mbits &= mbits - 1;
+          const int b1 = mbits ? __builtin_ctz(mbits) : -1; if (mbits) mbits &= mbits - 1;
+          const int b2 = mbits ? __builtin_ctz(mbits) : -1; if (mbits) mbits &= mbits - 1;
+          const int b3 = mbits ? __builtin_ctz(mbits) : -1; if (mbits) mbits &= mbits - 1;
+          const float4 v0 = *reinterpret_cast<const float4*>(base + b0 * a.F);
+          const float4 v1 = *reinterpret_cast<const float4*>(base + (b1 < 0 ? b0 : b1) * a.F);
+          const float4 v2 = *reinterpret_cast<const float4*>(base + (b2 < 0 ? b0 : b2) * a.F);
+          const float4 v3 = *reinterpret_cast<const float4*>(base + (b3 < 0 ? b0 : b3) * a.F);
+          const float m1 = b1 < 0 ? 0.f : 1.f, m2 = b2 < 0 ? 0.f : 1.f, m3 = b3 < 0 ? 0.f : 1.f;
+          acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+          acc.x += v1.x * m1; acc.y += v1.y * m1; acc.z += v1.z * m1; acc.w += v1.w * m1;
+          acc.x += v2.x * m2; acc.y += v2.y * m2; acc.z += v2.z * m2; acc.w += v2.w * m2;
+          acc.x += v3.x * m3; acc.y += v3.y * m3; acc.z += v3.z * m3; acc.w += v3.w * m3;
         }
       }
     }
-    const int64_t row = r_begin + gb + q;
-    if (a.add) {
-      const float4 v = *reinterpret_cast<const float4*>(a.add + row * a.add_stride + li4);
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    if (a.mask) {
-      const float4 mk = *reinterpret_cast<const float4*>(a.mask + row * a.F + li4);
-      acc.x = mk.x > 0.f ? acc.x : 0.f; acc.y = mk.y > 0.f ? acc.y : 0.f;
-      acc.z = mk.z > 0.f ? acc.z : 0.f; acc.w = mk.w > 0.f ? acc.w : 0.f;
-    }
+    acc.x += addv.x; acc.y += addv.y; acc.z += addv.z; acc.w += addv.w;
+    acc.x = mk.x > 0.f ? acc.x : 0.f; acc.y = mk.y > 0.f ? acc.y : 0.f;
+    acc.z = mk.z > 0.f ? acc.z : 0.f; acc.w = mk.w > 0.f ? acc.w : 0.f;
     *reinterpret_cast<float4*>(a.out + row * a.F + li4) = acc;
   }
 }
@@ -180,10 +209,15 @@ struct GemmArgs {
   RowPad pad;
   float* out; int out_stride;
   int relu;
-  int n_idx, row_stride, base_mul;      // row(idx) = idx*row_stride + slot*base_mul
+  int n_idx, row_stride, base_mul;      // row(idx) = (idx_base + idx)*row_stride + slot*base_mul
+  int idx_base;
 };
 
-template <int F, bool HAS0, bool HAS2, bool DGRAD, int RT>
+// Persistent form: grid = (workgroups per slot, slots).  A workgroup stages its slot's weight image in LDS
+// ONCE, then its 4 waves walk a contiguous range of 16-row tiles (wave-interleaved), each wave keeping the
+// NEXT tile's activation fragments in flight (register double buffer) while the MFMAs of the current tile
+// run; no barrier in the loop.  The host sizes the grid so that every SIMD gets the same number of tiles.
+template <int F, bool HAS0, bool HAS2, bool DGRAD>
 __global__ __launch_bounds__(256) void k_gemm_rows(GemmArgs a) {
   constexpr int FB = F / 16;
   constexpr int KB = DGRAD ? FB : ((HAS0 ? FB : 0) + 1 + (HAS2 ? FB : 0));
@@ -196,87 +230,93 @@ __global__ __launch_bounds__(256) void k_gemm_rows(GemmArgs a) {
 
   const int slot = blockIdx.y;
   const float* Wg = a.W + slot * a.slot_stride;
-  fill_weight_image(sW, LDW, KP, F, Wg, a.pad, F);
-  if (!DGRAD) fill_bias(sB, F, Wg + (int64_t)a.pad.k_real * F, F);
-
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane & 15, kg = lane >> 4;
 
-  // ---- B operand (activations): one float4 per 16-wide K block, straight from HBM
-  float4 bf[RT][KB];
-  int64_t rows[RT];
-  bool valid[RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int idx = blockIdx.x * (64 * RT) + wv * (16 * RT) + rt * 16 + j;
-    valid[rt] = idx < a.n_idx;
-    const int64_t row = (int64_t)min(idx, a.n_idx - 1) * a.row_stride + slot * a.base_mul;
-    rows[rt] = row;
+  const int n_tiles = (a.n_idx + 15) >> 4;
+  const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_end = min((int)(blockIdx.x + 1) * per, n_tiles);
+
+  // B operand (activations) of one 16-row tile: one float4 per 16-wide K block, straight HBM -> VGPR.
+  // Rows past n_idx are clamped (valid address, result dropped at the store).
+  auto load_tile = [&](int t, float4 (&bf)[KB], int64_t& row) {
+    const int idx = min(t * 16 + j, a.n_idx - 1);
+    row = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
     int kb = 0;
     if (HAS0 || DGRAD) {
 #pragma unroll
       for (int b = 0; b < FB; ++b)
-        bf[rt][kb++] = *reinterpret_cast<const float4*>(a.seg0 + row * a.seg0_stride + b * 16 + 4 * kg);
+        bf[kb++] = *reinterpret_cast<const float4*>(a.seg0 + row * a.seg0_stride + b * 16 + 4 * kg);
     }
     if (!DGRAD) {
-      bf[rt][kb++] = *reinterpret_cast<const float4*>(a.xe + row * XE + 4 * kg);
+      bf[kb++] = *reinterpret_cast<const float4*>(a.xe + row * XE + 4 * kg);
       if (HAS2) {
 #pragma unroll
         for (int b = 0; b < FB; ++b)
-          bf[rt][kb++] = *reinterpret_cast<const float4*>(a.seg2 + row * a.seg2_stride + b * 16 + 4 * kg);
+          bf[kb++] = *reinterpret_cast<const float4*>(a.seg2 + row * a.seg2_stride + b * 16 + 4 * kg);
       }
     }
-  }
+  };
+
+  auto compute_store = [&](int t, const float4 (&bf)[KB], int64_t row) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float w[4];
+        if (!DGRAD) {
+          // A[i = out feature nt*16+j][k = kb*16 + 4*kg + s]  = W[k][i]  (column of the image)
+#pragma unroll
+          for (int s = 0; s < 4; ++s) w[s] = sW[(kb * 16 + 4 * kg + s) * LDW + nt * 16 + j];
+        } else {
+          // A[i = input feature][k = out feature]  = W[i][k]  (row of the image, skipping the xe rows)
+          const int orow = nt < FB ? nt * 16 : F + XE + (nt - FB) * 16;
+          const float4 tw = *reinterpret_cast<const float4*>(sW + (orow + j) * LDW + kb * 16 + 4 * kg);
+          w[0] = tw.x; w[1] = tw.y; w[2] = tw.z; w[3] = tw.w;
+        }
+        acc[nt] = V2X_MFMA(w[0], bf[kb].x, acc[nt]);
+        acc[nt] = V2X_MFMA(w[1], bf[kb].y, acc[nt]);
+        acc[nt] = V2X_MFMA(w[2], bf[kb].z, acc[nt]);
+        acc[nt] = V2X_MFMA(w[3], bf[kb].w, acc[nt]);
+      }
+    }
+    // epilogue: lane holds out[row j][nt*16 + 4*kg .. +3]
+    if (t * 16 + j < a.n_idx) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 v = acc[nt];
+        if (!DGRAD) {
+          const float4 b = *reinterpret_cast<const float4*>(sB + nt * 16 + 4 * kg);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          if (a.relu) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          }
+        }
+        *reinterpret_cast<float4*>(a.out + row * a.out_stride + nt * 16 + 4 * kg) =
+            make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  };
+
+  int t = blockIdx.x * per + wv;
+  float4 bfA[KB], bfB[KB];
+  int64_t rowA = 0, rowB = 0;
+  if (t < t_end) load_tile(t, bfA, rowA);          // in flight while the weights are staged
+  fill_weight_image<KP, F, LDW>(sW, Wg, a.pad, F);
+  if (!DGRAD) fill_bias(sB, F, Wg + (int64_t)a.pad.k_real * F, F);
   __syncthreads();
 
-  f32x4 acc[RT][NT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int kb = 0; kb < KB; ++kb) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      float w[4];
-      if (!DGRAD) {
-        // A[i = out feature nt*16+j][k = kb*16 + 4*kg + s]  = W[k][i]  (column of the image)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) w[s] = sW[(kb * 16 + 4 * kg + s) * LDW + nt * 16 + j];
-      } else {
-        // A[i = input feature][k = out feature]  = W[i][k]  (row of the image, skipping the xe rows)
-        const int orow = nt < FB ? nt * 16 : F + XE + (nt - FB) * 16;
-        const float4 t = *reinterpret_cast<const float4*>(sW + (orow + j) * LDW + kb * 16 + 4 * kg);
-        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        acc[rt][nt] = V2X_MFMA(w[0], bf[rt][kb].x, acc[rt][nt]);
-        acc[rt][nt] = V2X_MFMA(w[1], bf[rt][kb].y, acc[rt][nt]);
-        acc[rt][nt] = V2X_MFMA(w[2], bf[rt][kb].z, acc[rt][nt]);
-        acc[rt][nt] = V2X_MFMA(w[3], bf[rt][kb].w, acc[rt][nt]);
-      }
-    }
-  }
-
-  // ---- epilogue: lane holds out[row j][nt*16 + 4*kg .. +3]
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    if (!valid[rt]) continue;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      f32x4 v = acc[rt][nt];
-      if (!DGRAD) {
-        const float4 b = *reinterpret_cast<const float4*>(sB + nt * 16 + 4 * kg);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        if (a.relu) {
-          v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f);
-          v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        }
-      }
-      *reinterpret_cast<float4*>(a.out + rows[rt] * a.out_stride + nt * 16 + 4 * kg) =
-          make_float4(v[0], v[1], v[2], v[3]);
+  for (; t < t_end; t += 8) {
+    const bool haveB = t + 4 < t_end;              // wave-uniform
+    if (haveB) load_tile(t + 4, bfB, rowB);
+    compute_store(t, bfA, rowA);
+    if (haveB) {
+      if (t + 8 < t_end) load_tile(t + 8, bfA, rowA);
+      compute_store(t + 4, bfB, rowB);
     }
   }
 }
@@ -293,7 +333,7 @@ struct MlpArgs {
   const float* y; float inv_denom;
   float* dq; float* dz1; float* dz2; float* dz3; float* gha;   // gha[R][2F] = [dh | dagg]
   float* rowloss;                                       // [R] sum_c huber(y - q)
-  int n_idx, row_stride, base_mul;
+  int n_idx, row_stride, base_mul, idx_base;
 };
 
 template <int F>
@@ -322,10 +362,10 @@ __device__ __forceinline__ void mlp_fill_lds(float* smem, const MlpArgs& a, int 
   // Dense-0 rows [h(F) | x(2C+1) | agg(F)]: the image keeps xe's 16 columns; the edge-feature
   // and pad rows are ZERO so the packed xe block can be used as-is (BS_brain.py:175 feeds
   // only the node features to the decision DNN).
-  fill_weight_image(smem + L::W1, LD1, L::K1P, H1, w1, RowPad{F + 2 * C + 1, XE - (2 * C + 1), k1}, H1);
-  fill_weight_image(smem + L::W2, LD2, H1, H2P, w2, RowPad{H1, 0, H1}, H2);
-  fill_weight_image(smem + L::W3, LD3, H2P, H3P, w3, RowPad{H2, H2P - H2, H2}, H3);
-  fill_weight_image(smem + L::W4, LD4, H3P, CP, w4, RowPad{H3, H3P - H3, H3}, C);
+  fill_weight_image<L::K1P, H1, LD1>(smem + L::W1, w1, RowPad{F + 2 * C + 1, XE - (2 * C + 1), k1}, H1);
+  fill_weight_image<H1, H2P, LD2>(smem + L::W2, w2, RowPad{H1, 0, H1}, H2);
+  fill_weight_image<H2P, H3P, LD3>(smem + L::W3, w3, RowPad{H2, H2P - H2, H2}, H3);
+  fill_weight_image<H3P, CP, LD4>(smem + L::W4, w4, RowPad{H3, H3P - H3, H3}, C);
   if (with_bias) {
     fill_bias(smem + L::B1, H1, w1 + (int64_t)k1 * H1, H1);
     fill_bias(smem + L::B2, H2P, w2 + H1 * H2, H2);
@@ -399,7 +439,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
   for (int rt = 0; rt < RT; ++rt) {
     const int idx = blockIdx.x * (64 * RT) + wv * (16 * RT) + rt * 16 + j;
     valid[rt] = idx < a.n_idx;
-    const int64_t row = (int64_t)min(idx, a.n_idx - 1) * a.row_stride + slot * a.base_mul;
+    const int64_t row = (int64_t)(a.idx_base + min(idx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
     rows[rt] = row;
 #pragma unroll
     for (int b = 0; b < FB; ++b) z0[b][rt] = ld4(a.h + row * F + b * 16 + 4 * kg);
@@ -501,7 +541,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
   for (int rt = 0; rt < RT; ++rt) {
     const int idx = blockIdx.x * (64 * RT) + wv * (16 * RT) + rt * 16 + j;
     valid[rt] = idx < a.n_idx;
-    const int64_t row = (int64_t)min(idx, a.n_idx - 1) * a.row_stride + slot * a.base_mul;
+    const int64_t row = (int64_t)(a.idx_base + min(idx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
     rows[rt] = row;
     g4[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (4 * kg < a.C) {
@@ -596,92 +636,266 @@ struct WgradArgs {
   float* slab; int64_t slab_stride;               // slab[chunk][P]
   int64_t layer_off; int64_t slot_stride;         // where this layer's (slot 0) block starts in P
   int n_idx, row_stride, base_mul, chunk;         // idx range of chunk c: [c*chunk, (c+1)*chunk)
+  const float* zeros;                             // >= 16 B of zeros (source of absent segments)
+  int idx_base, chunk_base;                       // sub-range of the batch; first slab index of this launch
+  int n_chunks;                                   // workgroups (slabs) of THIS role; blockIdx.x >= n_chunks exits
+  int kind;                                       // WG_KIND_*: selects the compile-time operand widths
 };
 
-constexpr int WG_TR = 64;   // rows per LDS tile
+constexpr int WG_TR = 16;        // rows per MFMA block (chunk sizes are multiples of it)
 
-template <int TPW>
-__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int ldi = a.kp + 4, ldd = a.np + 4;
-  float* sIn = smem;                    // [WG_TR][ldi]
-  float* sD = smem + WG_TR * ldi;       // [WG_TR][ldd]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// ---- operand of width W (multiple of 16) in MFMA fragment layout, straight from HBM -------------------------
+// The assignment of features to (tile, lane) inside an operand is free, so every full group of 64 features is
+// labelled   feature = 64*g + 4*lane + t   (t = tile within the group): ONE float4 load per lane and k-step (a
+// full 256-byte row per 16 lanes) feeds FOUR tiles.  The remaining 16-wide tiles use feature = 16*r + lane (dword
+// loads).  A 144-wide GNN input is 3 loads per k-step instead of 9, and two blocks in flight stay below the
+// 6-bit vmcnt counter (above it hipcc falls back to vmcnt(0) and the prefetch is lost).
+template <int W>
+struct WgOperand {
+  static constexpr int G = W / 64;              // float4 groups
+  static constexpr int R = (W % 64) / 16;       // dword tiles
+  static constexpr int T = W / 16;              // MFMA tiles
+  f32x4 g[G > 0 ? G : 1][4];                    // [group][k-step]
+  float d[R > 0 ? R : 1][4];                    // [tile][k-step]
+  // value of tile q at k-step s
+  __device__ __forceinline__ float get(int q, int s) const {
+    if (q < 4 * G) {
+      return g[q >> 2][s][q & 3];
+    }
+    return d[q - 4 * G][s];
+  }
+  // feature (column inside the operand) that (tile q, lane index i) stands for
+  static __device__ __forceinline__ int feature(int q, int i) {
+    return q < 4 * G ? 64 * (q >> 2) + 4 * i + (q & 3) : 64 * G + 16 * (q - 4 * G) + i;
+  }
+};
+
+// source of one operand: wave-uniform base + row stride, real width (columns >= width are clamped: the dW entries
+// they feed are never written)
+struct WgSrc { gfloat_p p; unsigned stride; int width; };
+
+template <int W>
+__device__ __forceinline__ void wg_load(WgOperand<W>& o, const WgSrc& src, unsigned row, int s, int j, float mk) {
+  if constexpr (W > 0) {
+    const unsigned base = row * src.stride;
+#pragma unroll
+    for (int g = 0; g < WgOperand<W>::G; ++g) {      // widths that are multiples of 64 are always complete
+      typedef const __attribute__((address_space(1))) f32x4* gvec_p;
+      const f32x4 v = *(gvec_p)(src.p + base + 64 * g + 4 * j);
+      o.g[g][s] = v * mk;
+    }
+#pragma unroll
+    for (int r = 0; r < WgOperand<W>::R; ++r) {
+      const int c = min(64 * WgOperand<W>::G + 16 * r + j, src.width - 1);
+      o.d[r][s] = src.p[base + c] * mk;
+    }
+  }
+}
+
+// K operands K0|K1|K2 (compile-time padded widths, 0 = absent), N operand NW.  Every wave owns ALL output tiles for
+// ITS OWN 16-row blocks (blocks wv, wv+4, ... of the chunk): each element is loaded from HBM exactly once, 4*KT*NT
+// MFMAs per block (4.6k cycles for a GNN stage) run while the next block's loads are in flight (register double
+// buffer, branch-free steady state, counted vmcnt), no LDS or barrier in the loop; the four accumulator sets are
+// summed through LDS once at the end and written as float4.  (Measured alternatives, all ~2x slower: LDS-transposed
+// tiles with a barrier per tile; a 2 x 2 tile split over the waves that loads every operand twice; dword-only
+// fragment loads; single buffering at 4 waves/SIMD -- waves sharing a SIMD run in lockstep, so occupancy alone
+// does not overlap memory and MFMA phases.)
+template <int K0, int K1, int K2, int NW>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, const int bx, const int slot) {
+  constexpr int T0 = K0 / 16, T1 = K1 / 16, T2 = K2 / 16, KT = T0 + T1 + T2, NT = NW / 16;
+  if (bx >= a.n_chunks) return;                                  // roles have work-proportional grids
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
   const int j = lane & 15, kg = lane >> 4;
-  const int slot = blockIdx.y;
-  const int KT = a.kp >> 4, NT = a.np >> 4, ntiles = KT * NT;
-  const int i_begin = blockIdx.x * a.chunk, i_end = min(i_begin + a.chunk, a.n_idx);
+  const int i_begin = bx * a.chunk, i_end = min(i_begin + a.chunk, a.n_idx);
 
-  f32x4 acc[TPW];
+  // (the descriptor was copied out of the kernarg segment as raw words: cast to the global address space
+  //  explicitly, else hipcc emits flat loads and waits vmcnt(0) lgkmcnt(0) before every MFMA)
+  WgSrc src[3], srcn;
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
+  for (int i = 0; i < 3; ++i) {
+    const bool have = i < a.n_seg && a.seg[i].ptr != nullptr;
+    src[i].p = (gfloat_p)(have ? a.seg[i].ptr : a.zeros);
+    src[i].stride = have ? a.seg[i].stride : 0;
+    src[i].width = have ? a.seg[i].width : 64;               // zero buffer: 64 floats, stride 0
+  }
+  srcn.p = (gfloat_p)a.dpre; srcn.stride = a.d_stride; srcn.width = a.n_real;
 
-  const int kc4 = a.kp >> 2, nc4 = a.np >> 2;
-  for (int i0 = i_begin; i0 < i_end; i0 += WG_TR) {
-    // ---- stage the input tile [64][kp] (zero padded) and the dpre tile [64][np]
-    for (int i = tid; i < WG_TR * kc4; i += 256) {
-      const int r = i / kc4, c = (i - r * kc4) << 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i0 + r < i_end) {
-        const int64_t row = (int64_t)(i0 + r) * a.row_stride + slot * a.base_mul;
+  f32x4 acc[KT][NT];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-          if (s < a.n_seg && c >= a.seg[s].col && c < a.seg[s].col + a.seg[s].width && a.seg[s].ptr)
-            v = *reinterpret_cast<const float4*>(a.seg[s].ptr + row * a.seg[s].stride + (c - a.seg[s].col));
-      }
-      *reinterpret_cast<float4*>(sIn + r * ldi + c) = v;
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[kt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+  struct Block { WgOperand<K0> k0; WgOperand<K1> k1; WgOperand<K2> k2; WgOperand<NW> n; };
+  auto kval = [&](const Block& b, int kt, int s) -> float {
+    if (kt < T0) return b.k0.get(kt, s);
+    if (kt < T0 + T1) return b.k1.get(kt - T0, s);
+    return b.k2.get(kt - T0 - T1, s);
+  };
+  auto mfma_block = [&](const Block& b) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[kt][nt] = V2X_MFMA(kval(b, kt, s), b.n.get(nt, s), acc[kt][nt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bsum[nt] += (b.n.get(nt, 0) + b.n.get(nt, 1)) + (b.n.get(nt, 2) + b.n.get(nt, 3));
+  };
+  const int n_rows_here = max(i_end - i_begin, 0);
+  const int n_full = n_rows_here / WG_TR;
+  const unsigned row_lane0 = (unsigned)(a.idx_base + i_begin + 4 * kg) * a.row_stride + slot * a.base_mul;
+  auto load_full = [&](int blk, Block& b) {                      // full block: no clamps on rows, no masks
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const unsigned row = row_lane0 + (unsigned)(blk * WG_TR + s) * a.row_stride;
+      wg_load<K0>(b.k0, src[0], row, s, j, 1.f);
+      wg_load<K1>(b.k1, src[1], row, s, j, 1.f);
+      wg_load<K2>(b.k2, src[2], row, s, j, 1.f);
+      wg_load<NW>(b.n, srcn, row, s, j, 1.f);
     }
-    for (int i = tid; i < WG_TR * nc4; i += 256) {
-      const int r = i / nc4, c = (i - r * nc4) << 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (i0 + r < i_end && c < a.n_real) {
-        const int64_t row = (int64_t)(i0 + r) * a.row_stride + slot * a.base_mul;
-        v = *reinterpret_cast<const float4*>(a.dpre + row * a.d_stride + c);
-      }
-      *reinterpret_cast<float4*>(sD + r * ldd + c) = v;
+  };
+
+  // This wave's blocks: wv, wv+4, ...  The loads of the next block are issued, THEN the MFMAs of the current one
+  // run (sched_barrier pins that order; a load under an `if` would force vmcnt(0) at the join).
+  const int nb = n_full > wv ? (n_full - wv + 3) >> 2 : 0;
+  Block b0, b1;
+  if (nb > 0) load_full(wv, b0);
+  int k = 0;
+#pragma unroll 1
+  for (; k + 2 < nb; k += 2) {
+    load_full(wv + 4 * (k + 1), b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(b0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_full(wv + 4 * (k + 2), b0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(b1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (nb - k == 2) {                                             // peeled tail: 2 or 1 blocks left
+    load_full(wv + 4 * (k + 1), b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(b0);
+    mfma_block(b1);
+  } else if (nb - k == 1) {
+    mfma_block(b0);
+  }
+  if (n_full * WG_TR < n_rows_here && wv == (n_full & 3)) {      // partial last block of the chunk
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ridx = i_begin + n_full * WG_TR + 4 * kg + s;
+      const float mk = ridx < i_end ? 1.f : 0.f;                 // rows past the chunk contribute 0
+      const unsigned row = (unsigned)(a.idx_base + min(ridx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
+      wg_load<K0>(b0.k0, src[0], row, s, j, 1.f);
+      wg_load<K1>(b0.k1, src[1], row, s, j, 1.f);
+      wg_load<K2>(b0.k2, src[2], row, s, j, 1.f);
+      wg_load<NW>(b0.n, srcn, row, s, j, mk);
     }
-    __syncthreads();
-    if (tid < a.np) {
-      float s = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < WG_TR; ++r) s += sD[r * ldd + tid];
-      bsum += s;
-    }
+    mfma_block(b0);
+  }
+
+  // ---- sum the 4 waves' accumulators through LDS (wave 0 stores, waves 1..3 add in turn; fixed order =>
+  //      deterministic).  Lane (kg, j) of tile (kt, nt) holds rows feature_k(kt, 4*kg + r), column feature_n(nt, j).
+  f32x4* sAcc = reinterpret_cast<f32x4*>(smem);                  // [KT*NT][64 lanes]
+  float* sBias = smem + KT * NT * 64 * 4;                        // [NT][16]
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-      const int tile = wv + 4 * t;
-      if (tile < ntiles) {
-        const int kt = tile / NT, nt = tile - kt * NT;
-        const float* pa = sIn + (4 * kg) * ldi + kt * 16 + j;
-        const float* pb = sD + (4 * kg) * ldd + nt * 16 + j;
+  for (int nt = 0; nt < NT; ++nt) {                              // bias: fold the 4 row groups of the wave
+    float v = bsum[nt];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    bsum[nt] = v;
+  }
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wv == w) {
 #pragma unroll
-        for (int r0 = 0; r0 < WG_TR; r0 += 16) {
+      for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc[t] = V2X_MFMA(pa[(r0 + s) * ldi], pb[(r0 + s) * ldd], acc[t]);
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x4* p = sAcc + (kt * NT + nt) * 64 + lane;
+          if (w == 0) *p = acc[kt][nt]; else *p += acc[kt][nt];
+        }
+      if (kg == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float* p = sBias + nt * 16 + j;
+          if (w == 0) *p = bsum[nt]; else *p += bsum[nt];
         }
       }
     }
     __syncthreads();
   }
-
-  // ---- write this WG's partial: lane holds dW[kt*16 + 4*kg + r][nt*16 + j]
-  float* dst = a.slab + blockIdx.x * a.slab_stride + a.layer_off + slot * a.slot_stride;
+  // ---- write the partial.  Padded K row of (kt, lane index i): operand column offset + feature(); output column of
+  //      (nt, j): WgOperand<NW>::feature.  Inside a 64-wide N group the 4 tiles of a lane are 4 consecutive columns
+  //      => float4 stores.
+  float* dst = a.slab + (int64_t)(a.chunk_base + bx) * a.slab_stride + a.layer_off + slot * a.slot_stride;
+  auto krow = [&](int kt, int i) -> int {
+    if (kt < T0) return WgOperand<K0>::feature(kt, i);
+    if (kt < T0 + T1) return K0 + WgOperand<K1>::feature(kt - T0, i);
+    return K0 + K1 + WgOperand<K2>::feature(kt - T0 - T1, i);
+  };
+  constexpr int NG = WgOperand<NW>::G, NR = WgOperand<NW>::R;
+  constexpr int UNITS = KT * (NG + NR);                          // (k tile, n group | n dword tile)
+  for (int u = wv; u < UNITS; u += 4) {
+    const int kt = u / (NG + NR), nn = u - kt * (NG + NR);
 #pragma unroll
-  for (int t = 0; t < TPW; ++t) {
-    const int tile = wv + 4 * t;
-    if (tile < ntiles) {
-      const int kt = tile / NT, nt = tile - kt * NT;
-      const int col = nt * 16 + j;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rr = real_row(a.pad, kt * 16 + 4 * kg + r);
-        if (rr >= 0 && col < a.n_real) dst[(int64_t)rr * a.n_real + col] = acc[t][r];
+    for (int r = 0; r < 4; ++r) {
+      const int rr = real_row(a.pad, krow(kt, 4 * kg + r));
+      if (rr < 0) continue;
+      if (nn < NG) {                                             // 4 tiles -> 4 consecutive columns
+        const int col = 64 * nn + 4 * j;
+        float4 v;
+        v.x = sAcc[(kt * NT + 4 * nn + 0) * 64 + lane][r];
+        v.y = sAcc[(kt * NT + 4 * nn + 1) * 64 + lane][r];
+        v.z = sAcc[(kt * NT + 4 * nn + 2) * 64 + lane][r];
+        v.w = sAcc[(kt * NT + 4 * nn + 3) * 64 + lane][r];
+        if (col + 3 < a.n_real) *reinterpret_cast<float4*>(dst + (int64_t)rr * a.n_real + col) = v;
+      } else {
+        const int nt = 4 * NG + (nn - NG), col = 64 * NG + 16 * (nn - NG) + j;
+        if (col < a.n_real) dst[(int64_t)rr * a.n_real + col] = sAcc[(kt * NT + nt) * 64 + lane][r];
       }
     }
   }
-  if (tid < a.n_real) dst[(int64_t)a.pad.k_real * a.n_real + tid] = bsum;
+  if (tid < NT * 16) {
+    const int nt = tid >> 4, jj = tid & 15, col = WgOperand<NW>::feature(nt, jj);
+    if (col < a.n_real) dst[(int64_t)a.pad.k_real * a.n_real + col] = sBias[tid];
+  }
+}
+
+// Several independent weight-gradient problems (roles) in ONE launch: blockIdx.z selects the layer and each
+// role runs the body instantiated for ITS operand widths; the kernel template only bounds the register budget.
+// Every launch of this path costs ~6-8 us of fixed latency, so the 4 Dense layers (and the L+1 GNN stages)
+// share one launch each instead of 4 (L+1).  Kernarg structs indexed by blockIdx.z would be copied to scratch
+// (runtime-indexed array): the role's descriptor is read through the constant-address-space kernarg pointer.
+constexpr int WG_MAX_ROLES = 4;
+struct WgradMulti { WgradArgs w[WG_MAX_ROLES]; };
+enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 3, WG_KIND_DENSE2 = 4, WG_KIND_DENSE3 = 5 };
+
+template <int F, bool DENSE>
+__global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef const __attribute__((address_space(4))) unsigned* CWords;
+  static_assert(sizeof(WgradArgs) % 4 == 0, "WgradArgs must be dword sized");
+  constexpr int NW = sizeof(WgradArgs) / 4;
+  CWords srcw = (CWords)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.z * NW;
+  WgradArgs a;
+  unsigned* dstw = reinterpret_cast<unsigned*>(&a);
+#pragma unroll
+  for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
+  if constexpr (!DENSE) {
+    if (a.kind == WG_KIND_GNN) wgrad_body<F, XE, F, F>(a, smem, blockIdx.x, blockIdx.y);
+    else wgrad_body<XE, F, 0, F>(a, smem, blockIdx.x, blockIdx.y);
+  } else {
+    if (a.kind == WG_KIND_DENSE0) wgrad_body<F, XE, F, H1>(a, smem, blockIdx.x, blockIdx.y);
+    else if (a.kind == WG_KIND_DENSE1) wgrad_body<H1, 0, 0, H2P>(a, smem, blockIdx.x, blockIdx.y);
+    else if (a.kind == WG_KIND_DENSE2) wgrad_body<H2P, 0, 0, H3P>(a, smem, blockIdx.x, blockIdx.y);
+    else wgrad_body<H3P, 0, 0, CP>(a, smem, blockIdx.x, blockIdx.y);
+  }
 }
 
 // =====================================================================================
@@ -690,17 +904,38 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
 struct AdamArgs {
   float* param; float* grad; float* mom; float* vel;
   const float* slab; int64_t slab_stride; int n_slabs;   // grad = sum of slabs (if slab != null)
+  int n_layers; int64_t layer_end4[16]; int layer_slabs[16];   // slabs written per layer (float4 offsets)
   int64_t n4;                                            // P / 4
   float lr_t, beta1, beta2, eps;
   int do_adam;
+  // blocks [n_adam_blocks, gridDim.x) reduce the per-row Huber sums to per-output means
+  int n_adam_blocks;
+  const float* rowloss; float* loss; int loss_n_idx, loss_stride; float loss_scale;
 };
 
 __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)gridDim.x * 256) {
+  if ((int)blockIdx.x >= a.n_adam_blocks) {      // loss role (deterministic tree reduction)
+    __shared__ float red[256];
+    const int slot = blockIdx.x - a.n_adam_blocks;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.loss_n_idx; i += 256) s += a.rowloss[(int64_t)i * a.loss_stride + slot];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.loss[slot] = red[0] * a.loss_scale;
+    return;
+  }
+  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)a.n_adam_blocks * 256) {
     float4 g;
     if (a.slab) {
       g = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int c = 0; c < a.n_slabs; ++c) {
+      int l = 0;
+      while (l + 1 < a.n_layers && i >= a.layer_end4[l]) ++l;
+      const int ns = a.layer_slabs[l];
+      for (int c = 0; c < ns; ++c) {
         const float4 t = reinterpret_cast<const float4*>(a.slab + c * a.slab_stride)[i];
         g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
       }

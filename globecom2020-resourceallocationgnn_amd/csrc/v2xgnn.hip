@@ -5,8 +5,10 @@
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -24,6 +26,7 @@ struct LayerDesc {
   int k_real, n_out;    // real weight shape
   int kp, np;           // padded (multiples of 16)
   RowPad pad;           // padded K row -> real row
+  int n_slabs = 0;      // partial-sum slabs the last weight-gradient launch wrote for this layer
 };
 
 struct DevBuf {
@@ -51,9 +54,12 @@ struct v2x_model {
   int64_t cap_rows = 0;
   std::vector<float*> h, a;
   float *z1 = nullptr, *z2 = nullptr, *z3 = nullptr, *q = nullptr;
-  float *dq = nullptr, *dz1 = nullptr, *dz2 = nullptr, *dz3 = nullptr, *gha = nullptr, *dpre = nullptr,
-        *rowloss = nullptr;
+  float *dq = nullptr, *dz1 = nullptr, *dz2 = nullptr, *dz3 = nullptr, *gha = nullptr, *rowloss = nullptr;
+  std::vector<float*> dpre;     // one pre-activation gradient per GNN stage (read concurrently by k_wgrad)
+  hipStream_t side = nullptr;   // weight-gradient kernels run here, forked/joined around the data chain
+  std::vector<hipEvent_t> ev;   // fork / per-stage / join events of the side stream
   float* loss_dev = nullptr;
+  float* zero_buf = nullptr;   // 256 B of zeros
   float* slab = nullptr; int slab_cap = 0;
   // staging for host-side inputs
   DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
@@ -157,26 +163,20 @@ void allow_big_lds(const void* f) { hipFuncSetAttribute(f, hipFuncAttributeMaxDy
 
 template <int F>
 void set_attrs_f() {
-  allow_big_lds((const void*)k_gemm_rows<F, false, false, false, 1>);
-  allow_big_lds((const void*)k_gemm_rows<F, false, false, false, 2>);
-  allow_big_lds((const void*)k_gemm_rows<F, false, true, false, 1>);
-  allow_big_lds((const void*)k_gemm_rows<F, false, true, false, 2>);
-  allow_big_lds((const void*)k_gemm_rows<F, true, true, false, 1>);
-  allow_big_lds((const void*)k_gemm_rows<F, true, true, false, 2>);
-  allow_big_lds((const void*)k_gemm_rows<F, true, false, true, 1>);
-  allow_big_lds((const void*)k_gemm_rows<F, true, false, true, 2>);
+  allow_big_lds((const void*)k_gemm_rows<F, false, false, false>);
+  allow_big_lds((const void*)k_gemm_rows<F, false, true, false>);
+  allow_big_lds((const void*)k_gemm_rows<F, true, true, false>);
+  allow_big_lds((const void*)k_gemm_rows<F, true, false, true>);
   allow_big_lds((const void*)k_mlp_fwd<F, 1>);
   allow_big_lds((const void*)k_mlp_fwd<F, 2>);
   allow_big_lds((const void*)k_mlp_bwd<F, 1>);
   allow_big_lds((const void*)k_mlp_bwd<F, 2>);
+  allow_big_lds((const void*)k_wgrad<F, false>);
+  allow_big_lds((const void*)k_wgrad<F, true>);
 }
 
 void set_attrs(int F) {
   allow_big_lds((const void*)k_agg);
-  allow_big_lds((const void*)k_wgrad<1>); allow_big_lds((const void*)k_wgrad<2>);
-  allow_big_lds((const void*)k_wgrad<3>); allow_big_lds((const void*)k_wgrad<4>);
-  allow_big_lds((const void*)k_wgrad<5>); allow_big_lds((const void*)k_wgrad<7>);
-  allow_big_lds((const void*)k_wgrad<9>); allow_big_lds((const void*)k_wgrad<12>);
   if (F == 16) set_attrs_f<16>();
   if (F == 32) set_attrs_f<32>();
   if (F == 64) set_attrs_f<64>();
@@ -203,21 +203,35 @@ int ensure_rows(v2x_model* m, int64_t R) {
   for (int s = 0; s <= m->L; ++s) { CHK(re(m->h[s], F)); CHK(re(m->a[s], F)); }
   CHK(re(m->z1, H1)); CHK(re(m->z2, H2)); CHK(re(m->z3, H3)); CHK(re(m->q, m->C));
   CHK(re(m->dq, m->C)); CHK(re(m->dz1, H1)); CHK(re(m->dz2, H2)); CHK(re(m->dz3, H3));
-  CHK(re(m->gha, 2 * F)); CHK(re(m->dpre, F)); CHK(re(m->rowloss, 1));
+  CHK(re(m->gha, 2 * F)); CHK(re(m->rowloss, 1));
+  for (int s = 0; s <= m->L; ++s) CHK(re(m->dpre[s], F));
   m->cap_rows = R;
   return V2X_OK;
 }
 
-constexpr int WG_ROWS_PER_CHUNK = 256;
-constexpr int WG_MAX_CHUNKS = 512;
-
-int wgrad_chunks(int n_idx, int* chunk_out) {
-  int nc = (n_idx + WG_ROWS_PER_CHUNK - 1) / WG_ROWS_PER_CHUNK;
+// Weight-gradient decomposition.  A role (= one layer) is cut into `nc` row chunks per slot, one workgroup and
+// one partial-sum slab each.  A workgroup walks its chunk sequentially (4 waves, 16-row blocks round-robin), so
+// the launch is as long as its longest workgroup: the chunk count of every role fused into a launch is chosen
+// proportional to the role's MFMA work (KT*NT tiles) so that the whole launch is about ONE balanced round of
+// the chip (V2X_WG_ROUNDS rounds), instead of the same chunking for a 45-tile and a 2-tile layer.
+int n_cus();
+int role_chunks(int n_idx, int n_slots, int work, int total_work, int* chunk_out, int dflt_rows = 768) {
+  static const int rounds = getenv("V2X_WG_ROUNDS") ? atoi(getenv("V2X_WG_ROUNDS")) : 0;
+  static const int env_rows = getenv("V2X_WG_CHUNK") ? atoi(getenv("V2X_WG_CHUNK")) : 0;
+  const int rows = env_rows > 0 ? env_rows : dflt_rows;
+  int nc;
+  if (rounds > 0) {                                             // work-proportional workgroup counts
+    long target = ((long)n_cus() * rounds * work + total_work / 2) / total_work;
+    nc = (int)(target / n_slots);
+  } else {                                                      // uniform rows per workgroup (measured best: 768)
+    nc = (n_idx + rows - 1) / rows;
+  }
   if (nc < 1) nc = 1;
-  if (nc > WG_MAX_CHUNKS) nc = WG_MAX_CHUNKS;
+  const int max_nc = (n_idx + 4 * WG_TR - 1) / (4 * WG_TR);                         // >= one block per wave
+  if (nc > max_nc) nc = max_nc;
+  if (nc < 1) nc = 1;
   int chunk = (n_idx + nc - 1) / nc;
-  chunk = (chunk + WG_TR - 1) / WG_TR * WG_TR;
-  if (chunk < WG_TR) chunk = WG_TR;
+  chunk = (chunk + 4 * WG_TR - 1) / (4 * WG_TR) * (4 * WG_TR);
   nc = (n_idx + chunk - 1) / chunk;
   if (nc < 1) nc = 1;
   *chunk_out = chunk;
@@ -282,13 +296,46 @@ int resolve_batch(v2x_model* m, const v2x_batch* b, DevBatch* d, hipStream_t st)
 }
 
 // ------------------------------------------------------------------------------------ launchers
-int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, int N, int F, const float* src, int src_stride,
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// A launch covers graphs [g0, g0+ng) of the batch.  Every activation / gradient buffer is indexed by the
+// ABSOLUTE node row, so disjoint ranges (micro-batches) can be in flight concurrently on different streams.
+struct Range { int g0, ng; };
+
+struct IdxMap { int idx_base, n_idx, row_stride, base_mul, grid_y; };
+IdxMap idx_map(const v2x_model* m, const DevBatch& d, Range r) {
+  IdxMap x;
+  if (m->S == 1) {            // shared weights: the GEMM row index is the node row
+    x.row_stride = 1; x.base_mul = 0; x.grid_y = 1;
+    if (m->cfg.variable_graphs) { x.idx_base = 0; x.n_idx = d.R; }   // ragged batches are never split
+    else { x.idx_base = r.g0 * m->N; x.n_idx = r.ng * m->N; }
+  } else {                    // per-node weights: slot k owns rows b*N + k, index = graph b
+    x.idx_base = r.g0; x.n_idx = r.ng; x.row_stride = m->N; x.base_mul = 1; x.grid_y = m->N;
+  }
+  return x;
+}
+
+int n_cus() {
+  static int n = 0;
+  if (!n) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    hipGetDevice(&dev);
+    n = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return n;
+}
+
+int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, int F, const float* src, int src_stride,
                const float* add, int add_stride, const float* mask, float* out, int transpose) {
   if (F < 16 || F > 256 || (F & (F - 1))) FAIL(m, V2X_EINVAL, "agg: feat_dim must be a power of two in [16,256]");
   AggArgs a;
   a.src = src; a.src_stride = src_stride; a.add = add; a.add_stride = add_stride; a.mask = mask; a.out = out;
   a.graph_off = d.goff; a.row_ptr = d.rp; a.col_idx = d.ci;
-  a.n_graphs = d.B; a.n_nodes = N; a.F = F;
+  a.g_base = r.g0; a.g_end = r.g0 + r.ng; a.n_nodes = N; a.F = F;
   int sh = 0; while ((4 << sh) < F) ++sh;
   a.lpr_shift = sh;
   a.mask_words = (d.max_nodes + 31) / 32;
@@ -297,16 +344,35 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, int N, int F, co
   const size_t per_graph = (size_t)d.max_nodes * F * 4 + (size_t)(d.max_nodes + 1) * 4 + (size_t)d.max_edges * 4 +
                            (transpose ? (size_t)d.max_nodes * a.mask_words * 4 : 0);
   int gpw = 1;
-  while (gpw * 2 <= nworkers && gpw * 2 <= 16 && (size_t)(gpw * 2) * per_graph <= 48 * 1024 && gpw * 2 <= d.B) gpw *= 2;
+  // few graphs per workgroup => many workers per graph => short per-worker row loops (the kernel is a
+  // latency chain: stage -> barrier -> LDS gathers -> store); keep >= 8 workers per graph when F allows
+  static const int wpg_min = env_int("V2X_AGG_WORKERS_PER_GRAPH", 8);
+  while (gpw * 2 <= nworkers && nworkers / (gpw * 2) >= wpg_min && (size_t)(gpw * 2) * per_graph <= 48 * 1024 && gpw * 2 <= r.ng) gpw *= 2;
   a.gpw = gpw;
   a.rows_cap = gpw * d.max_nodes;
   a.edges_cap = gpw * d.max_edges;
   const size_t lds = (size_t)a.rows_cap * F * 4 + (size_t)(a.rows_cap + 1) * 4 + (size_t)(gpw + 1) * 4 +
                      (size_t)a.edges_cap * 4 + (transpose ? (size_t)a.rows_cap * a.mask_words * 4 : 0);
   if (lds > 160 * 1024) FAIL(m, V2X_EINVAL, "agg: graph tile (%zu B) exceeds the 160 KiB LDS", lds);
-  const dim3 grid((d.B + gpw - 1) / gpw);
+  const dim3 grid((r.ng + gpw - 1) / gpw);
   LAUNCH(m, transpose ? "k_agg_bwd" : "k_agg_fwd", k_agg, grid, lds, st, a);
   return V2X_OK;
+}
+
+// persistent-grid sizing: ~`wgs_per_cu` workgroups per CU in total, split evenly over the slots, so that
+// every SIMD ends up with the same number of 16-row tiles (fp32 MFMA is the scarce resource)
+int persistent_wgs_per_slot(int n_idx, int n_slots, int wgs_per_cu) {
+  const int n_tiles = (n_idx + 15) / 16;
+  int w = (n_cus() * wgs_per_cu) / n_slots;
+  if (w < 1) w = 1;
+  const int max_useful = (n_tiles + 3) / 4;          // at least one tile per wave
+  if (w > max_useful) w = max_useful;
+  if (w < 1) w = 1;
+  return w;
+}
+
+void set_idx(GemmArgs& a, const IdxMap& x) {
+  a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.idx_base = x.idx_base;
 }
 
 template <int F, bool HAS0, bool HAS2, bool DGRAD>
@@ -315,11 +381,10 @@ int launch_gemm_t(v2x_model* m, hipStream_t st, GemmArgs& a, int grid_y, const c
   constexpr int KB = DGRAD ? FB : ((HAS0 ? FB : 0) + 1 + (HAS2 ? FB : 0));
   constexpr int KP = DGRAD ? (2 * F + XE) : KB * 16;
   const size_t lds = (size_t)(KP * (F + 4) + F) * 4;
-  if (a.n_idx >= 4096) {
-    auto k = k_gemm_rows<F, HAS0, HAS2, DGRAD, 2>;LAUNCH(m, name, k, dim3((a.n_idx + 127) / 128, grid_y), lds, st, a);
-  } else {
-    auto k = k_gemm_rows<F, HAS0, HAS2, DGRAD, 1>;LAUNCH(m, name, k, dim3((a.n_idx + 63) / 64, grid_y), lds, st, a);
-  }
+  static const int wgs_per_cu = env_int("V2X_GEMM_WGS_PER_CU", 1);
+  const int gx = persistent_wgs_per_slot(a.n_idx, grid_y, wgs_per_cu);
+  auto k = k_gemm_rows<F, HAS0, HAS2, DGRAD>;
+  LAUNCH(m, name, k, dim3(gx, grid_y), lds, st, a);
   return V2X_OK;
 }
 
@@ -332,51 +397,48 @@ int launch_node_fwd_f(v2x_model* m, hipStream_t st, int stage, GemmArgs& a, int 
   return launch_gemm_t<F, true, true, false>(m, st, a, grid_y, "k_node_fwd");
 }
 
-// GNNLayer forward of `stage` over n_rows
-int launch_node_fwd(v2x_model* m, hipStream_t st, int stage, int n_rows, const float* xe, const float* h_prev,
+// GNNLayer forward of `stage`
+int launch_node_fwd(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const float* xe, const float* h_prev,
                     const float* agg_prev, float* out) {
   const LayerDesc& ld = m->gnn[stage];
-  const RowMapH rm = row_map(m, n_rows);
   GemmArgs a;
   a.seg0 = h_prev; a.seg0_stride = m->F; a.xe = xe; a.seg2 = agg_prev; a.seg2_stride = m->F;
   a.W = m->params + ld.off; a.slot_stride = ld.slot_stride; a.pad = ld.pad;
   a.out = out; a.out_stride = m->F; a.relu = stage < m->L ? 1 : 0;
-  a.n_idx = rm.n_idx; a.row_stride = rm.row_stride; a.base_mul = rm.base_mul;
+  set_idx(a, x);
   if (stage > 0 && (!h_prev || !agg_prev)) FAIL(m, V2X_EINVAL, "node_update: stage>0 needs h_prev and agg_prev");
   switch (m->F) {
-    case 16: return launch_node_fwd_f<16>(m, st, stage, a, rm.grid_y);
-    case 32: return launch_node_fwd_f<32>(m, st, stage, a, rm.grid_y);
-    case 64: return launch_node_fwd_f<64>(m, st, stage, a, rm.grid_y);
+    case 16: return launch_node_fwd_f<16>(m, st, stage, a, x.grid_y);
+    case 32: return launch_node_fwd_f<32>(m, st, stage, a, x.grid_y);
+    case 64: return launch_node_fwd_f<64>(m, st, stage, a, x.grid_y);
   }
   FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
 }
 
 // data gradient of stage >= 1: gha[R][2F] = [dpre.W1h^T | dpre.W3^T]
-int launch_dgrad(v2x_model* m, hipStream_t st, int stage, int n_rows, const float* dpre, float* gha) {
+int launch_dgrad(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const float* dpre, float* gha) {
   const LayerDesc& ld = m->gnn[stage];
-  const RowMapH rm = row_map(m, n_rows);
   GemmArgs a;
   a.seg0 = dpre; a.seg0_stride = m->F; a.xe = nullptr; a.seg2 = nullptr; a.seg2_stride = 0;
   a.W = m->params + ld.off; a.slot_stride = ld.slot_stride; a.pad = ld.pad;
   a.out = gha; a.out_stride = 2 * m->F; a.relu = 0;
-  a.n_idx = rm.n_idx; a.row_stride = rm.row_stride; a.base_mul = rm.base_mul;
+  set_idx(a, x);
   switch (m->F) {
-    case 16: return launch_gemm_t<16, true, false, true>(m, st, a, rm.grid_y, "k_node_dgrad");
-    case 32: return launch_gemm_t<32, true, false, true>(m, st, a, rm.grid_y, "k_node_dgrad");
-    case 64: return launch_gemm_t<64, true, false, true>(m, st, a, rm.grid_y, "k_node_dgrad");
+    case 16: return launch_gemm_t<16, true, false, true>(m, st, a, x.grid_y, "k_node_dgrad");
+    case 32: return launch_gemm_t<32, true, false, true>(m, st, a, x.grid_y, "k_node_dgrad");
+    case 64: return launch_gemm_t<64, true, false, true>(m, st, a, x.grid_y, "k_node_dgrad");
   }
   FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
 }
 
-void mlp_args(v2x_model* m, MlpArgs& a, int n_rows, const float* xe, const float* h, const float* agg) {
-  const RowMapH rm = row_map(m, n_rows);
+void mlp_args(v2x_model* m, MlpArgs& a, const IdxMap& x, const float* xe, const float* h, const float* agg) {
   memset(&a, 0, sizeof(a));
   a.h = h; a.xe = xe; a.agg = agg;
   for (int i = 0; i < 4; ++i) { a.W[i] = m->params + m->dense[i].off; a.slot_stride[i] = m->dense[i].slot_stride; }
   a.C = m->C;
   a.z1 = m->z1; a.z2 = m->z2; a.z3 = m->z3; a.q = m->q;
   a.dq = m->dq; a.dz1 = m->dz1; a.dz2 = m->dz2; a.dz3 = m->dz3; a.gha = m->gha; a.rowloss = m->rowloss;
-  a.n_idx = rm.n_idx; a.row_stride = rm.row_stride; a.base_mul = rm.base_mul;
+  a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.idx_base = x.idx_base;
 }
 
 template <int F>
@@ -404,67 +466,116 @@ int launch_mlp(v2x_model* m, hipStream_t st, MlpArgs& a, bool bwd) {
   FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
 }
 
-// weight gradient of one layer into the slabs
-int launch_wgrad(v2x_model* m, hipStream_t st, const LayerDesc& ld, int n_rows, const WgSeg* segs, int n_seg,
-                 const float* dpre, int d_stride, const char* name) {
-  const RowMapH rm = row_map(m, n_rows);
+// weight gradients: build the role description of one layer ...
+int layer_work(const LayerDesc& ld) { return (ld.kp / 16) * (ld.np / 16); }
+
+int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total_work, const WgSeg* segs, int n_seg,
+               const float* dpre, int d_stride, WgradArgs& a) {
   int chunk;
-  const int nc = wgrad_chunks(rm.n_idx, &chunk);
-  CHK(ensure_slabs(m, nc));
-  WgradArgs a;
+  // measured at batch 4096 x 20 nodes: 1024 rows per workgroup for the GNN stages, 768 for the Dense layers
+  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, kind < WG_KIND_DENSE0 ? 1024 : 768);
+  if (nc > m->slab_cap) FAIL(m, V2X_ESTATE, "wgrad: slabs not pre-sized (%d > %d)", nc, m->slab_cap);
+  ld.n_slabs = nc;                       // remembered for the slab reduction
   memset(&a, 0, sizeof(a));
   for (int i = 0; i < n_seg; ++i) a.seg[i] = segs[i];
   a.n_seg = n_seg;
   a.dpre = dpre; a.d_stride = d_stride; a.n_real = ld.n_out;
   a.kp = ld.kp; a.np = ld.np; a.pad = ld.pad;
   a.slab = m->slab; a.slab_stride = m->P; a.layer_off = ld.off; a.slot_stride = ld.slot_stride;
-  a.n_idx = rm.n_idx; a.row_stride = rm.row_stride; a.base_mul = rm.base_mul; a.chunk = chunk;
-  const int ntiles = (ld.kp / 16) * (ld.np / 16);
-  const int tpw = (ntiles + 3) / 4;
-  const size_t lds = (size_t)WG_TR * (ld.kp + 4 + ld.np + 4) * 4;
-  const dim3 grid(nc, rm.grid_y);
-#define V2X_WG_CASE(T)                                                                                   \
-  if (tpw <= T) {                                                                                        \
-    auto k = k_wgrad<T>;                                                                                 \
-    LAUNCH(m, name, k, grid, lds, st, a);                                                                \
-    return V2X_OK;                                                                                       \
-  }
-  V2X_WG_CASE(1) V2X_WG_CASE(2) V2X_WG_CASE(3) V2X_WG_CASE(4) V2X_WG_CASE(5) V2X_WG_CASE(7) V2X_WG_CASE(9) V2X_WG_CASE(12)
-#undef V2X_WG_CASE
-  FAIL(m, V2X_EINVAL, "wgrad: %d tiles per wave unsupported", tpw);
+  a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.chunk = chunk;
+  a.idx_base = x.idx_base; a.chunk_base = 0; a.n_chunks = nc; a.kind = kind;
+  a.zeros = m->zero_buf;
+  return V2X_OK;
 }
 
-int wgrad_gnn(v2x_model* m, hipStream_t st, int stage, int n_rows, const float* xe, const float* h_prev,
-              const float* agg_prev, const float* dpre) {
+// ... and launch up to WG_MAX_ROLES of them as one grid (blockIdx.z = role)
+int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti& mu, int n_roles, const char* name) {
+  int maxt = 1, nc = 1;
+  for (int i = 0; i < n_roles; ++i) {
+    maxt = std::max(maxt, (mu.w[i].kp / 16) * (mu.w[i].np / 16));
+    nc = std::max(nc, mu.w[i].n_chunks);
+  }
+  const size_t lds = (size_t)(maxt * 64 * 4 + 5 * 16) * 4;      // accumulator exchange + bias
+  const dim3 grid(nc, x.grid_y, n_roles);
+  const bool dense = mu.w[0].kind >= WG_KIND_DENSE0;
+#define V2X_WG_CASE(FF)                                                              \
+  if (m->F == FF) {                                                                  \
+    if (dense) { auto k = k_wgrad<FF, true>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
+    else { auto k = k_wgrad<FF, false>; LAUNCH(m, name, k, grid, lds, st, mu); }       \
+    return V2X_OK;                                                                   \
+  }
+  V2X_WG_CASE(16) V2X_WG_CASE(32) V2X_WG_CASE(64)
+#undef V2X_WG_CASE
+  FAIL(m, V2X_EINVAL, "wgrad: %d output tiles unsupported", maxt);
+}
+
+int wgrad_gnn_role(v2x_model* m, int stage, const IdxMap& x, int total_work, const float* xe, const float* h_prev,
+                   const float* agg_prev, const float* dpre, WgradArgs& a) {
   const int F = m->F;
   WgSeg s[3];
   int n = 0;
   if (stage > 0) { s[n++] = WgSeg{h_prev, F, F, 0}; s[n++] = WgSeg{xe, XE, XE, F}; s[n++] = WgSeg{agg_prev, F, F, F + XE}; }
   else { s[n++] = WgSeg{xe, XE, XE, 0}; s[n++] = WgSeg{agg_prev /* neighbour-init or null */, F, F, XE}; }
-  return launch_wgrad(m, st, m->gnn[stage], n_rows, s, n, dpre, F, stage ? "k_wgrad_gnn" : "k_wgrad_embed");
+  return wgrad_role(m, m->gnn[stage], stage ? WG_KIND_GNN : WG_KIND_EMBED, x, total_work, s, n, dpre, F, a);
 }
 
-int wgrad_mlp(v2x_model* m, hipStream_t st, int n_rows, const float* xe, const float* h, const float* agg) {
-  const int F = m->F;
-  WgSeg s0[3] = {WgSeg{h, F, F, 0}, WgSeg{xe, XE, XE, F}, WgSeg{agg, F, F, F + XE}};
-  CHK(launch_wgrad(m, st, m->dense[0], n_rows, s0, 3, m->dz1, H1, "k_wgrad_dense0"));
-  WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0}};
-  CHK(launch_wgrad(m, st, m->dense[1], n_rows, s1, 1, m->dz2, H2, "k_wgrad_dense1"));
-  WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0}};
-  CHK(launch_wgrad(m, st, m->dense[2], n_rows, s2, 1, m->dz3, H3, "k_wgrad_dense2"));
-  WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0}};
-  CHK(launch_wgrad(m, st, m->dense[3], n_rows, s3, 1, m->dq, m->C, "k_wgrad_dense3"));
+// one GNN stage on its own (per-kernel entry point)
+int wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const float* xe, const float* h_prev,
+              const float* agg_prev, const float* dpre) {
+  WgradMulti mu;
+  memset(&mu, 0, sizeof(mu));
+  CHK(wgrad_gnn_role(m, stage, x, layer_work(m->gnn[stage]), xe, h_prev, agg_prev, dpre, mu.w[0]));
+  return launch_wgrad_multi(m, st, x, mu, 1, stage ? "k_wgrad_gnn" : "k_wgrad_embed");
+}
+
+// all GNN stages (needs dpre[0..L]) in ceil((L+1)/4) launches
+int wgrad_gnn_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch& d) {
+  WgradMulti mu;
+  int n = 0, s_first = m->L;
+  for (int s = m->L; s >= 0; --s) {
+    if (n == 0) { memset(&mu, 0, sizeof(mu)); s_first = s; }
+    int total = 0;                                    // work of the stages sharing this launch
+    for (int t = s_first; t >= 0 && t > s_first - WG_MAX_ROLES; --t) total += layer_work(m->gnn[t]);
+    CHK(wgrad_gnn_role(m, s, x, total, d.xe, s ? m->h[s - 1] : nullptr, s ? m->a[s - 1] : d.nbr, m->dpre[s], mu.w[n]));
+    if (++n == WG_MAX_ROLES || s == 0) { CHK(launch_wgrad_multi(m, st, x, mu, n, "k_wgrad_gnn")); n = 0; }
+  }
   return V2X_OK;
 }
 
-int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_rows, bool from_slabs, bool do_adam, float* grad_dst) {
+// the 4 Dense layers in one launch
+int wgrad_mlp(v2x_model* m, hipStream_t st, const IdxMap& x, const float* xe, const float* h, const float* agg) {
+  const int F = m->F;
+  int total = 0;
+  for (int i = 0; i < 4; ++i) total += layer_work(m->dense[i]);
+  WgradMulti mu;
+  memset(&mu, 0, sizeof(mu));
+  WgSeg s0[3] = {WgSeg{h, F, F, 0}, WgSeg{xe, XE, XE, F}, WgSeg{agg, F, F, F + XE}};
+  CHK(wgrad_role(m, m->dense[0], WG_KIND_DENSE0, x, total, s0, 3, m->dz1, H1, mu.w[0]));
+  WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0}};
+  CHK(wgrad_role(m, m->dense[1], WG_KIND_DENSE1, x, total, s1, 1, m->dz2, H2, mu.w[1]));
+  WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0}};
+  CHK(wgrad_role(m, m->dense[2], WG_KIND_DENSE2, x, total, s2, 1, m->dz3, H3, mu.w[2]));
+  WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0}};
+  CHK(wgrad_role(m, m->dense[3], WG_KIND_DENSE3, x, total, s3, 1, m->dq, m->C, mu.w[3]));
+  return launch_wgrad_multi(m, st, x, mu, 4, "k_wgrad_dense");
+}
+
+struct LossJob { int n_out, n_idx, stride; float scale; };   // n_out == 0: no loss role
+
+int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, float* grad_dst, LossJob lj = LossJob{0, 0, 0, 0.f}) {
   AdamArgs a;
   memset(&a, 0, sizeof(a));
   a.param = m->params; a.grad = grad_dst ? grad_dst : m->grads; a.mom = m->mom; a.vel = m->vel;
-  if (from_slabs) {
-    int chunk;
-    a.n_slabs = wgrad_chunks(row_map(m, n_rows).n_idx, &chunk);
-    a.slab = m->slab; a.slab_stride = m->P;
+  if (n_slabs > 0) {
+    a.n_slabs = n_slabs; a.slab = m->slab; a.slab_stride = m->P;
+    int nl = 0;
+    for (auto* v : {&m->gnn, &m->dense})
+      for (const LayerDesc& ld : *v) {
+        a.layer_end4[nl] = (ld.off + ld.slot_stride * m->S) / 4;
+        a.layer_slabs[nl] = ld.n_slabs;
+        ++nl;
+      }
+    a.n_layers = nl;
   }
   a.n4 = m->P / 4;
   a.do_adam = do_adam ? 1 : 0;
@@ -477,21 +588,30 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_rows, bool from_slabs
   int blocks = (int)((a.n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  LAUNCH(m, do_adam ? (from_slabs ? "k_reduce_adam" : "k_adam") : "k_grad_reduce", k_reduce_adam, dim3(blocks), 0, st, a);
+  a.n_adam_blocks = blocks;
+  a.rowloss = m->rowloss; a.loss = m->loss_dev; a.loss_n_idx = lj.n_idx; a.loss_stride = lj.stride; a.loss_scale = lj.scale;
+  LAUNCH(m, do_adam ? (n_slabs > 0 ? "k_reduce_adam" : "k_adam") : "k_grad_reduce", k_reduce_adam, dim3(blocks + lj.n_out), 0, st, a);
   return V2X_OK;
 }
 
+LossJob loss_job(const v2x_model* m, const DevBatch& d, int n_global) {
+  const float inv = 1.0f / (float)((double)n_global * m->C);
+  if (m->cfg.variable_graphs) return LossJob{1, d.R, 1, inv};
+  return LossJob{m->N, d.B, m->N, inv};
+}
+
 // ------------------------------------------------------------------------------------ passes
-int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d) {
-  const int F = m->F, L = m->L, R = d.R;
-  CHK(launch_node_fwd(m, st, 0, R, d.xe, nullptr, d.nbr, m->h[0]));
-  CHK(launch_agg(m, st, d, m->N, F, m->h[0], F, nullptr, 0, nullptr, m->a[0], 0));
+int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r) {
+  const int F = m->F, L = m->L;
+  const IdxMap x = idx_map(m, d, r);
+  CHK(launch_node_fwd(m, st, 0, x, d.xe, nullptr, d.nbr, m->h[0]));
+  CHK(launch_agg(m, st, d, r, m->N, F, m->h[0], F, nullptr, 0, nullptr, m->a[0], 0));
   for (int s = 1; s <= L; ++s) {
-    CHK(launch_node_fwd(m, st, s, R, d.xe, m->h[s - 1], m->a[s - 1], m->h[s]));
-    CHK(launch_agg(m, st, d, m->N, F, m->h[s], F, nullptr, 0, nullptr, m->a[s], 0));
+    CHK(launch_node_fwd(m, st, s, x, d.xe, m->h[s - 1], m->a[s - 1], m->h[s]));
+    CHK(launch_agg(m, st, d, r, m->N, F, m->h[s], F, nullptr, 0, nullptr, m->a[s], 0));
   }
   MlpArgs a;
-  mlp_args(m, a, R, d.xe, m->h[L], m->a[L]);
+  mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
   CHK(launch_mlp(m, st, a, false));
   return V2X_OK;
 }
@@ -502,27 +622,51 @@ float loss_denominator(const v2x_model* m, int n_global) {
   return (float)((double)n_global * m->C);
 }
 
-int run_backward(v2x_model* m, hipStream_t st, const DevBatch& d, const float* y_dev, int n_global) {
-  const int F = m->F, L = m->L, R = d.R;
+// backward kernel chain of one range.  sw != st: the weight-gradient kernels go to the side stream `sw`,
+// forked after the kernel producing their dpre (they only consume saved activations + dpre_s, and nothing
+// consumes them before the slab reduction); the caller joins sw back.
+int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d, Range r, const float* y_dev,
+                 int n_global) {
+  const int F = m->F, L = m->L;
+  const IdxMap x = idx_map(m, d, r);
+  const bool two = sw != st;
+  int evi = 0;
+  auto fork = [&]() -> int {      // side stream waits for everything issued on st so far
+    if (!two) return V2X_OK;
+    hipEvent_t e = m->ev[evi++];
+    HIPCHK(m, hipEventRecord(e, st));
+    HIPCHK(m, hipStreamWaitEvent(sw, e, 0));
+    return V2X_OK;
+  };
   MlpArgs a;
-  mlp_args(m, a, R, d.xe, m->h[L], m->a[L]);
+  mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
   a.y = y_dev;
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
   CHK(launch_mlp(m, st, a, true));
-  CHK(wgrad_mlp(m, st, R, d.xe, m->h[L], m->a[L]));
+  CHK(fork());
+  CHK(wgrad_mlp(m, sw, x, d.xe, m->h[L], m->a[L]));        // 4 Dense layers, one launch, side stream
   for (int s = L; s >= 1; --s) {
     // dpre_s = (dh_direct + Agg^T(dagg)) * relu'(h_s)
-    CHK(launch_agg(m, st, d, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, s < L ? m->h[s] : nullptr, m->dpre, 1));
-    CHK(wgrad_gnn(m, st, s, R, d.xe, m->h[s - 1], m->a[s - 1], m->dpre));
-    CHK(launch_dgrad(m, st, s, R, m->dpre, m->gha));
+    CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, s < L ? m->h[s] : nullptr, m->dpre[s], 1));
+    CHK(launch_dgrad(m, st, s, x, m->dpre[s], m->gha));
   }
-  CHK(launch_agg(m, st, d, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, m->h[0], m->dpre, 1));
-  CHK(wgrad_gnn(m, st, 0, R, d.xe, nullptr, d.nbr, m->dpre));
-  // per-output Huber means
-  if (m->cfg.variable_graphs) {
-    hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, m->rowloss, m->loss_dev, R, 1, a.inv_denom);
-  } else {
-    hipLaunchKernelGGL(k_loss_reduce, dim3(m->N), dim3(256), 0, st, m->rowloss, m->loss_dev, d.B, m->N, a.inv_denom);
+  CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, m->h[0], m->dpre[0], 1));
+  CHK(wgrad_gnn_all(m, st, x, d));                          // all L+1 GNN stages, one launch
+  if (two) {                      // join: st waits for the side stream
+    hipEvent_t e = m->ev[evi++];
+    HIPCHK(m, hipEventRecord(e, sw));
+    HIPCHK(m, hipStreamWaitEvent(st, e, 0));
+  }
+  return V2X_OK;
+}
+
+// forward (+ backward) of the whole batch; everything is joined back into `st`
+int run_step(v2x_model* m, hipStream_t st, const DevBatch& d, bool bwd, const float* y_dev, int n_global) {
+  const Range all{0, d.B};
+  CHK(run_forward(m, st, d, all));
+  if (bwd) {
+    const bool two = !m->prof && m->side && getenv("V2X_SINGLE_STREAM") == nullptr;
+    CHK(run_backward(m, st, two ? m->side : st, d, all, y_dev, n_global));
   }
   return V2X_OK;
 }
@@ -591,10 +735,31 @@ GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
   return k;
 }
 
+int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
+  int chunk, nc = 1;
+  for (int rows : {768, 1024}) nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
+  return nc + 1;
+}
+
 int presize(v2x_model* m, const DevBatch& d) {
   CHK(ensure_rows(m, d.R));
-  int chunk;
-  CHK(ensure_slabs(m, wgrad_chunks(row_map(m, d.R).n_idx, &chunk)));
+  const IdxMap x = idx_map(m, d, Range{0, d.B});
+  CHK(ensure_slabs(m, max_slabs(m, x.n_idx, x.grid_y)));
+  return V2X_OK;
+}
+
+// helpers for the per-kernel entry points: the whole batch as one range
+IdxMap idx_map_rows(const v2x_model* m, int n_rows) {
+  DevBatch d;
+  memset(&d, 0, sizeof(d));
+  d.R = n_rows; d.B = m->cfg.variable_graphs ? 1 : n_rows / m->N;
+  return idx_map(m, d, Range{0, d.B});
+}
+
+int presize_rows(v2x_model* m, int n_rows) {
+  CHK(ensure_rows(m, n_rows));
+  const IdxMap x = idx_map_rows(m, n_rows);
+  CHK(ensure_slabs(m, max_slabs(m, x.n_idx, x.grid_y)));
   return V2X_OK;
 }
 
@@ -637,6 +802,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   set_attrs(m->F);
   m->h.assign(m->L + 1, nullptr);
   m->a.assign(m->L + 1, nullptr);
+  m->dpre.assign(m->L + 1, nullptr);
   auto fail = [&](const char* what) {
     g_err = std::string("v2x_create: ") + what + ": " + m->err;
     v2x_destroy(m);
@@ -644,10 +810,14 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   };
   const size_t pb = (size_t)m->P * sizeof(float);
   if (dev_alloc(m, &m->params, m->P) || dev_alloc(m, &m->grads, m->P) || dev_alloc(m, &m->mom, m->P) ||
-      dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1))
+      dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1) || dev_alloc(m, &m->zero_buf, 64))
     return fail("allocation");
-  if (hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
+  if (hipMemset(m->zero_buf, 0, 256) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
+  if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return fail("side stream");
+  m->ev.resize(m->L + 4);
+  for (auto& e : m->ev)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event");
   *out = m;
   return V2X_OK;
 }
@@ -659,7 +829,10 @@ void v2x_destroy(v2x_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (auto& r : m->prof_recs) { hipEventDestroy(r.ev0); hipEventDestroy(r.ev1); }
   float* ptrs[] = {m->params, m->grads, m->mom, m->vel, m->z1, m->z2, m->z3, m->q, m->dq, m->dz1, m->dz2, m->dz3,
-                   m->gha, m->dpre, m->rowloss, m->loss_dev, m->slab};
+                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf};
+  for (float* p : m->dpre) if (p) hipFree(p);
+  for (auto& e : m->ev) if (e) hipEventDestroy(e);
+  if (m->side) hipStreamDestroy(m->side);
   for (float* p : ptrs) if (p) hipFree(p);
   for (float* p : m->h) if (p) hipFree(p);
   for (float* p : m->a) if (p) hipFree(p);
@@ -723,7 +896,7 @@ int v2x_forward(v2x_model* m, const v2x_batch* b, float* q_out, int q_on_device,
   DevBatch d;
   CHK(resolve_batch(m, b, &d, st));
   CHK(presize(m, d));
-  CHK(run_maybe_graph(m, st, make_key(1, d, nullptr, 0), [&]() { return run_forward(m, st, d); }));
+  CHK(run_maybe_graph(m, st, make_key(1, d, nullptr, 0), [&]() { return run_step(m, st, d, false, nullptr, 0); }));
   m->have_fwd = true;
   const size_t qb = (size_t)d.R * m->C * sizeof(float);
   if (q_on_device) {
@@ -748,16 +921,12 @@ static int fwd_bwd(v2x_model* m, const v2x_batch* b, const float* y, int y_on_de
   CHK(presize(m, d));
   if (with_adam) {
     // lr_t depends on the iteration count, so the Adam node stays outside the replayed graph
-    CHK(run_maybe_graph(m, st, make_key(2, d, yd, n_global), [&]() {
-      CHK(run_forward(m, st, d));
-      return run_backward(m, st, d, yd, n_global);
-    }));
-    CHK(launch_reduce_adam(m, st, d.R, true, true, nullptr));
+    CHK(run_maybe_graph(m, st, make_key(2, d, yd, n_global), [&]() { return run_step(m, st, d, true, yd, n_global); }));
+    CHK(launch_reduce_adam(m, st, 1, true, nullptr, loss_job(m, d, n_global)));
   } else {
     CHK(run_maybe_graph(m, st, make_key(3, d, yd, n_global), [&]() {
-      CHK(run_forward(m, st, d));
-      CHK(run_backward(m, st, d, yd, n_global));
-      return launch_reduce_adam(m, st, d.R, true, false, nullptr);
+      CHK(run_step(m, st, d, true, yd, n_global));
+      return launch_reduce_adam(m, st, 1, false, nullptr, loss_job(m, d, n_global));
     }));
   }
   m->have_fwd = true;
@@ -777,7 +946,7 @@ int v2x_forward_backward(v2x_model* m, const v2x_batch* b, const float* y, int y
 int v2x_apply_gradients(v2x_model* m, void* stream) {
   if (!m) FAIL(m, V2X_EINVAL, "null model");
   HIPCHK(m, hipSetDevice(m->cfg.device));
-  return launch_reduce_adam(m, (hipStream_t)stream, 0, false, true, nullptr);
+  return launch_reduce_adam(m, (hipStream_t)stream, 0, true, nullptr);
 }
 
 // ---------------------------------------------------------------------------- per-kernel entry points
@@ -793,20 +962,20 @@ static int batch_dev_only(const v2x_batch* b, DevBatch* d) {
 int v2x_agg_fwd(const v2x_batch* b, int32_t n_nodes, int32_t feat_dim, const float* h, float* out, void* stream) {
   DevBatch d;
   CHK(batch_dev_only(b, &d));
-  return launch_agg(nullptr, (hipStream_t)stream, d, n_nodes, feat_dim, h, feat_dim, nullptr, 0, nullptr, out, 0);
+  return launch_agg(nullptr, (hipStream_t)stream, d, Range{0, d.B}, n_nodes, feat_dim, h, feat_dim, nullptr, 0, nullptr, out, 0);
 }
 
 int v2x_agg_bwd(const v2x_batch* b, int32_t n_nodes, int32_t feat_dim, const float* g, float* out, void* stream) {
   DevBatch d;
   CHK(batch_dev_only(b, &d));
-  return launch_agg(nullptr, (hipStream_t)stream, d, n_nodes, feat_dim, g, feat_dim, nullptr, 0, nullptr, out, 1);
+  return launch_agg(nullptr, (hipStream_t)stream, d, Range{0, d.B}, n_nodes, feat_dim, g, feat_dim, nullptr, 0, nullptr, out, 1);
 }
 
 int v2x_node_update_fwd(v2x_model* m, int32_t stage, int32_t n_rows, const float* xe, const float* h_prev,
                         const float* agg_prev, float* out, void* stream) {
   if (!m || !xe || !out || stage < 0 || stage > m->L || n_rows <= 0) FAIL(m, V2X_EINVAL, "node_update_fwd: bad argument");
   if (m->S > 1 && n_rows % m->N) FAIL(m, V2X_EINVAL, "node_update_fwd: n_rows not a multiple of n_nodes");
-  return launch_node_fwd(m, (hipStream_t)stream, stage, n_rows, xe, h_prev, agg_prev, out);
+  return launch_node_fwd(m, (hipStream_t)stream, stage, idx_map_rows(m, n_rows), xe, h_prev, agg_prev, out);
 }
 
 static int copy_cols(v2x_model* m, float* dst, int dst_w, const float* src, int src_w, int col, int rows, hipStream_t st) {
@@ -821,11 +990,12 @@ int v2x_node_update_bwd(v2x_model* m, int32_t stage, int32_t n_rows, const float
   if (!m || !xe || !dpre || stage < 0 || stage > m->L || n_rows <= 0) FAIL(m, V2X_EINVAL, "node_update_bwd: bad argument");
   if (m->S > 1 && n_rows % m->N) FAIL(m, V2X_EINVAL, "node_update_bwd: n_rows not a multiple of n_nodes");
   hipStream_t st = (hipStream_t)stream;
-  CHK(ensure_rows(m, n_rows));
-  CHK(wgrad_gnn(m, st, stage, n_rows, xe, h_prev, agg_prev, dpre));
-  if (grad_out) CHK(launch_reduce_adam(m, st, n_rows, true, false, grad_out));
+  CHK(presize_rows(m, n_rows));
+  const IdxMap x = idx_map_rows(m, n_rows);
+  CHK(wgrad_gnn(m, st, stage, x, xe, h_prev, agg_prev, dpre));
+  if (grad_out) CHK(launch_reduce_adam(m, st, 1, false, grad_out));
   if (stage > 0 && (dh_prev || dagg_prev)) {
-    CHK(launch_dgrad(m, st, stage, n_rows, dpre, m->gha));
+    CHK(launch_dgrad(m, st, stage, x, dpre, m->gha));
     if (dh_prev) CHK(copy_cols(m, dh_prev, m->F, m->gha, 2 * m->F, 0, n_rows, st));
     if (dagg_prev) CHK(copy_cols(m, dagg_prev, m->F, m->gha, 2 * m->F, m->F, n_rows, st));
   }
@@ -837,7 +1007,7 @@ int v2x_mlp_fwd(v2x_model* m, int32_t n_rows, const float* xe, const float* h, c
   hipStream_t st = (hipStream_t)stream;
   CHK(ensure_rows(m, n_rows));
   MlpArgs a;
-  mlp_args(m, a, n_rows, xe, h, agg);
+  mlp_args(m, a, idx_map_rows(m, n_rows), xe, h, agg);
   CHK(launch_mlp(m, st, a, false));
   HIPCHK(m, hipMemcpyAsync(q_out, m->q, (size_t)n_rows * m->C * 4, hipMemcpyDeviceToDevice, st));
   return V2X_OK;
@@ -847,16 +1017,17 @@ int v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_global, const floa
                       const float* y, float* dh, float* dagg, float* grad_out, float* loss_out, void* stream) {
   if (!m || !xe || !h || !agg || !y || n_rows <= 0) FAIL(m, V2X_EINVAL, "mlp_huber_bwd: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  CHK(ensure_rows(m, n_rows));
+  CHK(presize_rows(m, n_rows));
+  const IdxMap x = idx_map_rows(m, n_rows);
   if (n_global <= 0) n_global = m->cfg.variable_graphs ? n_rows : n_rows / m->N;
   MlpArgs a;
-  mlp_args(m, a, n_rows, xe, h, agg);
+  mlp_args(m, a, x, xe, h, agg);
   CHK(launch_mlp(m, st, a, false));
   a.y = y;
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
   CHK(launch_mlp(m, st, a, true));
-  CHK(wgrad_mlp(m, st, n_rows, xe, h, agg));
-  if (grad_out) CHK(launch_reduce_adam(m, st, n_rows, true, false, grad_out));
+  CHK(wgrad_mlp(m, st, x, xe, h, agg));
+  if (grad_out) CHK(launch_reduce_adam(m, st, 1, false, grad_out));
   if (dh) CHK(copy_cols(m, dh, m->F, m->gha, 2 * m->F, 0, n_rows, st));
   if (dagg) CHK(copy_cols(m, dagg, m->F, m->gha, 2 * m->F, m->F, n_rows, st));
   if (loss_out) {

@@ -43,11 +43,14 @@ def synth_batch(rng, B, N, C=4):
     return x, e, adj, y
 
 
-def algorithmic_bytes(name, B, N, F, E, C=4, Dn=9, De=4):
+def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     """Unique fp32/int32 bytes a kernel must move per launch (inputs read once + outputs written once;
-    weights are cache-resident and not counted) -- the per-graph terms of SURVEY.md 8(d8) x B graphs."""
+    weights are cache-resident and not counted) -- the per-graph terms of SURVEY.md 8(d8) x B graphs.
+    Fused launches (all GNN weight gradients / all Dense weight gradients) count the sum of their roles."""
     R = B * N
     csr = 4 * E + 4 * (R + 1)
+    wg_gnn = 4 * R * (2 * F + Dn + De) + 4 * R * F
+    wg_embed = 4 * R * (Dn + De) + 4 * R * F
     table = {
         "k_node_fwd_embed": 4 * R * (Dn + De) + 4 * R * F,
         "k_agg_fwd": 8 * R * F + csr,
@@ -56,14 +59,25 @@ def algorithmic_bytes(name, B, N, F, E, C=4, Dn=9, De=4):
         "k_mlp_bwd": 4 * R * 2 * C + 4 * R * 2 * F,                 # q, y in; [dh|dagg] out (hidden grads stay on chip in the model)
         "k_agg_bwd": 4 * R * 2 * F + 4 * R * F + 4 * R * F + csr,   # [dh|dagg] + mask in, dpre out
         "k_node_dgrad": 4 * R * F + 4 * R * 2 * F,
-        "k_wgrad_gnn": 4 * R * (2 * F + Dn + De) + 4 * R * F,
-        "k_wgrad_embed": 4 * R * (Dn + De) + 4 * R * F,
-        "k_wgrad_dense0": 4 * R * (Dn + 2 * F) + 4 * R * 80,
-        "k_wgrad_dense1": 4 * R * (80 + 40),
-        "k_wgrad_dense2": 4 * R * (40 + 20),
-        "k_wgrad_dense3": 4 * R * (20 + C),
+        "k_wgrad_gnn": L * wg_gnn + wg_embed,                       # L message-passing stages + embed, one launch
+        "k_wgrad_embed": wg_embed,
+        "k_wgrad_dense": 4 * R * (Dn + 2 * F + 80) + 4 * R * (80 + 40) + 4 * R * (40 + 20) + 4 * R * (20 + C),
     }
     return table.get(name)
+
+
+def hbm_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled
+    per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE); only valid for the default workload."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    default = (args.batch, args.nodes, args.feat, args.layers, args.share_weights) == (4096, 20, 64, 2, False)
+    if not default or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return json.load(f).get("bytes_per_launch", {}).get(kernel)
+    except Exception:
+        return None
 
 
 def step_bytes_per_graph(N, F, L, E, C=4, Dn=9, De=4):
@@ -201,12 +215,12 @@ def main():
         tot = sum(ms for _, ms in prof.values())
         kernels = {k: {"calls": c, "avg_us": round(1e3 * ms / c, 2), "share": round(ms / tot, 3)} for k, (c, ms) in
                    sorted(prof.items(), key=lambda kv: -kv[1][1])}
-        dom = max((k for k in prof if algorithmic_bytes(k, B, N, F, E) is not None), key=lambda k: prof[k][1])
+        dom = max((k for k in prof if algorithmic_bytes(k, B, N, F, E, L) is not None), key=lambda k: prof[k][1])
         calls, ms = prof[dom]
-        bytes_per_launch = algorithmic_bytes(dom, B, N, F, E)
+        bytes_per_launch = algorithmic_bytes(dom, B, N, F, E, L)
         achieved = bytes_per_launch / (1e-3 * ms / calls) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": hbm_traffic(dom, args),
                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(1e3 * ms / calls, 2),
                     "step_hbm_frac": round(step_bytes_per_graph(N, F, L, E // B) * (value / world) / 1e9 / HBM_PEAK_GBS, 4)}
 

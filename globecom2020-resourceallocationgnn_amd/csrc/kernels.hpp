@@ -88,7 +88,10 @@ struct AggArgs {
   int transpose;                        // 0: out[q] = sum_{p->q} src[p];  1: out[p] = sum_{p->q} src[q]
 };
 
-__global__ __launch_bounds__(256) void k_agg(AggArgs a) {
+template <bool TRANSPOSE>   // forward gather (false) / its transpose for the backward pass (true)
+__global__ __launch_bounds__(256) void k_agg(AggArgs a_in) {
+  AggArgs a = a_in;
+  a.transpose = TRANSPOSE ? 1 : 0;                            // compile-time from here on
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sT = smem;                                         // [rows_cap][F]
   int* sRp = reinterpret_cast<int*>(sT + a.rows_cap * a.F); // [rows_cap+1]
@@ -264,24 +267,26 @@ __global__ __launch_bounds__(256) void k_gemm_rows(GemmArgs a) {
     for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
+      float w[NT][4];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        float w[4];
         if (!DGRAD) {
           // A[i = out feature nt*16+j][k = kb*16 + 4*kg + s]  = W[k][i]  (column of the image)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) w[s] = sW[(kb * 16 + 4 * kg + s) * LDW + nt * 16 + j];
+          for (int s = 0; s < 4; ++s) w[nt][s] = sW[(kb * 16 + 4 * kg + s) * LDW + nt * 16 + j];
         } else {
           // A[i = input feature][k = out feature]  = W[i][k]  (row of the image, skipping the xe rows)
           const int orow = nt < FB ? nt * 16 : F + XE + (nt - FB) * 16;
           const float4 tw = *reinterpret_cast<const float4*>(sW + (orow + j) * LDW + kb * 16 + 4 * kg);
-          w[0] = tw.x; w[1] = tw.y; w[2] = tw.z; w[3] = tw.w;
+          w[nt][0] = tw.x; w[nt][1] = tw.y; w[nt][2] = tw.z; w[nt][3] = tw.w;
         }
-        acc[nt] = V2X_MFMA(w[0], bf[kb].x, acc[nt]);
-        acc[nt] = V2X_MFMA(w[1], bf[kb].y, acc[nt]);
-        acc[nt] = V2X_MFMA(w[2], bf[kb].z, acc[nt]);
-        acc[nt] = V2X_MFMA(w[3], bf[kb].w, acc[nt]);
       }
+      // k-step outer, tile inner: consecutive MFMAs hit different accumulators (40-cycle dependent latency)
+      const float bv[4] = {bf[kb].x, bf[kb].y, bf[kb].z, bf[kb].w};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = V2X_MFMA(w[nt][s], bv[s], acc[nt]);
     }
     // epilogue: lane holds out[row j][nt*16 + 4*kg .. +3]
     if (t * 16 + j < a.n_idx) {
@@ -378,19 +383,19 @@ __device__ __forceinline__ void mlp_fill_lds(float* smem, const MlpArgs& a, int 
 template <int RT, int NT>
 __device__ __forceinline__ void mfma_cols(const float* sW, int ld, int kb, int j, int kg,
                                           const f32x4 (&bblk)[RT], f32x4 (&acc)[RT][NT]) {
+  // consecutive MFMAs go to DIFFERENT accumulators (k-step outer, tile inner): a dependent 16x16x4 f32 MFMA
+  // has 40 cycles of latency against a 32-cycle issue interval
+  float w[NT][4];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    float w[4];
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) w[s] = sW[(kb * 16 + 4 * kg + s) * ld + nt * 16 + j];
+    for (int s = 0; s < 4; ++s) w[nt][s] = sW[(kb * 16 + 4 * kg + s) * ld + nt * 16 + j];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      acc[rt][nt] = V2X_MFMA(w[0], bblk[rt][0], acc[rt][nt]);
-      acc[rt][nt] = V2X_MFMA(w[1], bblk[rt][1], acc[rt][nt]);
-      acc[rt][nt] = V2X_MFMA(w[2], bblk[rt][2], acc[rt][nt]);
-      acc[rt][nt] = V2X_MFMA(w[3], bblk[rt][3], acc[rt][nt]);
-    }
-  }
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = V2X_MFMA(w[nt][s], bblk[rt][s], acc[rt][nt]);
 }
 
 // acc (+)= W-tile(rows orow..orow+15) x grad-block  for one K block (row reads of the image)
@@ -405,6 +410,24 @@ __device__ __forceinline__ void mfma_rows(const float* sW, int ld, int orow, int
     acc[rt] = V2X_MFMA(t.z, bblk[rt][2], acc[rt]);
     acc[rt] = V2X_MFMA(t.w, bblk[rt][3], acc[rt]);
   }
+}
+
+// acc[nt] (+)= W-tile(rows orow(nt)..+15) x grad-block for one K block, all NT output tiles of a layer at once
+// (k-step outer, tile inner: independent accumulators back-to-back)
+template <int NT, typename OROW>
+__device__ __forceinline__ void mfma_rows_multi(const float* sW, int ld, OROW orow, int kb, int j, int kg,
+                                                const f32x4& bblk, f32x4 (&acc)[NT][1]) {
+  float4 t[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) t[nt] = *reinterpret_cast<const float4*>(sW + (orow(nt) + j) * ld + kb * 16 + 4 * kg);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt][0] = V2X_MFMA(t[nt].x, bblk[0], acc[nt][0]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt][0] = V2X_MFMA(t[nt].y, bblk[1], acc[nt][0]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt][0] = V2X_MFMA(t[nt].z, bblk[2], acc[nt][0]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt][0] = V2X_MFMA(t[nt].w, bblk[3], acc[nt][0]);
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) {
@@ -422,205 +445,230 @@ __device__ __forceinline__ f32x4 gate4(f32x4 g, f32x4 z) {   // g * (z > 0)
                  z[3] > 0.f ? g[3] : 0.f};
 }
 
-template <int F, int RT>
-__global__ __launch_bounds__(256) void k_mlp_fwd(MlpArgs a) {
+// Persistent tile loop shared by the two MLP kernels: the workgroup's 4 waves walk a contiguous range of 16-row
+// tiles (wave-interleaved); LOAD(t, buf) issues the global loads of tile t, COMPUTE(t, buf) consumes them.  The
+// steady state is branch-free (loads of tile t+4 are issued, THEN tile t is computed under a counted vmcnt;
+// sched_barrier pins that order) and the last one or two tiles are peeled.
+#define V2X_TILE_PIPELINE(T0, T_END, BUF_A, BUF_B, LOAD, COMPUTE)                     \
+  {                                                                                   \
+    int t_ = (T0);                                                                    \
+    const int nt_ = t_ < (T_END) ? ((T_END) - t_ + 3) >> 2 : 0;                       \
+    int k_ = 0;                                                                       \
+    if (nt_ > 0) LOAD(t_, BUF_A);                                                     \
+    for (; k_ + 2 < nt_; k_ += 2) {                                                   \
+      LOAD(t_ + 4 * (k_ + 1), BUF_B);                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      LOAD(t_ + 4 * (k_ + 2), BUF_A);                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      COMPUTE(t_ + 4 * (k_ + 1), BUF_B);                                              \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+    }                                                                                 \
+    if (nt_ - k_ == 2) {                                                              \
+      LOAD(t_ + 4 * (k_ + 1), BUF_B);                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
+      COMPUTE(t_ + 4 * (k_ + 1), BUF_B);                                              \
+    } else if (nt_ - k_ == 1) {                                                       \
+      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
+    }                                                                                 \
+  }
+
+template <int F>
+struct MlpFwdIn { f32x4 z0[2 * (F / 16) + 1]; int64_t row; };
+
+// Persistent: grid = (workgroups per slot, slots); the slot's 4 weight images are staged in LDS once.
+template <int F>
+__global__ __launch_bounds__(256, 2) void k_mlp_fwd(MlpArgs a) {
   using L = MlpLds<F>;
   constexpr int FB = F / 16, KB1 = 2 * FB + 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int slot = blockIdx.y;
-  mlp_fill_lds<F>(smem, a, slot, true);
-
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane & 15, kg = lane >> 4;
-  int64_t rows[RT];
-  bool valid[RT];
-  f32x4 z0[KB1][RT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int idx = blockIdx.x * (64 * RT) + wv * (16 * RT) + rt * 16 + j;
-    valid[rt] = idx < a.n_idx;
-    const int64_t row = (int64_t)(a.idx_base + min(idx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
-    rows[rt] = row;
-#pragma unroll
-    for (int b = 0; b < FB; ++b) z0[b][rt] = ld4(a.h + row * F + b * 16 + 4 * kg);
-    z0[FB][rt] = ld4(a.xe + row * XE + 4 * kg);
-#pragma unroll
-    for (int b = 0; b < FB; ++b) z0[FB + 1 + b][rt] = ld4(a.agg + row * F + b * 16 + 4 * kg);
-  }
-  __syncthreads();
+  const int n_tiles = (a.n_idx + 15) >> 4;
+  const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_end = min((int)(blockIdx.x + 1) * per, n_tiles);
 
-  // ---- Dense 0: [2F+9] -> 80, relu
-  f32x4 z1[RT][5];
+  auto load_in = [&](int t, MlpFwdIn<F>& in) {
+    const int idx = min(t * 16 + j, a.n_idx - 1);                 // clamped: always a valid row
+    const int64_t row = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
+    in.row = row;
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int b = 0; b < FB; ++b) in.z0[b] = ld4(a.h + row * F + b * 16 + 4 * kg);
+    in.z0[FB] = ld4(a.xe + row * XE + 4 * kg);
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) z1[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < FB; ++b) in.z0[FB + 1 + b] = ld4(a.agg + row * F + b * 16 + 4 * kg);
+  };
+  auto compute = [&](int t, const MlpFwdIn<F>& in) {
+    const bool valid = t * 16 + j < a.n_idx;
+    const int64_t row = in.row;
+    // ---- Dense 0: [2F+9] -> 80, relu
+    f32x4 z1[1][5];
 #pragma unroll
-  for (int kb = 0; kb < KB1; ++kb) mfma_cols<RT, 5>(smem + L::W1, LD1, kb, j, kg, z0[kb], z1);
+    for (int nt = 0; nt < 5; ++nt) z1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int kb = 0; kb < KB1; ++kb) {
+      f32x4 blk[1] = {in.z0[kb]};
+      mfma_cols<1, 5>(smem + L::W1, LD1, kb, j, kg, blk, z1);
+    }
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) {
-      z1[rt][nt] = relu4(z1[rt][nt] + ld4(smem + L::B1 + nt * 16 + 4 * kg));
-      if (valid[rt]) st4(a.z1 + rows[rt] * H1 + nt * 16 + 4 * kg, z1[rt][nt]);
+      z1[0][nt] = relu4(z1[0][nt] + ld4(smem + L::B1 + nt * 16 + 4 * kg));
+      if (valid) st4(a.z1 + row * H1 + nt * 16 + 4 * kg, z1[0][nt]);
     }
-  // ---- Dense 1: 80 -> 40 (48 padded), relu
-  f32x4 z2[RT][3];
+    // ---- Dense 1: 80 -> 40 (48 padded), relu
+    f32x4 z2[1][3];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int nt = 0; nt < 3; ++nt) z2[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) z2[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < 5; ++kb) {
-    f32x4 blk[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) blk[rt] = z1[rt][kb];
-    mfma_cols<RT, 3>(smem + L::W2, LD2, kb, j, kg, blk, z2);
-  }
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int kb = 0; kb < 5; ++kb) {
+      f32x4 blk[1] = {z1[0][kb]};
+      mfma_cols<1, 3>(smem + L::W2, LD2, kb, j, kg, blk, z2);
+    }
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
-      z2[rt][nt] = relu4(z2[rt][nt] + ld4(smem + L::B2 + nt * 16 + 4 * kg));
-      if (valid[rt] && nt * 16 + 4 * kg < H2) st4(a.z2 + rows[rt] * H2 + nt * 16 + 4 * kg, z2[rt][nt]);
+      z2[0][nt] = relu4(z2[0][nt] + ld4(smem + L::B2 + nt * 16 + 4 * kg));
+      if (valid && nt * 16 + 4 * kg < H2) st4(a.z2 + row * H2 + nt * 16 + 4 * kg, z2[0][nt]);
     }
-  // ---- Dense 2: 40 -> 20 (32 padded), relu
-  f32x4 z3[RT][2];
+    // ---- Dense 2: 40 -> 20 (32 padded), relu
+    f32x4 z3[1][2];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int nt = 0; nt < 2; ++nt) z3[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) z3[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < 3; ++kb) {
-    f32x4 blk[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) blk[rt] = z2[rt][kb];
-    mfma_cols<RT, 2>(smem + L::W3, LD3, kb, j, kg, blk, z3);
-  }
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+    for (int kb = 0; kb < 3; ++kb) {
+      f32x4 blk[1] = {z2[0][kb]};
+      mfma_cols<1, 2>(smem + L::W3, LD3, kb, j, kg, blk, z3);
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      z3[rt][nt] = relu4(z3[rt][nt] + ld4(smem + L::B3 + nt * 16 + 4 * kg));
-      if (valid[rt] && nt * 16 + 4 * kg < H3) st4(a.z3 + rows[rt] * H3 + nt * 16 + 4 * kg, z3[rt][nt]);
+      z3[0][nt] = relu4(z3[0][nt] + ld4(smem + L::B3 + nt * 16 + 4 * kg));
+      if (valid && nt * 16 + 4 * kg < H3) st4(a.z3 + row * H3 + nt * 16 + 4 * kg, z3[0][nt]);
     }
-  // ---- Dense 3: 20 -> C (16 padded), linear
-  f32x4 qa[RT][1];
+    // ---- Dense 3: 20 -> C (16 padded), linear
+    f32x4 qa[1][1];
+    qa[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) qa[rt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    f32x4 blk[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) blk[rt] = z3[rt][kb];
-    mfma_cols<RT, 1>(smem + L::W4, LD4, kb, j, kg, blk, qa);
-  }
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const f32x4 v = qa[rt][0] + ld4(smem + L::B4 + 4 * kg);
-    if (valid[rt] && 4 * kg < a.C) st4(a.q + rows[rt] * a.C + 4 * kg, v);
-  }
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 blk[1] = {z3[0][kb]};
+      mfma_cols<1, 1>(smem + L::W4, LD4, kb, j, kg, blk, qa);
+    }
+    const f32x4 v = qa[0][0] + ld4(smem + L::B4 + 4 * kg);
+    if (valid && 4 * kg < a.C) st4(a.q + row * a.C + 4 * kg, v);
+  };
+
+  MlpFwdIn<F> inA, inB;
+  mlp_fill_lds<F>(smem, a, slot, true);
+  __syncthreads();
+  V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, inA, inB, load_in, compute)
 }
 
+template <int F>
+struct MlpBwdIn { f32x4 q, y, z3[2], z2[3], z1[5]; int64_t row; };
+
 // Huber (delta = 1, tf.losses.huber_loss BS_brain.py:86-87) + reverse chain through the MLP.
-// Writes the pre-activation gradients dq, dz3, dz2, dz1 (for k_wgrad) and [dh | dagg].
-template <int F, int RT>
-__global__ __launch_bounds__(256) void k_mlp_bwd(MlpArgs a) {
+// Writes the pre-activation gradients dq, dz3, dz2, dz1 (for k_wgrad) and [dh | dagg].  Persistent like k_mlp_fwd.
+template <int F>
+__global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
   using L = MlpLds<F>;
   constexpr int FB = F / 16;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int slot = blockIdx.y;
-  mlp_fill_lds<F>(smem, a, slot, false);
-
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane & 15, kg = lane >> 4;
-  int64_t rows[RT];
-  bool valid[RT];
-  f32x4 g4[RT];        // dq block (16 wide, only channels < C non-zero)
+  const int n_tiles = (a.n_idx + 15) >> 4;
+  const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_end = min((int)(blockIdx.x + 1) * per, n_tiles);
+  // lanes whose 4 columns lie in the zero padding of a narrow layer read column 0 instead (unconditional
+  // loads; the value only gates a gradient that is already zero there)
+  const int c3[2] = {4 * kg, 16 + 4 * kg < H3 ? 16 + 4 * kg : 0};
+  const int c2[3] = {4 * kg, 16 + 4 * kg, 32 + 4 * kg < H2 ? 32 + 4 * kg : 0};
+  const int cq = 4 * kg < a.C ? 4 * kg : 0;
+
+  auto load_in = [&](int t, MlpBwdIn<F>& in) {
+    const int idx = min(t * 16 + j, a.n_idx - 1);
+    const int64_t row = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
+    in.row = row;
+    in.q = ld4(a.q + row * a.C + cq);
+    in.y = ld4(a.y + row * a.C + cq);
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int idx = blockIdx.x * (64 * RT) + wv * (16 * RT) + rt * 16 + j;
-    valid[rt] = idx < a.n_idx;
-    const int64_t row = (int64_t)(a.idx_base + min(idx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
-    rows[rt] = row;
-    g4[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < 2; ++nt) in.z3[nt] = ld4(a.z3 + row * H3 + c3[nt]);
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) in.z2[nt] = ld4(a.z2 + row * H2 + c2[nt]);
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) in.z1[nt] = ld4(a.z1 + row * H1 + nt * 16 + 4 * kg);
+  };
+  auto compute = [&](int t, const MlpBwdIn<F>& in) {
+    const bool valid = t * 16 + j < a.n_idx;
+    const int64_t row = in.row;
+    f32x4 g4[1];        // dq block (16 wide, only channels < C non-zero)
+    g4[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (4 * kg < a.C) {
-      const f32x4 qv = ld4(a.q + row * a.C + 4 * kg), yv = ld4(a.y + row * a.C + 4 * kg);
       float ls = 0.f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float err = qv[c] - yv[c];
+        const float err = in.q[c] - in.y[c];
         const float ab = fabsf(err), quad = fminf(ab, 1.f);
         ls += 0.5f * quad * quad + (ab - quad);
-        g4[rt][c] = fminf(fmaxf(err, -1.f), 1.f) * a.inv_denom;
+        g4[0][c] = fminf(fmaxf(err, -1.f), 1.f) * a.inv_denom;
       }
-      if (valid[rt]) {
-        st4(a.dq + row * a.C + 4 * kg, g4[rt]);
+      if (valid) {
+        st4(a.dq + row * a.C + 4 * kg, g4[0]);
         a.rowloss[row] = ls;      // C == 4: exactly one lane (kg == 0) per row
       }
     }
-  }
-  __syncthreads();
+    // ---- Dense 3 backward: dz3 = (dq . W4^T) * (z3 > 0)
+    const auto lin = [](int nt) { return nt * 16; };
+    f32x4 d3[2][1];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) d3[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows_multi<2>(smem + L::W4, LD4, lin, 0, j, kg, g4[0], d3);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const bool in_range = nt * 16 + 4 * kg < H3;
+      d3[nt][0] = in_range ? gate4(d3[nt][0], in.z3[nt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (valid && in_range) st4(a.dz3 + row * H3 + nt * 16 + 4 * kg, d3[nt][0]);
+    }
+    // ---- Dense 2 backward: dz2 = (dz3 . W3^T) * (z2 > 0)
+    f32x4 d2[3][1];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) d2[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) mfma_rows_multi<3>(smem + L::W3, LD3, lin, kb, j, kg, d3[kb][0], d2);
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const bool in_range = nt * 16 + 4 * kg < H2;
+      d2[nt][0] = in_range ? gate4(d2[nt][0], in.z2[nt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (valid && in_range) st4(a.dz2 + row * H2 + nt * 16 + 4 * kg, d2[nt][0]);
+    }
+    // ---- Dense 1 backward: dz1 = (dz2 . W2^T) * (z1 > 0)
+    f32x4 d1[5][1];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) d1[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) mfma_rows_multi<5>(smem + L::W2, LD2, lin, kb, j, kg, d2[kb][0], d1);
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      d1[nt][0] = gate4(d1[nt][0], in.z1[nt]);
+      if (valid) st4(a.dz1 + row * H1 + nt * 16 + 4 * kg, d1[nt][0]);
+    }
+    // ---- Dense 0 backward (data): [dh | dagg] = dz1 . W1^T   (h rows and agg rows of the image)
+    const auto skip_xe = [](int nt) { return nt < FB ? nt * 16 : F + XE + (nt - FB) * 16; };
+    f32x4 o[2 * FB][1];
+#pragma unroll
+    for (int nt = 0; nt < 2 * FB; ++nt) o[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) mfma_rows_multi<2 * FB>(smem + L::W1, LD1, skip_xe, kb, j, kg, d1[kb][0], o);
+#pragma unroll
+    for (int nt = 0; nt < 2 * FB; ++nt)
+      if (valid) st4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt][0]);
+  };
 
-  // ---- Dense 3 backward: dz3 = (dq . W4^T) * (z3 > 0)
-  f32x4 d3[2][RT];
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) d3[nt][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    mfma_rows<RT>(smem + L::W4, LD4, nt * 16, 0, j, kg, g4, d3[nt]);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const bool in = nt * 16 + 4 * kg < H3;
-      const f32x4 z = in ? ld4(a.z3 + rows[rt] * H3 + nt * 16 + 4 * kg) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      d3[nt][rt] = gate4(d3[nt][rt], z);
-      if (valid[rt] && in) st4(a.dz3 + rows[rt] * H3 + nt * 16 + 4 * kg, d3[nt][rt]);
-    }
-  }
-  // ---- Dense 2 backward: dz2 = (dz3 . W3^T) * (z2 > 0)
-  f32x4 d2[3][RT];
-#pragma unroll
-  for (int nt = 0; nt < 3; ++nt) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) d2[nt][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) mfma_rows<RT>(smem + L::W3, LD3, nt * 16, kb, j, kg, d3[kb], d2[nt]);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const bool in = nt * 16 + 4 * kg < H2;
-      const f32x4 z = in ? ld4(a.z2 + rows[rt] * H2 + nt * 16 + 4 * kg) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      d2[nt][rt] = gate4(d2[nt][rt], z);
-      if (valid[rt] && in) st4(a.dz2 + rows[rt] * H2 + nt * 16 + 4 * kg, d2[nt][rt]);
-    }
-  }
-  // ---- Dense 1 backward: dz1 = (dz2 . W2^T) * (z1 > 0)
-  f32x4 d1[5][RT];
-#pragma unroll
-  for (int nt = 0; nt < 5; ++nt) {
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) d1[nt][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 3; ++kb) mfma_rows<RT>(smem + L::W2, LD2, nt * 16, kb, j, kg, d2[kb], d1[nt]);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const f32x4 z = ld4(a.z1 + rows[rt] * H1 + nt * 16 + 4 * kg);
-      d1[nt][rt] = gate4(d1[nt][rt], z);
-      if (valid[rt]) st4(a.dz1 + rows[rt] * H1 + nt * 16 + 4 * kg, d1[nt][rt]);
-    }
-  }
-  // ---- Dense 0 backward (data): [dh | dagg] = dz1 . W1^T   (h rows and agg rows of the image)
-#pragma unroll
-  for (int nt = 0; nt < 2 * FB; ++nt) {
-    const int orow = nt < FB ? nt * 16 : F + XE + (nt - FB) * 16;
-    f32x4 o[RT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) o[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kb = 0; kb < 5; ++kb) mfma_rows<RT>(smem + L::W1, LD1, orow, kb, j, kg, d1[kb], o);
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-      if (valid[rt]) st4(a.gha + rows[rt] * (2 * F) + nt * 16 + 4 * kg, o[rt]);
-  }
+  MlpBwdIn<F> inA, inB;
+  mlp_fill_lds<F>(smem, a, slot, false);
+  __syncthreads();
+  V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, inA, inB, load_in, compute)
 }
 
 // =====================================================================================

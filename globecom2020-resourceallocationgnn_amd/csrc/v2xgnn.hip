@@ -167,16 +167,15 @@ void set_attrs_f() {
   allow_big_lds((const void*)k_gemm_rows<F, false, true, false>);
   allow_big_lds((const void*)k_gemm_rows<F, true, true, false>);
   allow_big_lds((const void*)k_gemm_rows<F, true, false, true>);
-  allow_big_lds((const void*)k_mlp_fwd<F, 1>);
-  allow_big_lds((const void*)k_mlp_fwd<F, 2>);
-  allow_big_lds((const void*)k_mlp_bwd<F, 1>);
-  allow_big_lds((const void*)k_mlp_bwd<F, 2>);
+  allow_big_lds((const void*)k_mlp_fwd<F>);
+  allow_big_lds((const void*)k_mlp_bwd<F>);
   allow_big_lds((const void*)k_wgrad<F, false>);
   allow_big_lds((const void*)k_wgrad<F, true>);
 }
 
 void set_attrs(int F) {
-  allow_big_lds((const void*)k_agg);
+  allow_big_lds((const void*)k_agg<false>);
+  allow_big_lds((const void*)k_agg<true>);
   if (F == 16) set_attrs_f<16>();
   if (F == 32) set_attrs_f<32>();
   if (F == 64) set_attrs_f<64>();
@@ -355,7 +354,8 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, 
                      (size_t)a.edges_cap * 4 + (transpose ? (size_t)a.rows_cap * a.mask_words * 4 : 0);
   if (lds > 160 * 1024) FAIL(m, V2X_EINVAL, "agg: graph tile (%zu B) exceeds the 160 KiB LDS", lds);
   const dim3 grid((r.ng + gpw - 1) / gpw);
-  LAUNCH(m, transpose ? "k_agg_bwd" : "k_agg_fwd", k_agg, grid, lds, st, a);
+  if (transpose) { auto k = k_agg<true>; LAUNCH(m, "k_agg_bwd", k, grid, lds, st, a); }
+  else { auto k = k_agg<false>; LAUNCH(m, "k_agg_fwd", k, grid, lds, st, a); }
   return V2X_OK;
 }
 
@@ -444,15 +444,10 @@ void mlp_args(v2x_model* m, MlpArgs& a, const IdxMap& x, const float* xe, const 
 template <int F>
 int launch_mlp_f(v2x_model* m, hipStream_t st, MlpArgs& a, int grid_y, bool bwd) {
   const size_t lds = (size_t)MlpLds<F>::TOTAL * 4;
-  const bool big = a.n_idx >= 4096;
-#define V2X_MLP_CASE(KERN, RT, NAME)                                                                      \
-  {                                                                                                       \
-    auto k = KERN<F, RT>;                                                                                 \
-    LAUNCH(m, NAME, k, dim3((a.n_idx + 64 * RT - 1) / (64 * RT), grid_y), lds, st, a);                    \
-  }
-  if (!bwd) { if (big) V2X_MLP_CASE(k_mlp_fwd, 2, "k_mlp_fwd") else V2X_MLP_CASE(k_mlp_fwd, 1, "k_mlp_fwd") }
-  else      { if (big) V2X_MLP_CASE(k_mlp_bwd, 2, "k_mlp_bwd") else V2X_MLP_CASE(k_mlp_bwd, 1, "k_mlp_bwd") }
-#undef V2X_MLP_CASE
+  static const int wgs_per_cu = env_int("V2X_MLP_WGS_PER_CU", 2);
+  const int gx = persistent_wgs_per_slot(a.n_idx, grid_y, wgs_per_cu);
+  if (!bwd) { auto k = k_mlp_fwd<F>; LAUNCH(m, "k_mlp_fwd", k, dim3(gx, grid_y), lds, st, a); }
+  else { auto k = k_mlp_bwd<F>; LAUNCH(m, "k_mlp_bwd", k, dim3(gx, grid_y), lds, st, a); }
   return V2X_OK;
 }
 

@@ -246,3 +246,52 @@ def test_grad_tensor_aliases_library_memory():
     t.fill_(3.0)
     torch.cuda.synchronize()
     assert (eng.get_grad_flat() == 3.0).all()
+
+
+def test_ragged_graphs_shared_weights_vs_oracle():
+    """BASELINE config 5 shape: graphs of different sizes packed with graph_off, shared weights.  Forward, loss and
+    every gradient against the CSR oracle (single Huber mean over all rows x channels)."""
+    import ctypes as C
+    from oracle.spec import GnnSpec as OSpec
+    F = 64
+    spec = GnnSpec(n_nodes=1, feat_dim=F, share_weights=True, variable_graphs=True)
+    osp = OSpec(n_nodes=1, feat_dim=F, share_weights=True)
+    rng = np.random.default_rng(42)
+    sizes = [8, 33, 1, 128, 17, 64, 9, 100, 2, 40]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    R = int(offs[-1])
+    row_ptr, cols, max_e = [0], [], 0
+    for n in sizes:
+        adj = rng.uniform(size=(n, n)) < min(0.5, 6.0 / max(n, 1))
+        e_g = 0
+        for q in range(n):
+            src = np.nonzero(adj[:, q])[0]
+            cols.append(src)
+            row_ptr.append(row_ptr[-1] + len(src))
+            e_g += len(src)
+        max_e = max(max_e, e_g)
+    col_idx = np.concatenate(cols).astype(np.int32)
+    x = np.concatenate([rng.normal(0.84, 0.39, size=(R, 4)), rng.normal(0.6, 0.21, size=(R, 4)), np.full((R, 1), 10.0)], 1).astype(np.float32)
+    e = rng.normal(0.88, 0.11, size=(R, 4)).astype(np.float32)
+    pb = PackedBatch(len(sizes), 0, v2xgnn.pack_xe(x, e), np.array(row_ptr, np.int32), col_idx, max_e,
+                     graph_off=offs, max_nodes=max(sizes))
+    P = f32_params(spec, rng)
+    eng = GnnEngine(spec)
+    eng.set_weights(oc.params_to_list(P))
+    M = oc.csr_to_matrix(offs, pb.row_ptr, pb.col_idx, np.float64)
+    q_ref, cache = oc.forward(osp, P, x.astype(np.float64), e.astype(np.float64), M)
+    q = eng.forward(pb)
+    assert_fwd_close(q, q_ref, "ragged forward")
+    y = (q_ref + rng.normal(0, 1.2, size=q_ref.shape)).astype(np.float32)
+    err = q.astype(np.float64) - y
+    ab = np.abs(err)
+    quad = np.minimum(ab, 1.0)
+    loss_ref = (0.5 * quad * quad + (ab - quad)).sum() / (R * 4)
+    dq = np.clip(err, -1, 1) / (R * 4)
+    g_ref = oc.backward(osp, P, cache, dq)
+    loss = eng.forward_backward(pb, y)
+    assert loss.shape == (1,)
+    assert_close(loss, [loss_ref], 2e-4, 1e-7, "ragged loss")
+    got = v2xgnn.flat_to_keras_list(spec, eng.get_grad_flat())
+    for i, (a, b) in enumerate(zip(got, oc.params_to_list(g_ref))):
+        assert_grad_close(a, b, "ragged gradient array %d" % i)

@@ -148,9 +148,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    force_dp = os.environ.get("V2X_FORCE_DP") == "1"      # exercise the RCCL path with a single rank (tests)
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     N, F, L, B = args.nodes, args.feat, args.layers, args.batch
@@ -165,7 +167,7 @@ def main():
     db = eng.to_device(pb)
     yd = torch.from_numpy(y).to(db.device)
     n_global = B * world
-    trainer = DataParallelTrainer(eng) if world > 1 else None
+    trainer = DataParallelTrainer(eng, force=force_dp) if (world > 1 or force_dp) else None
 
     def one_step():
         if trainer is not None:

@@ -216,6 +216,36 @@ struct GemmArgs {
   int idx_base;
 };
 
+// Persistent tile loop shared by the node-update and MLP kernels: the workgroup's 4 waves walk a contiguous range of 16-row
+// tiles (wave-interleaved); LOAD(t, buf) issues the global loads of tile t, COMPUTE(t, buf) consumes them.  The
+// steady state is branch-free (loads of tile t+4 are issued, THEN tile t is computed under a counted vmcnt;
+// sched_barrier pins that order) and the last one or two tiles are peeled.
+#define V2X_TILE_PIPELINE(T0, T_END, BUF_A, BUF_B, LOAD, COMPUTE)                     \
+  {                                                                                   \
+    int t_ = (T0);                                                                    \
+    const int nt_ = t_ < (T_END) ? ((T_END) - t_ + 3) >> 2 : 0;                       \
+    int k_ = 0;                                                                       \
+    if (nt_ > 0) LOAD(t_, BUF_A);                                                     \
+    for (; k_ + 2 < nt_; k_ += 2) {                                                   \
+      LOAD(t_ + 4 * (k_ + 1), BUF_B);                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      LOAD(t_ + 4 * (k_ + 2), BUF_A);                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      COMPUTE(t_ + 4 * (k_ + 1), BUF_B);                                              \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+    }                                                                                 \
+    if (nt_ - k_ == 2) {                                                              \
+      LOAD(t_ + 4 * (k_ + 1), BUF_B);                                                 \
+      __builtin_amdgcn_sched_barrier(0);                                              \
+      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
+      COMPUTE(t_ + 4 * (k_ + 1), BUF_B);                                              \
+    } else if (nt_ - k_ == 1) {                                                       \
+      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
+    }                                                                                 \
+  }
+
 // Persistent form: grid = (workgroups per slot, slots).  A workgroup stages its slot's weight image in LDS
 // ONCE, then its 4 waves walk a contiguous range of 16-row tiles (wave-interleaved), each wave keeping the
 // NEXT tile's activation fragments in flight (register double buffer) while the MFMAs of the current tile
@@ -307,23 +337,14 @@ __global__ __launch_bounds__(256) void k_gemm_rows(GemmArgs a) {
     }
   };
 
-  int t = blockIdx.x * per + wv;
-  float4 bfA[KB], bfB[KB];
-  int64_t rowA = 0, rowB = 0;
-  if (t < t_end) load_tile(t, bfA, rowA);          // in flight while the weights are staged
+  struct Tile { float4 bf[KB]; int64_t row; };
+  auto load_t = [&](int t, Tile& x) { load_tile(t, x.bf, x.row); };
+  auto comp_t = [&](int t, const Tile& x) { compute_store(t, x.bf, x.row); };
+  Tile tA, tB;
   fill_weight_image<KP, F, LDW>(sW, Wg, a.pad, F);
   if (!DGRAD) fill_bias(sB, F, Wg + (int64_t)a.pad.k_real * F, F);
   __syncthreads();
-
-  for (; t < t_end; t += 8) {
-    const bool haveB = t + 4 < t_end;              // wave-uniform
-    if (haveB) load_tile(t + 4, bfB, rowB);
-    compute_store(t, bfA, rowA);
-    if (haveB) {
-      if (t + 8 < t_end) load_tile(t + 8, bfA, rowA);
-      compute_store(t + 4, bfB, rowB);
-    }
-  }
+  V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, tA, tB, load_t, comp_t)
 }
 
 // =====================================================================================
@@ -444,36 +465,6 @@ __device__ __forceinline__ f32x4 gate4(f32x4 g, f32x4 z) {   // g * (z > 0)
   return (f32x4){z[0] > 0.f ? g[0] : 0.f, z[1] > 0.f ? g[1] : 0.f, z[2] > 0.f ? g[2] : 0.f,
                  z[3] > 0.f ? g[3] : 0.f};
 }
-
-// Persistent tile loop shared by the two MLP kernels: the workgroup's 4 waves walk a contiguous range of 16-row
-// tiles (wave-interleaved); LOAD(t, buf) issues the global loads of tile t, COMPUTE(t, buf) consumes them.  The
-// steady state is branch-free (loads of tile t+4 are issued, THEN tile t is computed under a counted vmcnt;
-// sched_barrier pins that order) and the last one or two tiles are peeled.
-#define V2X_TILE_PIPELINE(T0, T_END, BUF_A, BUF_B, LOAD, COMPUTE)                     \
-  {                                                                                   \
-    int t_ = (T0);                                                                    \
-    const int nt_ = t_ < (T_END) ? ((T_END) - t_ + 3) >> 2 : 0;                       \
-    int k_ = 0;                                                                       \
-    if (nt_ > 0) LOAD(t_, BUF_A);                                                     \
-    for (; k_ + 2 < nt_; k_ += 2) {                                                   \
-      LOAD(t_ + 4 * (k_ + 1), BUF_B);                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                              \
-      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
-      __builtin_amdgcn_sched_barrier(0);                                              \
-      LOAD(t_ + 4 * (k_ + 2), BUF_A);                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                              \
-      COMPUTE(t_ + 4 * (k_ + 1), BUF_B);                                              \
-      __builtin_amdgcn_sched_barrier(0);                                              \
-    }                                                                                 \
-    if (nt_ - k_ == 2) {                                                              \
-      LOAD(t_ + 4 * (k_ + 1), BUF_B);                                                 \
-      __builtin_amdgcn_sched_barrier(0);                                              \
-      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
-      COMPUTE(t_ + 4 * (k_ + 1), BUF_B);                                              \
-    } else if (nt_ - k_ == 1) {                                                       \
-      COMPUTE(t_ + 4 * k_, BUF_A);                                                    \
-    }                                                                                 \
-  }
 
 template <int F>
 struct MlpFwdIn { f32x4 z0[2 * (F / 16) + 1]; int64_t row; };

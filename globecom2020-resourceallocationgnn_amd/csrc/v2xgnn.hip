@@ -381,7 +381,7 @@ int launch_gemm_t(v2x_model* m, hipStream_t st, GemmArgs& a, int grid_y, const c
   constexpr int KB = DGRAD ? FB : ((HAS0 ? FB : 0) + 1 + (HAS2 ? FB : 0));
   constexpr int KP = DGRAD ? (2 * F + XE) : KB * 16;
   const size_t lds = (size_t)(KP * (F + 4) + F) * 4;
-  static const int wgs_per_cu = env_int("V2X_GEMM_WGS_PER_CU", 1);
+  static const int wgs_per_cu = env_int("V2X_GEMM_WGS_PER_CU", 2);
   const int gx = persistent_wgs_per_slot(a.n_idx, grid_y, wgs_per_cu);
   auto k = k_gemm_rows<F, HAS0, HAS2, DGRAD>;
   LAUNCH(m, name, k, dim3(gx, grid_y), lds, st, a);

@@ -16,7 +16,7 @@ class DataParallelTrainer(object):
     grad_tensor() -> flat torch tensor aliasing the gradient buffer, apply_gradients().
     `GnnEngine` is the GPU backend."""
 
-    def __init__(self, backend, process_group=None):
+    def __init__(self, backend, process_group=None, force=False):
         import torch.distributed as dist
         self.dist = dist
         self.backend = backend
@@ -24,6 +24,7 @@ class DataParallelTrainer(object):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self._grad = None
+        self.force = force          # run the collective even with one rank (exercises the RCCL path)
 
     def shard(self, batch, y):
         """Contiguous shard of whole graphs for this rank.  y is [R, C] for the full batch."""
@@ -36,7 +37,7 @@ class DataParallelTrainer(object):
     def train_step(self, local_batch, local_y, n_graphs_global, want_loss=True):
         """forward+backward on the local shard, all-reduce the gradient, Adam on every rank."""
         loss = self.backend.forward_backward(local_batch, local_y, n_global=n_graphs_global, want_loss=want_loss)
-        if self.world > 1:
+        if self.world > 1 or self.force:
             if self._grad is None:
                 self._grad = self.backend.grad_tensor()
             self.dist.all_reduce(self._grad, op=self.dist.ReduceOp.SUM, group=self.group)

@@ -295,3 +295,22 @@ def test_ragged_graphs_shared_weights_vs_oracle():
     got = v2xgnn.flat_to_keras_list(spec, eng.get_grad_flat())
     for i, (a, b) in enumerate(zip(got, oc.params_to_list(g_ref))):
         assert_grad_close(a, b, "ragged gradient array %d" % i)
+
+
+def test_rccl_path_single_rank(tmp_path):
+    """bench.py launched the way the driver launches it (torch.distributed.run, backend nccl == RCCL) with one
+    rank: process-group init, the in-place all-reduce on the engine's aliased gradient buffer and the split
+    forward_backward / apply_gradients step all run for real; multi-rank numerics are covered by the gloo test."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(GOLDEN.rstrip('/')).rsplit('/tests', 1)[0]
+    env = dict(os.environ, V2X_FORCE_DP="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
+           "--batch", "256", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["global_batch"] == 256

@@ -123,6 +123,28 @@ class GnnQModel(object):
                 hist.history[name + '_loss'].append(float(tot[k]))
         return hist
 
+    # ------------------------------------------------------------------ compact surface
+    # Same arithmetic as predict / fit without the dict-of-arrays and the dense kron(Adj, I_F)
+    # adjacency (6.5 MB per graph at 20 links x 64 features); used by v2xgnn.rl.Agent.
+    def predict_arrays(self, x, e, adj, nbr=None):
+        """x [B, N, Dn], e [B, N, De], adj [B, N, N] (Adj[p, q] = 1 when p sends to q) -> Q [B, N, C]"""
+        x = np.asarray(x)
+        q = self.engine.forward(PackedBatch.from_dense(x, e, adj, nbr))
+        return q.reshape(x.shape[0], self.spec.n_nodes, self.spec.n_channels)
+
+    def fit_arrays(self, x, e, adj, y, nbr=None):
+        """One Adam step on the whole batch (what the reference's fit call amounts to, BS_brain.py:218-223);
+        y [B, N, C].  -> History with the same keys as fit."""
+        loss = self.engine.train_step(PackedBatch.from_dense(x, e, adj, nbr),
+                                      np.asarray(y).reshape(-1, self.spec.n_channels))
+        loss = np.asarray(loss, np.float64)
+        hist = History()
+        hist.epoch.append(0)
+        hist.history['loss'] = [float(loss.sum())]
+        for k, name in enumerate(self.output_names):
+            hist.history[name + '_loss'] = [float(loss[k])]
+        return hist
+
     def train_on_batch(self, x, y):
         h = self.fit(x, y, batch_size=len(next(iter(self._named(x, self.input_names, "input").values()))),
                      epochs=1, shuffle=False)

@@ -1,0 +1,266 @@
+"""DQN agent glue around the Q-network: the counterpart of the reference `Memory` (BS_brain.py:245-270) and
+`Agent` (BS_brain.py:280-910) for any number of V2V links (the reference hard-codes D1..D4), SURVEY.md 8f-1.
+
+Same method names, argument meaning, return values and numpy-RNG consumption as the reference, so a seeded run
+with the same brain reproduces the reference's replay memory and the exact x / y payload it hands to `fit`
+(pinned by tests/golden/golden_agent_n4.npz, captured from the reference agent on the real simulator).  What is
+different: no per-sample Python loops (state packing, batch assembly and target construction are vectorised), and
+when the brain exposes the compact entry points (`predict_arrays` / `fit_arrays`, v2xgnn.GnnQModel) the dense
+`kron(Adj, I_F)` adjacency of the dict payload -- 6.5 MB per graph at 20 links x 64 features -- is never built.
+"""
+import datetime
+import os
+
+import numpy as np
+
+MEMORY_CAPACITY = 1000000          # BS_brain.py:274
+UPDATE_TARGET_FREQUENCY = 500      # :275
+MAX_EPSILON = 1                    # :276
+MIN_EPSILON = 0.01                 # :277
+
+
+class Memory(object):
+    """FIFO replay memory of (s, a, r, s_) (BS_brain.py:245-270); per-instance storage (the reference's list is a
+    class attribute shared by all instances, :246)."""
+
+    def __init__(self, capacity):
+        self.capacity = int(capacity)
+        self.samples = []
+
+    def add(self, sample):
+        self.samples.append(sample)
+        if len(self.samples) > self.capacity:
+            self.samples.pop(0)
+
+    def sample(self, n):
+        """n distinct samples when enough are stored, otherwise n draws with replacement -- the same global
+        numpy RNG calls as the reference (:261, :268)."""
+        if len(self.samples) >= n:
+            idx = np.random.choice(len(self.samples), n, replace=False)
+        else:
+            idx = [np.random.randint(0, len(self.samples)) for _ in range(n)]
+        return [self.samples[i] for i in idx]
+
+
+class Agent(object):
+    def __init__(self, num_d2d, num_ch, num_neighbor, num_d2d_feedback, environment, curr_rl_config, brain=None,
+                 **brain_kwargs):
+        self.epsilon = MAX_EPSILON
+        self.num_step = 0
+        self.num_CH = num_ch
+        self.num_D2D = num_d2d
+        self.num_Neighbor = num_neighbor
+        self.num_Feedback = num_d2d_feedback
+        self.memory = Memory(MEMORY_CAPACITY)
+        self.input_Node_Info = 3       # BS_brain.py:294
+        self.input_Edge_Info = 1       # :295
+        self.env = environment
+        if brain is None:
+            from ..bs_brain import BS
+            brain = BS(self.num_D2D, self.input_Node_Info, self.input_Edge_Info, self.num_Feedback,
+                       self.num_Neighbor, self.num_CH, **brain_kwargs)
+        self.brain = brain
+        self.num_States = self.brain.num_D2D_Input
+        self.num_Actions = self.num_CH * self.num_Neighbor
+        self.batch_size = curr_rl_config.Batch_Size
+        self.gamma = curr_rl_config.Gamma
+        self.v2v_weight = curr_rl_config.v2v_weight
+        self.v2i_weight = curr_rl_config.v2i_weight
+        self.num_Episodes, self.num_Train_Step, self.num_transition = 1, 1, 50
+
+    # ------------------------------------------------------------------ observation
+    def get_state(self, idx):
+        """Normalised observation of link idx[0] towards its idx[1]-th receiver (BS_brain.py:389-407)."""
+        Constant_A, Constant_B = 80, 60
+        v2v = self.env.V2V_channels_with_fastfading
+        dst = self.env.vehicles[idx[0]].destinations[idx[1]]
+        V2V_channel = (v2v[idx[0], dst, :] - Constant_A) / Constant_B
+        V2I_channel = (self.env.V2I_channels_with_fastfading[idx[0], :] - Constant_A) / Constant_B
+        V2V_edge = (((np.sum(v2v[:, dst, :], axis=0) - v2v[dst, dst, :]) - (self.num_D2D - 1) * Constant_A) / Constant_B
+                    - V2V_channel) / (self.num_D2D - 2)
+        return V2V_channel, V2I_channel, V2V_edge
+
+    def adjacency(self):
+        """Adj[p, q] = 1 unless p == q or p is the receiver of link q (BS_brain.py:441-445)."""
+        n = self.num_D2D
+        adj = np.ones((n, n)) - np.eye(n)
+        for q in range(n):
+            adj[self.env.vehicles[q].destinations[0], q] = 0
+        return adj
+
+    def observe(self):
+        """-> D2D_State [N, Dn+De] = [V2V gain x C | V2I gain x C | power | edge gain x C] (BS_brain.py:458-467)
+        and the adjacency."""
+        n, C, nn = self.num_D2D, self.num_CH, self.num_Neighbor
+        power = self.env.V2V_power_dB_List[self.env.fixed_v2v_power_index]
+        state = np.zeros((n, self.brain.num_One_D2D_Input))
+        for k in range(n):
+            ch, v2i, edge = np.zeros((nn, C)), None, np.zeros((nn, C))
+            for m in range(nn):
+                ch[m], v2i, edge[m] = self.get_state([k, m])
+            state[k, 0:nn * C] = ch.reshape(-1)
+            state[k, nn * C:2 * nn * C] = v2i
+            state[k, 2 * nn * C:2 * nn * C + nn] = power
+            state[k, 2 * nn * C + nn:] = edge.reshape(-1)
+        return state, self.adjacency()
+
+    # ------------------------------------------------------------------ brain I/O
+    def _compact(self):
+        return hasattr(getattr(self.brain, 'model', None), 'predict_arrays')
+
+    def _feed(self, states, adj):
+        """states [B, N, Dn+De], adj [B, N, N] -> the reference's dict payload (BS_brain.py:495-504, :642-651)."""
+        B, n = states.shape[0], self.num_D2D
+        dn, F = self.brain.num_One_Node_Input, self.brain.num_Feedback
+        feed = {}
+        for k in range(n):
+            feed['D%d_Node_Input' % (k + 1)] = np.array(states[:, k, :dn])
+            feed['D%d_Edge_Input' % (k + 1)] = np.array(states[:, k, dn:])
+            feed['D%d_Neighbor_Input' % (k + 1)] = np.zeros((B, F))
+        feed['Adjacency_Matrix'] = np.kron(adj, np.eye(F))
+        return feed
+
+    def _predict(self, states, adj, target=False):
+        """-> Q [N, B, C]"""
+        dn = self.brain.num_One_Node_Input
+        if self._compact():
+            model = self.brain.target_model if target else self.brain.model
+            q = model.predict_arrays(states[:, :, :dn], states[:, :, dn:], adj)          # [B, N, C]
+            return np.ascontiguousarray(np.transpose(q, (1, 0, 2)))
+        return np.stack(self.brain.predict(self._feed(states, adj), target=target))
+
+    # ------------------------------------------------------------------ acting
+    def select_action_while_training(self, state):
+        """epsilon-greedy (BS_brain.py:308-352); `state` = (D2D_State [N, .], Adj [N, N])."""
+        n, nn = self.num_D2D, self.num_Neighbor
+        steps = self.num_Episodes * 0.8 * self.num_Train_Step * self.num_transition
+        per_step = (MAX_EPSILON - MIN_EPSILON) / steps
+        self.epsilon = MAX_EPSILON - per_step * self.num_step if self.num_step < steps else MIN_EPSILON
+        if np.random.random() < self.epsilon:
+            action = np.zeros((n, nn))
+            for k in range(n):
+                action[k, :] = np.random.choice(range(0, self.num_CH), nn)
+            return action.astype(int)
+        d2d_state, adj = state
+        q = self._predict(d2d_state[None], adj[None])[:, 0, :]                           # [N, C]
+        return np.argmax(q, axis=1).reshape(n, nn).astype(int)   # first maximiser, as np.where(...)[0][0] (:342-344)
+
+    def select_action_random(self, state):
+        action = np.zeros((self.num_D2D, self.num_Neighbor))
+        for k in range(self.num_D2D):
+            action[k, :] = np.random.choice(range(0, self.num_CH), self.num_Neighbor)
+        return action.astype(int)
+
+    def act(self, actions):
+        """BS_brain.py:366-376"""
+        self.num_step += 1
+        rates = self.env.compute_reward_with_channel_selection(actions)
+        self.env.renew_positions()
+        self.env.renew_channels_fastfading()
+        self.env.Compute_Interference(actions)
+        return rates
+
+    def dump_act(self, actions):
+        return self.env.compute_reward_with_channel_selection(actions)
+
+    def train_observe(self, sample):
+        self.memory.add(sample)
+
+    def generate_d2d_transition(self, num_transitions):
+        """num_transitions environment steps under the epsilon-greedy policy into the replay memory
+        (BS_brain.py:409-553).  A sample is [States(1, N*13+N*N), Actions(1, N), reward, States_]."""
+        rewards = np.zeros(num_transitions)
+        for self.train_step in range(num_transitions):
+            d2d_state, adj = self.observe()
+            states = np.concatenate((d2d_state.reshape(1, -1), adj.reshape(1, -1)), axis=-1)
+            action = self.select_action_while_training((d2d_state, adj))
+            v2v_rate, v2i_rate, _ = self.act(action)
+            reward = self.v2v_weight * np.sum(np.sum(v2v_rate, axis=1)) + self.v2i_weight * np.sum(v2i_rate)
+            rewards[self.train_step] = reward
+            next_state, _ = self.observe()
+            states_ = np.concatenate((next_state.reshape(1, -1), adj.reshape(1, -1)), axis=-1)   # same adjacency (:547)
+            self.train_observe([states, action.reshape(1, -1), reward, states_])
+        return rewards
+
+    # ------------------------------------------------------------------ learning
+    def replay(self):
+        """One DQN update on a replay minibatch (BS_brain.py:555-748): y = Q(s) with the taken action's entry
+        replaced by r + gamma * max_a' Q_target(s', a')."""
+        n, d = self.num_D2D, self.brain.num_One_D2D_Input
+        batch = self.memory.sample(self.batch_size)
+        B = len(batch)
+        s = np.stack([b[0][0] for b in batch])
+        s_ = np.stack([b[3][0] for b in batch])
+        a = np.stack([b[1][0] for b in batch]).astype(int)                                # [B, N]
+        r = np.array([b[2] for b in batch], dtype=np.float64)
+        states, adj = s[:, :n * d].reshape(B, n, d), s[:, n * d:].reshape(B, n, n)
+        states_ = s_[:, :n * d].reshape(B, n, d)
+        p = self._predict(states, adj)                                                    # online   [N, B, C]
+        p_ = self._predict(states_, adj, target=True)                                     # target   (adjacency reused, :583)
+        target = r[None, :] + self.gamma * np.max(p_, axis=2)                             # [N, B]
+        np.put_along_axis(p, np.transpose(a)[:, :, None], target[:, :, None].astype(p.dtype), axis=2)
+        y = p.astype(np.float64)
+        if self._compact():
+            dn = self.brain.num_One_Node_Input
+            result = self.brain.model.fit_arrays(states[:, :, :dn], states[:, :, dn:], adj, np.transpose(y, (1, 0, 2)))
+        else:
+            y_train = {'D%d_Decide_Output' % (k + 1): y[k] for k in range(n)}
+            result = self.brain.train_dnn(self._feed(states, adj), y_train, self.batch_size)
+        q_mean = np.sum(np.sum(y, axis=2) / self.num_Actions, axis=1) / B
+        q_max_mean = np.sum(np.max(y, axis=2), axis=1) / B
+        # the reference reads "original" Q statistics from p AFTER it was overwritten in place (:684-690, :743-746)
+        return result, q_mean, q_max_mean, q_mean.copy(), q_max_mean.copy()
+
+    def train(self, num_episodes, num_train_steps, save_dir=None, save_interval=5, verbose=False):
+        """BS_brain.py:750-910 without the plotting / pickling: episodes x train steps x (50 transitions + 1 replay),
+        target sync whenever num_step is a multiple of 500, weights saved every `save_interval` episodes."""
+        self.num_Episodes, self.num_Train_Step = num_episodes, num_train_steps
+        n = self.num_D2D
+        self.num_transition = 50
+        loss = np.ones((n, num_episodes, num_train_steps))
+        q_mean, q_max = np.zeros_like(loss), np.zeros_like(loss)
+        self.num_step = 0
+        reward_step = np.zeros((num_episodes, num_train_steps, self.num_transition))
+        reward_episode = np.zeros(num_episodes)
+        for ep in range(num_episodes):
+            self.env.new_random_game(self.num_D2D)
+            for it in range(num_train_steps):
+                reward_step[ep, it, :] = self.generate_d2d_transition(self.num_transition)
+                result, qm, qx, _, _ = self.replay()
+                for k in range(n):
+                    loss[k, ep, it] = result.history['D%d_Decide_Output_loss' % (k + 1)][0]
+                q_mean[:, ep, it], q_max[:, ep, it] = qm, qx
+                if self.num_step % UPDATE_TARGET_FREQUENCY == 0:
+                    self.brain.update_target_model()
+            reward_episode[ep] = np.sum(reward_step[ep])
+            if verbose:
+                print(datetime.datetime.now().strftime('%H:%M:%S'), 'episode', ep + 1, 'reward %.3f' % reward_episode[ep],
+                      'loss', np.round(loss[:, ep].mean(axis=1), 4))
+            if save_dir is not None and (ep + 1) % save_interval == 0:
+                os.makedirs(save_dir, exist_ok=True)
+                tag = '-Episode-%d-Step-%d-Batch-%d.h5' % (ep + 1, num_train_steps, self.batch_size)     # names of :859-868
+                self.brain.model.save_weights(os.path.join(save_dir, 'Q-Network_model_weights' + tag))
+                self.brain.target_model.save_weights(os.path.join(save_dir, 'Target-Network_model_weights' + tag))
+        return loss, reward_step, reward_episode, q_mean, q_max, q_mean.copy(), q_max.copy()
+
+    # ------------------------------------------------------------------ evaluation
+    def generate_d2d_initial_states(self):
+        """BS_brain.py:912-984: the dict payload of the current simulator state (B = 1)."""
+        d2d_state, adj = self.observe()
+        return self._feed(d2d_state[None], adj[None])
+
+    def test_run(self, num_episodes, num_test_step):
+        """Greedy policy vs the random-action baseline (BS_brain.py:986-1162 without the 4^4 brute force)."""
+        self.num_Episodes, self.num_Test_Step = num_episodes, num_test_step
+        rl, rnd = np.zeros((num_episodes, num_test_step)), np.zeros((num_episodes, num_test_step))
+        for ep in range(num_episodes):
+            self.env.new_random_game(self.num_D2D)
+            for st in range(num_test_step):
+                d2d_state, adj = self.observe()
+                v2v, v2i, _ = self.dump_act(self.select_action_random(None))
+                rnd[ep, st] = self.v2v_weight * np.sum(v2v) + self.v2i_weight * np.sum(v2i)
+                q = self._predict(d2d_state[None], adj[None])[:, 0, :]
+                action = np.argmax(q, axis=1).reshape(self.num_D2D, self.num_Neighbor).astype(int)
+                v2v, v2i, _ = self.act(action)
+                rl[ep, st] = self.v2v_weight * np.sum(v2v) + self.v2i_weight * np.sum(v2i)
+        return rl, rnd

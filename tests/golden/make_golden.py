@@ -295,6 +295,76 @@ def main():
             for k, o in enumerate(model.outputs):
                 fwd[pre + 'out/%d' % k] = o
     np.savez_compressed(os.path.join(OUT, 'golden_forward_n4.npz'), **fwd)
+
+    # ---- (3) simulator trajectories: the reference Environ stepped with seeded random actions
+    #          (Environment.py:179-506; the call order per step is Agent.act, BS_brain.py:366-376)
+    for n_veh, steps in ((4, 40), (20, 12)):
+        random.seed(2020 + n_veh)
+        np.random.seed(2020 + n_veh)
+        env = make_env(Environment)
+        if n_veh != env.n_Veh:
+            env.new_random_game(n_veh)
+        tr = {'n_veh': n_veh, 'steps': steps,
+              'init_pos': np.array([v.position for v in env.vehicles], float),
+              'init_dir': np.array([v.direction for v in env.vehicles]),
+              'velocity': np.array([v.velocity for v in env.vehicles], float),
+              'init_dest': np.array([v.destinations[0] for v in env.vehicles]),
+              'init_v2v': env.V2V_channels_with_fastfading.copy(),
+              'init_v2i': env.V2I_channels_with_fastfading.copy()}
+        pos, dirs, v2v, v2i, acts, r_v2v, r_v2i, intf, v2v_int_all = [], [], [], [], [], [], [], [], []
+        for t in range(steps):
+            a = np.random.randint(0, env.n_RB, size=(n_veh, 1))
+            acts.append(a.copy())
+            V2V_Rate, V2I_Rate, Interference = env.compute_reward_with_channel_selection(a.copy())
+            r_v2v.append(V2V_Rate.copy()); r_v2i.append(V2I_Rate.copy()); intf.append(Interference.copy())
+            env.renew_positions()
+            env.renew_channels_fastfading()
+            env.Compute_Interference(a.copy())
+            pos.append(np.array([v.position for v in env.vehicles], float))
+            dirs.append(np.array([v.direction for v in env.vehicles]))
+            v2v.append(env.V2V_channels_with_fastfading.copy())
+            v2i.append(env.V2I_channels_with_fastfading.copy())
+            v2v_int_all.append(env.V2V_Interference_all.copy())
+        tr.update(pos=np.stack(pos), dirs=np.stack(dirs), v2v=np.stack(v2v), v2i=np.stack(v2i), actions=np.stack(acts),
+                  v2v_rate=np.stack(r_v2v), v2i_rate=np.stack(r_v2i), interference=np.stack(intf),
+                  v2v_interference_all=np.stack(v2v_int_all))
+        np.savez_compressed(os.path.join(OUT, 'golden_env_n%d.npz' % n_veh), **tr)
+
+    # ---- (4) mobility at crossings and exits: vehicles are re-placed just before a crossing lane / the map
+    #          border (seeded), then the reference renew_positions runs; pins the turn logic and its RNG use
+    random.seed(77)
+    env = make_env(Environment)
+    pr = np.random.RandomState(9)
+    rounds, per = 60, 3
+    place_pos, place_dir, out_pos, out_dir = [], [], [], []
+    for rd in range(rounds):
+        pp, pd = [], []
+        for v in env.vehicles:
+            d = ['u', 'd', 'l', 'r'][pr.randint(4)]
+            if pr.uniform() < 0.25:                     # near the border: exercises the exit handling
+                if d == 'u': pos = [env.up_lanes[pr.randint(6)], env.height - 0.05]
+                elif d == 'd': pos = [env.down_lanes[pr.randint(6)], 0.05]
+                elif d == 'l': pos = [0.05, env.left_lanes[pr.randint(6)]]
+                else: pos = [env.width - 0.05, env.right_lanes[pr.randint(6)]]
+            else:                                        # just before a crossing lane
+                if d in ('u', 'd'):
+                    lanes = env.left_lanes + env.right_lanes
+                    y = lanes[pr.randint(len(lanes))] + (-0.06 if d == 'u' else 0.06)
+                    pos = [(env.up_lanes if d == 'u' else env.down_lanes)[pr.randint(6)], y]
+                else:
+                    lanes = env.up_lanes + env.down_lanes
+                    x = lanes[pr.randint(len(lanes))] + (0.06 if d == 'l' else -0.06)
+                    pos = [x, (env.left_lanes if d == 'l' else env.right_lanes)[pr.randint(6)]]
+            v.position, v.direction = list(pos), d
+            pp.append(list(pos)); pd.append(d)
+        place_pos.append(pp); place_dir.append(pd)
+        for _ in range(per):
+            env.renew_positions()
+            out_pos.append([list(v.position) for v in env.vehicles])
+            out_dir.append([v.direction for v in env.vehicles])
+    np.savez_compressed(os.path.join(OUT, 'golden_env_cross.npz'), velocity=np.array([v.velocity for v in env.vehicles], float),
+                        place_pos=np.array(place_pos, float), place_dir=np.array(place_dir), per=per,
+                        out_pos=np.array(out_pos, float), out_dir=np.array(out_dir))
     print('wrote', sorted(os.listdir(OUT)))
     print('weights per model:', per_model)
 

@@ -1,0 +1,76 @@
+"""GPU: the reference's training loop (config 1: 4 links, F=16) end to end on the engine -- simulator -> agent ->
+BS -> C-ABI -> kernels -- and the compact agent path against the dict path and the oracle."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from util import assert_fwd_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed, batch=64, n_veh=4, feat=16):
+    from v2xgnn.rl import Agent, RL_Config
+    from test_rl_env import make_env
+    random.seed(seed)
+    np.random.seed(seed)
+    cfg = RL_Config()
+    cfg.set_train_value(feat, 0.5, batch, 1, 0.1)
+    env = make_env()
+    if n_veh != env.n_Veh:
+        env.new_random_game(n_veh)
+    agent = Agent(n_veh, env.n_RB, env.n_Neighbor, feat, env, cfg, seed=seed)
+    return agent, env, cfg
+
+
+def test_training_loop_runs_and_learns_signal(tmp_path):
+    agent, env, cfg = _setup(11)
+    w0 = [w.copy() for w in agent.brain.model.get_weights()]
+    loss, reward_step, reward_ep, q_mean, q_max, _, _ = agent.train(2, 5, save_dir=str(tmp_path), save_interval=2)
+    assert loss.shape == (4, 2, 5) and np.all(np.isfinite(loss)) and np.all(loss >= 0)
+    assert reward_step.shape == (2, 5, 50) and np.all(np.isfinite(reward_step))
+    assert agent.num_step == 2 * 5 * 50 and len(agent.memory.samples) == 500
+    assert np.all(q_max >= q_mean)
+    w1 = agent.brain.model.get_weights()
+    assert any(not np.array_equal(a, b) for a, b in zip(w0, w1))
+    # num_step hit 500 on the last replay -> target network synced (BS_brain.py:847-848)
+    for a, b in zip(w1, agent.brain.target_model.get_weights()):
+        assert np.array_equal(a, b)
+    tag = '-Episode-2-Step-5-Batch-64.h5'
+    assert os.path.exists(os.path.join(str(tmp_path), 'Q-Network_model_weights' + tag))
+    assert os.path.exists(os.path.join(str(tmp_path), 'Target-Network_model_weights' + tag))
+    rl, rnd = agent.test_run(1, 5)
+    assert rl.shape == rnd.shape == (1, 5) and np.all(np.isfinite(rl))
+
+
+def test_compact_path_equals_dict_path_and_oracle():
+    from oracle import compact
+    from oracle.spec import GnnSpec as OSpec
+    from v2xgnn.packing import PackedBatch
+    agent, env, cfg = _setup(12)
+    agent.generate_d2d_transition(40)
+    batch = agent.memory.sample(32)
+    s = np.stack([b[0][0] for b in batch])
+    states, adj = s[:, :52].reshape(32, 4, 13), s[:, 52:].reshape(32, 4, 4)
+    q_compact = agent._predict(states, adj)                                           # [N, B, C]
+    q_dict = np.stack(agent.brain.predict(agent._feed(states, adj)))
+    assert np.array_equal(q_compact, q_dict)
+    spec = OSpec(n_nodes=4, n_channels=4, feat_dim=16, n_mp_layers=2)
+    params = compact.params_from_list(spec, agent.brain.model.get_weights())
+    pb = PackedBatch.from_dense(states[:, :, :9], states[:, :, 9:], adj)
+    graph = ((np.arange(33) * 4).astype(np.int32), pb.row_ptr, pb.col_idx)
+    om = compact.OracleModel(spec, params, dtype=np.float64)
+    q_ref = om.predict(states[:, :, :9].reshape(128, 9), states[:, :, 9:].reshape(128, 4), graph)
+    assert_fwd_close(np.transpose(q_compact, (1, 0, 2)).reshape(-1, 4), q_ref)
+
+def test_twenty_link_agent_step():
+    """The same loop at the headline topology size (20 links, F=64): one replay step."""
+    agent, env, cfg = _setup(13, batch=128, n_veh=20, feat=64)
+    agent.num_Episodes, agent.num_Train_Step = 1, 1
+    r = agent.generate_d2d_transition(10)
+    assert np.all(np.isfinite(r))
+    result, q_mean, q_max, _, _ = agent.replay()
+    assert len(q_mean) == 20
+    assert all(np.isfinite(result.history['D%d_Decide_Output_loss' % (k + 1)][0]) for k in range(20))

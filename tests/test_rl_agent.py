@@ -1,0 +1,115 @@
+"""CPU: the DQN agent glue (v2xgnn.rl.Agent / Memory) against the replay memory and the exact fit payload the
+reference Agent produced on the reference simulator with a recording fake brain (tests/golden/make_golden.py,
+section 1).  The fake brain here draws its "Q values" from the same private RandomState(77) stream."""
+import os
+import random
+import types
+
+import numpy as np
+
+from v2xgnn.rl import Agent, Memory, RL_Config
+from test_rl_env import make_env
+from util import GOLDEN
+
+
+class RecordingBrain(object):
+    def __init__(self, num_d2d, input_node_info, input_edge_info, num_d2d_feedback, num_d2d_neighbor, num_ch):
+        self.num_D2D, self.num_Neighbor, self.num_CH = num_d2d, num_d2d_neighbor, num_ch
+        self.num_Feedback = num_d2d_feedback
+        self.num_One_Node_Input = ((input_node_info - 1) * num_ch + 1) * num_d2d_neighbor
+        self.num_One_Edge_Input = input_edge_info * num_ch
+        self.num_One_D2D_Input = self.num_One_Node_Input + self.num_One_Edge_Input
+        self.num_D2D_Input = num_d2d * self.num_One_D2D_Input + num_d2d ** 2
+        self.prng = np.random.RandomState(77)
+        self.predicts, self.fits = [], []
+
+    def predict(self, data, target=False):
+        B = data['D1_Node_Input'].shape[0]
+        out = [self.prng.normal(2.0, 1.0, size=(B, self.num_CH)).astype(np.float32) for _ in range(self.num_D2D)]
+        self.predicts.append(({k: v.copy() for k, v in data.items()}, bool(target), [o.copy() for o in out]))
+        return out
+
+    def train_dnn(self, x, y, batch_size):
+        self.fits.append((x, y, batch_size))
+        return types.SimpleNamespace(history={('D%d_Decide_Output_loss' % (k + 1)): [0.0] for k in range(self.num_D2D)})
+
+
+def _same(a, b):
+    return np.allclose(a, b, rtol=1e-10, atol=1e-10)
+
+
+def test_agent_reproduces_reference_memory_and_fit_payload():
+    g = np.load(os.path.join(GOLDEN, 'golden_agent_n4.npz'))
+    seed = int(g['seed'])
+    random.seed(seed)
+    np.random.seed(seed)
+    cfg = RL_Config()
+    cfg.set_train_value(16, float(g['gamma']), int(g['batch_size']), 1, 0.1)
+    env = make_env()
+    brain = RecordingBrain(env.n_Veh, 3, 1, cfg.Num_Feedback, env.n_Neighbor, env.n_RB)
+    agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, cfg.Num_Feedback, env, cfg, brain=brain)
+    agent.num_Episodes, agent.num_Train_Step, agent.num_transition = 10, 20, 50
+    assert np.array_equal([v.destinations[0] for v in env.vehicles], g['destinations'])
+    assert agent.num_States == 4 * 13 + 16 and agent.num_Actions == 4
+
+    init = agent.generate_d2d_initial_states()
+    for k in init:
+        assert init[k].shape == g['init/' + k].shape and _same(init[k], g['init/' + k]), k
+
+    agent.num_step = 10 ** 9
+    rewards = agent.generate_d2d_transition(24)
+    assert _same(rewards, g['rollout_rewards'])
+    mem = agent.memory.samples
+    assert len(mem) == 24
+    assert _same(np.stack([s[0][0] for s in mem]), g['mem_states'])
+    assert np.array_equal(np.stack([s[1][0] for s in mem]), g['mem_actions'])
+    assert _same(np.array([s[2] for s in mem]), g['mem_rewards'])
+    assert _same(np.stack([s[3][0] for s in mem]), g['mem_states_next'])
+
+    n_roll = len(brain.predicts)
+    _, q_mean, q_max_mean, _, _ = agent.replay()
+    (s, t0, p), (s_, t1, p_) = brain.predicts[n_roll:n_roll + 2]
+    assert (t0, t1) == (False, True)
+    for k in s:
+        assert _same(s[k], g['replay_s/' + k]), k
+        assert _same(s_[k], g['replay_s_next/' + k]), k
+    for i in range(4):
+        assert np.array_equal(p[i], g['replay_p/%d' % i]) and np.array_equal(p_[i], g['replay_p_next/%d' % i])
+    fit_x, fit_y, bs = brain.fits[0]
+    assert bs == int(g['batch_size'])
+    for k in fit_x:
+        assert fit_x[k].shape == g['fit_x/' + k].shape and _same(fit_x[k], g['fit_x/' + k]), k
+    for k in fit_y:
+        assert fit_y[k].dtype == g['fit_y/' + k].dtype
+        assert np.array_equal(fit_y[k], g['fit_y/' + k]), k              # same float32 -> float64 arithmetic: exact
+    assert np.array_equal(q_mean, g['q_mean']) and np.array_equal(q_max_mean, g['q_max_mean'])
+
+
+def test_memory_capacity_and_sampling_branches():
+    m = Memory(5)
+    for i in range(8):
+        m.add([i])
+    assert [s[0] for s in m.samples] == [3, 4, 5, 6, 7]
+    np.random.seed(0)
+    assert sorted(s[0] for s in m.sample(5)) == [3, 4, 5, 6, 7]          # without replacement
+    assert len(m.sample(9)) == 9                                         # with replacement
+    assert Memory(5).samples == []                                       # storage is per instance
+
+
+def test_epsilon_schedule_and_random_actions():
+    random.seed(3)
+    np.random.seed(3)
+    cfg = RL_Config()
+    env = make_env()
+    brain = RecordingBrain(env.n_Veh, 3, 1, 16, env.n_Neighbor, env.n_RB)
+    agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, 16, env, cfg, brain=brain)
+    agent.num_Episodes, agent.num_Train_Step, agent.num_transition = 2, 5, 50
+    state = agent.observe()
+    a = agent.select_action_while_training(state)
+    assert agent.epsilon == 1 and a.shape == (4, 1) and a.dtype.kind == 'i' and len(brain.predicts) == 0
+    agent.num_step = 200                                                  # half way through the 0.8 * 500 decay steps
+    agent.select_action_while_training(state)
+    assert abs(agent.epsilon - (1 - 0.99 * 0.5)) < 1e-12
+    agent.num_step = 400
+    agent.select_action_while_training(state)
+    assert agent.epsilon == 0.01

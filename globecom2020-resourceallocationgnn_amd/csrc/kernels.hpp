@@ -362,9 +362,9 @@ struct MlpArgs {
   int n_idx, row_stride, base_mul, idx_base;
 };
 
-template <int F>
+template <int F>    // F == 0: "tail" form without the Dense-0 image (wide features: Dense-0 runs in k_wide_gemm)
 struct MlpLds {
-  static constexpr int K1P = 2 * F + XE;
+  static constexpr int K1P = F > 0 ? 2 * F + XE : 0;
   static constexpr int W1 = 0;
   static constexpr int W2 = W1 + K1P * LD1;
   static constexpr int W3 = W2 + H1 * LD2;
@@ -388,12 +388,13 @@ __device__ __forceinline__ void mlp_fill_lds(float* smem, const MlpArgs& a, int 
   // Dense-0 rows [h(F) | x(2C+1) | agg(F)]: the image keeps xe's 16 columns; the edge-feature
   // and pad rows are ZERO so the packed xe block can be used as-is (BS_brain.py:175 feeds
   // only the node features to the decision DNN).
-  fill_weight_image<L::K1P, H1, LD1>(smem + L::W1, w1, RowPad{F + 2 * C + 1, XE - (2 * C + 1), k1}, H1);
+  if constexpr (F > 0)
+    fill_weight_image<L::K1P, H1, LD1>(smem + L::W1, w1, RowPad{F + 2 * C + 1, XE - (2 * C + 1), k1}, H1);
   fill_weight_image<H1, H2P, LD2>(smem + L::W2, w2, RowPad{H1, 0, H1}, H2);
   fill_weight_image<H2P, H3P, LD3>(smem + L::W3, w3, RowPad{H2, H2P - H2, H2}, H3);
   fill_weight_image<H3P, CP, LD4>(smem + L::W4, w4, RowPad{H3, H3P - H3, H3}, C);
   if (with_bias) {
-    fill_bias(smem + L::B1, H1, w1 + (int64_t)k1 * H1, H1);
+    if constexpr (F > 0) fill_bias(smem + L::B1, H1, w1 + (int64_t)k1 * H1, H1);
     fill_bias(smem + L::B2, H2P, w2 + H1 * H2, H2);
     fill_bias(smem + L::B3, H3P, w3 + H2 * H3, H3);
     fill_bias(smem + L::B4, CP, w4 + H3 * C, C);
@@ -467,7 +468,7 @@ __device__ __forceinline__ f32x4 gate4(f32x4 g, f32x4 z) {   // g * (z > 0)
 }
 
 template <int F>
-struct MlpFwdIn { f32x4 z0[2 * (F / 16) + 1]; int64_t row; };
+struct MlpFwdIn { f32x4 z0[F > 0 ? 2 * (F / 16) + 1 : 5]; int64_t row; };   // tail form: the 5 blocks of z1
 
 // Persistent: grid = (workgroups per slot, slots); the slot's 4 weight images are staged in LDS once.
 template <int F>
@@ -486,28 +487,38 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd(MlpArgs a) {
     const int idx = min(t * 16 + j, a.n_idx - 1);                 // clamped: always a valid row
     const int64_t row = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
     in.row = row;
+    if constexpr (F > 0) {
 #pragma unroll
-    for (int b = 0; b < FB; ++b) in.z0[b] = ld4(a.h + row * F + b * 16 + 4 * kg);
-    in.z0[FB] = ld4(a.xe + row * XE + 4 * kg);
+      for (int b = 0; b < FB; ++b) in.z0[b] = ld4(a.h + row * F + b * 16 + 4 * kg);
+      in.z0[FB] = ld4(a.xe + row * XE + 4 * kg);
 #pragma unroll
-    for (int b = 0; b < FB; ++b) in.z0[FB + 1 + b] = ld4(a.agg + row * F + b * 16 + 4 * kg);
+      for (int b = 0; b < FB; ++b) in.z0[FB + 1 + b] = ld4(a.agg + row * F + b * 16 + 4 * kg);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) in.z0[nt] = ld4(a.z1 + row * H1 + nt * 16 + 4 * kg);
+    }
   };
   auto compute = [&](int t, const MlpFwdIn<F>& in) {
     const bool valid = t * 16 + j < a.n_idx;
     const int64_t row = in.row;
     // ---- Dense 0: [2F+9] -> 80, relu
     f32x4 z1[1][5];
+    if constexpr (F > 0) {
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) z1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < 5; ++nt) z1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < KB1; ++kb) {
-      f32x4 blk[1] = {in.z0[kb]};
-      mfma_cols<1, 5>(smem + L::W1, LD1, kb, j, kg, blk, z1);
-    }
+      for (int kb = 0; kb < KB1; ++kb) {
+        f32x4 blk[1] = {in.z0[kb]};
+        mfma_cols<1, 5>(smem + L::W1, LD1, kb, j, kg, blk, z1);
+      }
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) {
-      z1[0][nt] = relu4(z1[0][nt] + ld4(smem + L::B1 + nt * 16 + 4 * kg));
-      if (valid) st4(a.z1 + row * H1 + nt * 16 + 4 * kg, z1[0][nt]);
+      for (int nt = 0; nt < 5; ++nt) {
+        z1[0][nt] = relu4(z1[0][nt] + ld4(smem + L::B1 + nt * 16 + 4 * kg));
+        if (valid) st4(a.z1 + row * H1 + nt * 16 + 4 * kg, z1[0][nt]);
+      }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 5; ++nt) z1[0][nt] = in.z0[nt];
     }
     // ---- Dense 1: 80 -> 40 (48 padded), relu
     f32x4 z2[1][3];
@@ -645,15 +656,17 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
       if (valid) st4(a.dz1 + row * H1 + nt * 16 + 4 * kg, d1[nt][0]);
     }
     // ---- Dense 0 backward (data): [dh | dagg] = dz1 . W1^T   (h rows and agg rows of the image)
-    const auto skip_xe = [](int nt) { return nt < FB ? nt * 16 : F + XE + (nt - FB) * 16; };
-    f32x4 o[2 * FB][1];
+    if constexpr (F > 0) {
+      const auto skip_xe = [](int nt) { return nt < FB ? nt * 16 : F + XE + (nt - FB) * 16; };
+      f32x4 o[2 * FB][1];
 #pragma unroll
-    for (int nt = 0; nt < 2 * FB; ++nt) o[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int nt = 0; nt < 2 * FB; ++nt) o[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < 5; ++kb) mfma_rows_multi<2 * FB>(smem + L::W1, LD1, skip_xe, kb, j, kg, d1[kb][0], o);
+      for (int kb = 0; kb < 5; ++kb) mfma_rows_multi<2 * FB>(smem + L::W1, LD1, skip_xe, kb, j, kg, d1[kb][0], o);
 #pragma unroll
-    for (int nt = 0; nt < 2 * FB; ++nt)
-      if (valid) st4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt][0]);
+      for (int nt = 0; nt < 2 * FB; ++nt)
+        if (valid) st4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt][0]);
+    }
   };
 
   MlpBwdIn<F> inA, inB;

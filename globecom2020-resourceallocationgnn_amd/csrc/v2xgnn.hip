@@ -3,6 +3,7 @@
 // kernels.hpp for Model.predict / Model.fit (BS_brain.py:218-235), optionally as a hipGraph.
 #include "../../include/v2xgnn.h"
 #include "kernels.hpp"
+#include "kernels_wide.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -59,7 +60,7 @@ struct v2x_model {
   hipStream_t side = nullptr;   // weight-gradient kernels run here, forked/joined around the data chain
   std::vector<hipEvent_t> ev;   // fork / per-stage / join events of the side stream
   float* loss_dev = nullptr;
-  float* zero_buf = nullptr;   // 256 B of zeros
+  float* zero_buf = nullptr;   // 4 KiB of zeros
   float* slab = nullptr; int slab_cap = 0;
   // staging for host-side inputs
   DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
@@ -179,7 +180,14 @@ void set_attrs(int F) {
   if (F == 16) set_attrs_f<16>();
   if (F == 32) set_attrs_f<32>();
   if (F == 64) set_attrs_f<64>();
+  if (F >= 128) {                     // wide path: tail MLP kernels + the narrow weight-gradient kernel for Dense 1..3
+    allow_big_lds((const void*)k_mlp_fwd<0>);
+    allow_big_lds((const void*)k_mlp_bwd<0>);
+    allow_big_lds((const void*)k_wgrad<64, true>);
+  }
 }
+
+inline bool is_wide(const v2x_model* m) { return m->F >= 128; }
 
 struct RowMapH { int n_idx, row_stride, base_mul, grid_y; };
 RowMapH row_map(const v2x_model* m, int n_rows) {
@@ -371,6 +379,74 @@ int persistent_wgs_per_slot(int n_idx, int n_slots, int wgs_per_cu) {
   return w;
 }
 
+
+// ---- wide-feature path (feat_dim >= 128): LDS-tiled GEMMs of kernels_wide.hpp -------------------------------
+void set_idx(WideGemmArgs& a, const IdxMap& x) {
+  a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.idx_base = x.idx_base;
+}
+
+int launch_wide_gemm(v2x_model* m, hipStream_t st, WideGemmArgs& a, int grid_z, bool trans, const char* name) {
+  const dim3 grid((a.n_idx + WD_TM - 1) / WD_TM, (a.n_out + WD_TN - 1) / WD_TN, grid_z);
+  if (trans) { auto k = k_wide_gemm<true>; LAUNCH(m, name, k, grid, 0, st, a); }
+  else { auto k = k_wide_gemm<false>; LAUNCH(m, name, k, grid, 0, st, a); }
+  return V2X_OK;
+}
+
+// out = act([seg...] W + b) of layer `ld`
+int wide_fwd(v2x_model* m, hipStream_t st, const LayerDesc& ld, const IdxMap& x, const WideSeg* segs, int n_seg,
+             float* out, int out_stride, int relu, const char* name) {
+  WideGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  int k = 0;
+  for (int i = 0; i < n_seg; ++i) { a.seg[i] = segs[i]; k += segs[i].width; }
+  a.n_seg = n_seg;
+  a.W = m->params + ld.off; a.slot_stride = ld.slot_stride; a.pad = ld.pad; a.n_real = ld.n_out;
+  a.k_total = k; a.n_out = ld.n_out; a.out = out; a.out_stride = out_stride; a.relu = relu; a.has_bias = 1;
+  set_idx(a, x);
+  return launch_wide_gemm(m, st, a, x.grid_y, false, name);
+}
+
+// gha[R][2F] = [dpre . W[h rows]^T | dpre . W[agg rows]^T];  `skip` = real weight rows between the two blocks
+int wide_dgrad(v2x_model* m, hipStream_t st, const LayerDesc& ld, const IdxMap& x, const float* dpre, int d_width,
+               int skip, float* gha, const char* name) {
+  WideGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.seg[0] = WideSeg{dpre, d_width, d_width}; a.n_seg = 1;
+  a.W = m->params + ld.off; a.slot_stride = ld.slot_stride; a.pad = ld.pad; a.n_real = ld.n_out;
+  a.k_total = d_width; a.n_out = 2 * m->F; a.split = m->F; a.skip = skip;
+  a.out = gha; a.out_stride = 2 * m->F;
+  set_idx(a, x);
+  return launch_wide_gemm(m, st, a, x.grid_y, true, name);
+}
+
+// row splits of a wide weight gradient: enough workgroups to fill the chip a few times over
+int wide_splits(int n_idx, int n_tiles, int n_slots) {
+  int sp = (4 * n_cus() + n_tiles * n_slots - 1) / (n_tiles * n_slots);
+  const int max_sp = (n_idx + 255) / 256;                      // at least 256 rows per split
+  if (sp > max_sp) sp = max_sp;
+  return sp < 1 ? 1 : sp;
+}
+
+int wide_wgrad(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, const WideSeg* segs, const int* seg_kpad,
+               int n_seg, const float* dpre, int d_stride, const char* name) {
+  WideWgradArgs a;
+  memset(&a, 0, sizeof(a));
+  int kt = 0;
+  for (int i = 0; i < n_seg; ++i) { a.seg[i] = segs[i]; a.seg_kpad[i] = seg_kpad[i]; kt += (segs[i].width + 63) / 64; }
+  a.n_seg = n_seg;
+  a.dpre = dpre; a.d_stride = d_stride; a.n_real = ld.n_out; a.pad = ld.pad;
+  a.slab = m->slab; a.slab_stride = m->P; a.layer_off = ld.off; a.slot_stride = ld.slot_stride;
+  a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.idx_base = x.idx_base;
+  const int nt = (ld.n_out + 63) / 64;
+  const int sp = wide_splits(x.n_idx, kt * nt, x.grid_y);
+  if (sp > m->slab_cap) FAIL(m, V2X_ESTATE, "wide wgrad: slabs not pre-sized (%d > %d)", sp, m->slab_cap);
+  a.n_split = sp;
+  a.rows_per_split = ((x.n_idx + sp - 1) / sp + WW_TR - 1) / WW_TR * WW_TR;
+  ld.n_slabs = sp;
+  LAUNCH(m, name, k_wide_wgrad, dim3(kt, nt, x.grid_y * sp), 0, st, a);
+  return V2X_OK;
+}
+
 void set_idx(GemmArgs& a, const IdxMap& x) {
   a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.idx_base = x.idx_base;
 }
@@ -407,6 +483,14 @@ int launch_node_fwd(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, co
   a.out = out; a.out_stride = m->F; a.relu = stage < m->L ? 1 : 0;
   set_idx(a, x);
   if (stage > 0 && (!h_prev || !agg_prev)) FAIL(m, V2X_EINVAL, "node_update: stage>0 needs h_prev and agg_prev");
+  if (is_wide(m)) {
+    const int F = m->F;
+    WideSeg s[3];
+    int n = 0;
+    if (stage > 0) { s[n++] = WideSeg{h_prev, F, F}; s[n++] = WideSeg{xe, XE, XE}; s[n++] = WideSeg{agg_prev, F, F}; }
+    else { s[n++] = WideSeg{xe, XE, XE}; if (agg_prev) s[n++] = WideSeg{agg_prev, F, F}; }
+    return wide_fwd(m, st, ld, x, s, n, out, F, a.relu, stage ? "k_node_fwd" : "k_node_fwd_embed");
+  }
   switch (m->F) {
     case 16: return launch_node_fwd_f<16>(m, st, stage, a, x.grid_y);
     case 32: return launch_node_fwd_f<32>(m, st, stage, a, x.grid_y);
@@ -423,6 +507,7 @@ int launch_dgrad(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const
   a.W = m->params + ld.off; a.slot_stride = ld.slot_stride; a.pad = ld.pad;
   a.out = gha; a.out_stride = 2 * m->F; a.relu = 0;
   set_idx(a, x);
+  if (is_wide(m)) return wide_dgrad(m, st, ld, x, dpre, m->F, m->Dn + m->De, gha, "k_node_dgrad");
   switch (m->F) {
     case 16: return launch_gemm_t<16, true, false, true>(m, st, a, x.grid_y, "k_node_dgrad");
     case 32: return launch_gemm_t<32, true, false, true>(m, st, a, x.grid_y, "k_node_dgrad");
@@ -453,6 +538,19 @@ int launch_mlp_f(v2x_model* m, hipStream_t st, MlpArgs& a, int grid_y, bool bwd)
 
 int launch_mlp(v2x_model* m, hipStream_t st, MlpArgs& a, bool bwd) {
   const int gy = m->S == 1 ? 1 : m->N;
+  if (is_wide(m)) {
+    // Dense-0 and its data gradient are wide GEMMs; Dense 1..3 (+ Huber) stay register-chained ("tail" form)
+    IdxMap x;
+    x.idx_base = a.idx_base; x.n_idx = a.n_idx; x.row_stride = a.row_stride; x.base_mul = a.base_mul; x.grid_y = gy;
+    const int F = m->F;
+    if (!bwd) {
+      WideSeg s[3] = {WideSeg{a.h, F, F}, WideSeg{a.xe, XE, XE}, WideSeg{a.agg, F, F}};
+      CHK(wide_fwd(m, st, m->dense[0], x, s, 3, m->z1, H1, 1, "k_dense0_fwd"));
+      return launch_mlp_f<0>(m, st, a, gy, false);
+    }
+    CHK(launch_mlp_f<0>(m, st, a, gy, true));
+    return wide_dgrad(m, st, m->dense[0], x, m->dz1, H1, m->Dn, m->gha, "k_dense0_dgrad");
+  }
   switch (m->F) {
     case 16: return launch_mlp_f<16>(m, st, a, gy, bwd);
     case 32: return launch_mlp_f<32>(m, st, a, gy, bwd);
@@ -501,6 +599,11 @@ int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti
   }
   V2X_WG_CASE(16) V2X_WG_CASE(32) V2X_WG_CASE(64)
 #undef V2X_WG_CASE
+  if (is_wide(m) && dense) {            // Dense 1..3 only (their operand widths do not depend on F)
+    auto k = k_wgrad<64, true>;
+    LAUNCH(m, name, k, grid, lds, st, mu);
+    return V2X_OK;
+  }
   FAIL(m, V2X_EINVAL, "wgrad: %d output tiles unsupported", maxt);
 }
 
@@ -514,9 +617,27 @@ int wgrad_gnn_role(v2x_model* m, int stage, const IdxMap& x, int total_work, con
   return wgrad_role(m, m->gnn[stage], stage ? WG_KIND_GNN : WG_KIND_EMBED, x, total_work, s, n, dpre, F, a);
 }
 
+int wide_wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const float* xe, const float* h_prev,
+                   const float* agg_prev, const float* dpre) {
+  const int F = m->F;
+  WideSeg s[3];
+  int kp[3], n = 0;
+  if (stage > 0) {
+    s[n] = WideSeg{h_prev, F, F}; kp[n++] = 0;
+    s[n] = WideSeg{xe, XE, XE}; kp[n++] = F;
+    s[n] = WideSeg{agg_prev, F, F}; kp[n++] = F + XE;
+  } else {
+    s[n] = WideSeg{xe, XE, XE}; kp[n++] = 0;
+    // neighbour-init absent (the reference always feeds zeros): its weight rows get an exact zero gradient
+    s[n] = WideSeg{agg_prev ? agg_prev : m->zero_buf, agg_prev ? F : 0, F}; kp[n++] = XE;
+  }
+  return wide_wgrad(m, st, m->gnn[stage], x, s, kp, n, dpre, F, stage ? "k_wgrad_gnn" : "k_wgrad_embed");
+}
+
 // one GNN stage on its own (per-kernel entry point)
 int wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const float* xe, const float* h_prev,
               const float* agg_prev, const float* dpre) {
+  if (is_wide(m)) return wide_wgrad_gnn(m, st, stage, x, xe, h_prev, agg_prev, dpre);
   WgradMulti mu;
   memset(&mu, 0, sizeof(mu));
   CHK(wgrad_gnn_role(m, stage, x, layer_work(m->gnn[stage]), xe, h_prev, agg_prev, dpre, mu.w[0]));
@@ -525,6 +646,11 @@ int wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const fl
 
 // all GNN stages (needs dpre[0..L]) in ceil((L+1)/4) launches
 int wgrad_gnn_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch& d) {
+  if (is_wide(m)) {
+    for (int s = m->L; s >= 0; --s)
+      CHK(wide_wgrad_gnn(m, st, s, x, d.xe, s ? m->h[s - 1] : nullptr, s ? m->a[s - 1] : d.nbr, m->dpre[s]));
+    return V2X_OK;
+  }
   WgradMulti mu;
   int n = 0, s_first = m->L;
   for (int s = m->L; s >= 0; --s) {
@@ -544,6 +670,18 @@ int wgrad_mlp(v2x_model* m, hipStream_t st, const IdxMap& x, const float* xe, co
   for (int i = 0; i < 4; ++i) total += layer_work(m->dense[i]);
   WgradMulti mu;
   memset(&mu, 0, sizeof(mu));
+  if (is_wide(m)) {
+    WideSeg w0[3] = {WideSeg{h, F, F}, WideSeg{xe, XE, XE}, WideSeg{agg, F, F}};
+    const int kp[3] = {0, F, F + XE};
+    CHK(wide_wgrad(m, st, m->dense[0], x, w0, kp, 3, m->dz1, H1, "k_wgrad_dense0"));
+    WgSeg t1[1] = {WgSeg{m->z1, H1, H1, 0}};
+    CHK(wgrad_role(m, m->dense[1], WG_KIND_DENSE1, x, total, t1, 1, m->dz2, H2, mu.w[0]));
+    WgSeg t2[1] = {WgSeg{m->z2, H2, H2, 0}};
+    CHK(wgrad_role(m, m->dense[2], WG_KIND_DENSE2, x, total, t2, 1, m->dz3, H3, mu.w[1]));
+    WgSeg t3[1] = {WgSeg{m->z3, H3, H3, 0}};
+    CHK(wgrad_role(m, m->dense[3], WG_KIND_DENSE3, x, total, t3, 1, m->dq, m->C, mu.w[2]));
+    return launch_wgrad_multi(m, st, x, mu, 3, "k_wgrad_dense");
+  }
   WgSeg s0[3] = {WgSeg{h, F, F, 0}, WgSeg{xe, XE, XE, F}, WgSeg{agg, F, F, F + XE}};
   CHK(wgrad_role(m, m->dense[0], WG_KIND_DENSE0, x, total, s0, 3, m->dz1, H1, mu.w[0]));
   WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0}};
@@ -733,6 +871,7 @@ GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
 int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   int chunk, nc = 1;
   for (int rows : {768, 1024}) nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
+  if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 2, n_slots));     // the fewest tiles (embed layer) split most
   return nc + 1;
 }
 
@@ -772,8 +911,8 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   if (!cfg || !out) FAIL(nullm, V2X_EINVAL, "v2x_create: null argument");
   *out = nullptr;
   if (cfg->n_channels != 4) FAIL(nullm, V2X_EINVAL, "n_channels must be 4 in this build (got %d)", cfg->n_channels);
-  if (cfg->feat_dim != 16 && cfg->feat_dim != 32 && cfg->feat_dim != 64)
-    FAIL(nullm, V2X_EINVAL, "feat_dim must be 16, 32 or 64 in this build (got %d)", cfg->feat_dim);
+  if (cfg->feat_dim != 16 && cfg->feat_dim != 32 && cfg->feat_dim != 64 && cfg->feat_dim != 128 && cfg->feat_dim != 256)
+    FAIL(nullm, V2X_EINVAL, "feat_dim must be 16, 32, 64, 128 or 256 in this build (got %d)", cfg->feat_dim);
   if (cfg->n_nodes < 1) FAIL(nullm, V2X_EINVAL, "n_nodes must be >= 1");
   if (cfg->n_mp_layers < 1 || cfg->n_mp_layers > 8) FAIL(nullm, V2X_EINVAL, "n_mp_layers must be in [1,8]");
   if (cfg->variable_graphs && !cfg->share_weights)
@@ -805,9 +944,9 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   };
   const size_t pb = (size_t)m->P * sizeof(float);
   if (dev_alloc(m, &m->params, m->P) || dev_alloc(m, &m->grads, m->P) || dev_alloc(m, &m->mom, m->P) ||
-      dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1) || dev_alloc(m, &m->zero_buf, 64))
+      dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1) || dev_alloc(m, &m->zero_buf, 1024))
     return fail("allocation");
-  if (hipMemset(m->zero_buf, 0, 256) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
+  if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
   if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return fail("side stream");
   m->ev.resize(m->L + 4);

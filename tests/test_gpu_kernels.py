@@ -115,6 +115,10 @@ CASES = [  # N, F, L, shared, B
     (20, 64, 2, True, 70),
     (6, 32, 3, False, 130),
     (20, 64, 2, False, 4096 // 16),
+    # wide-feature path (feat_dim >= 128, kernels_wide.hpp)
+    (5, 128, 2, False, 140),
+    (12, 256, 3, True, 150),
+    (100, 256, 3, False, 6),      # BASELINE config 4 shape: 100 links, feat_dim 256, 3 layers
 ]
 
 

@@ -243,4 +243,138 @@ __global__ __launch_bounds__(256) void k_wide_wgrad(WideWgradArgs a) {
   if (do_bias && n0 + tid < a.n_real) dst[(int64_t)a.pad.k_real * a.n_real + n0 + tid] = bsum;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// k_agg_dense : AggLayer.call (BS_brain.py:69-76) for LARGE, DENSE graphs (e.g. 100 links, in-degree 98).
+//
+// The gather form (k_agg) issues one 16-byte LDS read per edge and lane: at in-degree 98 it is LDS-bandwidth
+// bound (measured 360 us per launch at 1024 x 100 x 256, 1.06 TB/s of HBM).  Here the graph's feature tile
+// is still staged in LDS once (same HBM traffic), but the contraction out[q] = sum_p Adj[p][q] h[p] runs on
+// the fp32 MFMA pipe with the adjacency held as per-source BIT masks (N x ceil(N/32) words, built from the
+// CSR with integer atomics) and expanded to 0.0/1.0 B-operand values on the fly:
+//   A[i = feature][k = p] = h[p][f0+i]   (LDS, consecutive lanes -> consecutive banks)
+//   B[k = p][j = q]       = Adj[p][q]    (bit q of mask[p];   transposed:  B[k = q][j = p] = bit q of mask[p])
+//   D[i][j]: lane holds out[row j][4 consecutive features] -> float4 epilogue (+add, ReLU' gate) and store.
+// 0/1 times h is exact, so the only difference to the gather form is the fp32 summation order.
+struct AggDenseArgs {
+  const float* src; int src_stride;
+  const float* add; int add_stride;
+  const float* mask;                    // optional [R][F] ReLU' gate
+  float* out;
+  const int32_t* graph_off; const int32_t* row_ptr; const int32_t* col_idx;
+  unsigned* adj;                        // [R][mask_words]: bit q of adj[p] = edge p -> q (graph-local q), built by k_adj_masks
+  int g_base, n_graphs, n_nodes, F;
+  int n_fg;                             // 64-wide feature groups per graph (one workgroup each)
+  int rows_cap, mask_words;             // rows_cap: max nodes rounded up to 16
+};
+
+// CSR-by-destination -> per-source bit masks, one workgroup per graph (integer atomics in LDS: order-independent).
+// Runs ONCE per batch; the 2(L+1) aggregations of a training step then read 4*ceil(N/32) bytes per node instead
+// of 4 bytes per edge.
+__global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned* sM = reinterpret_cast<unsigned*>(smem);                         // [rows_cap][mask_words]
+  const int tid = threadIdx.x;
+  const int g = a.g_base + blockIdx.x;
+  const int r_begin = a.graph_off ? a.graph_off[g] : g * a.n_nodes;
+  const int n = (a.graph_off ? a.graph_off[g + 1] : r_begin + a.n_nodes) - r_begin;
+  for (int i = tid; i < n * a.mask_words; i += 256) sM[i] = 0u;
+  __syncthreads();
+  for (int i = tid; i < n * 32; i += 256) {                                 // 32 threads per destination row
+    const int q = i >> 5, sl = i & 31;
+    const int e0 = a.row_ptr[r_begin + q] + sl, e1 = a.row_ptr[r_begin + q + 1];
+    int p[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] = e0 + 32 * u < e1 ? a.col_idx[e0 + 32 * u] : -1;   // 4 loads in flight
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (p[u] >= 0) atomicOr(&sM[p[u] * a.mask_words + (q >> 5)], 1u << (q & 31));
+    for (int e = e0 + 128; e < e1; e += 32) atomicOr(&sM[a.col_idx[e] * a.mask_words + (q >> 5)], 1u << (q & 31));
+  }
+  __syncthreads();
+  for (int i = tid; i < n * a.mask_words; i += 256) a.adj[(int64_t)r_begin * a.mask_words + i] = sM[i];
+}
+
+constexpr int AD_LDT = 64 + 16;         // LDS row stride of the feature tile: the 4 k-groups of a wave hit disjoint banks
+
+// grid = n_graphs * n_fg workgroups.  Workgroup ids are dealt round-robin to the 8 XCDs, so the n_fg feature
+// groups of one graph are given ids with the SAME id mod 8: they run on one XCD and share its L2.
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void k_agg_dense(AggDenseArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sT = smem;                                                         // [rows_cap][AD_LDT]
+  unsigned* sM = reinterpret_cast<unsigned*>(sT + a.rows_cap * AD_LDT);     // [rows_cap][mask_words]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, kg = lane >> 4;
+  const int b = blockIdx.x, span = 8 * a.n_fg;
+  const int gl = (b / span) * 8 + (b & 7), fg = (b % span) >> 3;
+  if (gl >= a.n_graphs) return;
+  const int g = a.g_base + gl, f0 = fg << 6;
+  const int r_begin = a.graph_off ? a.graph_off[g] : g * a.n_nodes;
+  const int n = (a.graph_off ? a.graph_off[g + 1] : r_begin + a.n_nodes) - r_begin;
+
+  // stage the graph's [n][64] feature slice (4 loads in flight per thread) and its adjacency bit masks
+  const int n_mw = n * a.mask_words;
+  for (int i = tid; i < a.rows_cap * a.mask_words; i += 256) sM[i] = i < n_mw ? a.adj[(int64_t)r_begin * a.mask_words + i] : 0u;
+  for (int i0 = 0; i0 < n * 16; i0 += 1024) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + u * 256 + tid, n * 16 - 1);
+      v[u] = *reinterpret_cast<const float4*>(a.src + (int64_t)(r_begin + (i >> 4)) * a.src_stride + f0 + ((i & 15) << 2));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * 256 + tid;
+      if (i < n * 16) *reinterpret_cast<float4*>(sT + (i >> 4) * AD_LDT + ((i & 15) << 2)) = v[u];
+    }
+  }
+  __syncthreads();
+
+  const int n_rt = (n + 15) >> 4;
+  const int n_k4 = (n + 15) >> 4;                                           // groups of 4 k-steps (16 contraction rows)
+  for (int rt = wv; rt < n_rt; rt += 4) {
+    const int row = rt * 16 + j;                                            // this lane's OUTPUT row (dest q / source p)
+    f32x4 acc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // epilogue operands first (HBM latency hidden behind the MFMA loop)
+    const bool valid = row < n;
+    const int64_t grow = r_begin + (valid ? row : 0);
+    f32x4 addv[4], gate[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      addv[nt] = a.add ? ld4(a.add + grow * a.add_stride + f0 + nt * 16 + 4 * kg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      gate[nt] = a.mask ? ld4(a.mask + grow * a.F + f0 + nt * 16 + 4 * kg) : (f32x4){1.f, 1.f, 1.f, 1.f};
+    }
+#pragma unroll 1
+    for (int k4 = 0; k4 < n_k4; ++k4) {
+      float bv[4], av[4][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {                                         // all LDS reads of 4 k-steps, then 16 MFMAs
+        const int kk = k4 * 16 + s * 4 + kg;                                // contraction index of this lane (< rows_cap)
+        const int kc = min(kk, n - 1);                                      // clamped: finite value x 0.0
+        unsigned w;
+        if (!TRANSPOSE) w = sM[kk * a.mask_words + (row >> 5)] >> (row & 31);   // Adj[p = kk][q = row]
+        else w = sM[row * a.mask_words + (kk >> 5)] >> (kk & 31);               // Adj[p = row][q = kk]
+        bv[s] = (float)(w & 1u);
+        const float* tp = sT + kc * AD_LDT + j;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) av[s][nt] = tp[nt * 16];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = V2X_MFMA(av[s][nt], bv[s], acc[nt]);
+    }
+    if (valid) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        f32x4 v = acc[nt] + addv[nt];
+        v = gate4(v, gate[nt]);
+        st4(a.out + grow * a.F + f0 + nt * 16 + 4 * kg, v);
+      }
+    }
+  }
+}
+
 }  // namespace v2x

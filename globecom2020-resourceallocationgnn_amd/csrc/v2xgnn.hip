@@ -64,6 +64,7 @@ struct v2x_model {
   float* slab = nullptr; int slab_cap = 0;
   // staging for host-side inputs
   DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
+  DevBuf adj_mask;              // adjacency bit masks of the current batch (dense-graph aggregation)
   bool have_fwd = false;
   std::string err;
   // profiling
@@ -177,6 +178,8 @@ void set_attrs_f() {
 void set_attrs(int F) {
   allow_big_lds((const void*)k_agg<false>);
   allow_big_lds((const void*)k_agg<true>);
+  allow_big_lds((const void*)k_agg_dense<false>);
+  allow_big_lds((const void*)k_agg_dense<true>);
   if (F == 16) set_attrs_f<16>();
   if (F == 32) set_attrs_f<32>();
   if (F == 64) set_attrs_f<64>();
@@ -336,9 +339,63 @@ int n_cus() {
   return n;
 }
 
+// Large dense graphs (e.g. 100 links, in-degree 98): the contraction runs on the MFMA pipe against adjacency
+// bit masks (k_agg_dense) instead of one LDS gather per edge.
+bool use_dense_agg(const DevBatch& d, int F) {
+  static const int dense_min_nodes = env_int("V2X_AGG_DENSE_MIN_NODES", 32);
+  const size_t rows_cap = (d.max_nodes + 15) / 16 * 16, mw = (d.max_nodes + 31) / 32;
+  return F >= 64 && d.max_nodes >= dense_min_nodes && (int64_t)d.max_edges * 4 >= (int64_t)d.max_nodes * d.max_nodes &&
+         rows_cap * AD_LDT * 4 + rows_cap * mw * 4 <= 160 * 1024;
+}
+
+AggDenseArgs agg_dense_args(const DevBatch& d, Range r, int N, int F) {
+  AggDenseArgs q;
+  memset(&q, 0, sizeof(q));
+  q.graph_off = d.goff; q.row_ptr = d.rp; q.col_idx = d.ci;
+  q.g_base = r.g0; q.n_graphs = r.ng; q.n_nodes = N; q.F = F; q.n_fg = F / 64;
+  q.rows_cap = (d.max_nodes + 15) / 16 * 16;
+  q.mask_words = (d.max_nodes + 31) / 32;
+  return q;
+}
+
+int build_adj_masks(v2x_model* m, hipStream_t st, const AggDenseArgs& q) {
+  const size_t lds = (size_t)q.rows_cap * q.mask_words * 4;
+  LAUNCH(m, "k_adj_masks", k_adj_masks, dim3(q.n_graphs), lds, st, q);
+  return V2X_OK;
+}
+
 int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, int F, const float* src, int src_stride,
                const float* add, int add_stride, const float* mask, float* out, int transpose) {
   if (F < 16 || F > 256 || (F & (F - 1))) FAIL(m, V2X_EINVAL, "agg: feat_dim must be a power of two in [16,256]");
+  static const bool attrs_once = [] {        // the per-kernel entry points can get here without any model
+    allow_big_lds((const void*)k_agg<false>); allow_big_lds((const void*)k_agg<true>);
+    allow_big_lds((const void*)k_agg_dense<false>); allow_big_lds((const void*)k_agg_dense<true>);
+    return true;
+  }();
+  (void)attrs_once;
+  if (use_dense_agg(d, F)) {
+    AggDenseArgs q = agg_dense_args(d, r, N, F);
+    q.src = src; q.src_stride = src_stride; q.add = add; q.add_stride = add_stride; q.mask = mask; q.out = out;
+    if (m) {
+      q.adj = (unsigned*)m->adj_mask.p;                 // built by run_forward for this batch
+    } else {                                            // handle-less entry point: build into a scratch buffer
+      static thread_local DevBuf scratch;
+      const size_t need = (size_t)d.R * q.mask_words * 4;
+      if (need > scratch.cap) {
+        if (scratch.p) hipFree(scratch.p);
+        scratch.p = nullptr; scratch.cap = 0;
+        HIPCHK(m, hipMalloc(&scratch.p, need));
+        scratch.cap = need;
+      }
+      q.adj = (unsigned*)scratch.p;
+      CHK(build_adj_masks(m, st, q));
+    }
+    const size_t lds = (size_t)q.rows_cap * AD_LDT * 4 + (size_t)q.rows_cap * q.mask_words * 4;
+    const dim3 grid((r.ng + 7) / 8 * 8 * q.n_fg);
+    if (transpose) { auto k = k_agg_dense<true>; LAUNCH(m, "k_agg_bwd", k, grid, lds, st, q); }
+    else { auto k = k_agg_dense<false>; LAUNCH(m, "k_agg_fwd", k, grid, lds, st, q); }
+    return V2X_OK;
+  }
   AggArgs a;
   a.src = src; a.src_stride = src_stride; a.add = add; a.add_stride = add_stride; a.mask = mask; a.out = out;
   a.graph_off = d.goff; a.row_ptr = d.rp; a.col_idx = d.ci;
@@ -737,6 +794,11 @@ LossJob loss_job(const v2x_model* m, const DevBatch& d, int n_global) {
 int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r) {
   const int F = m->F, L = m->L;
   const IdxMap x = idx_map(m, d, r);
+  if (use_dense_agg(d, F)) {
+    AggDenseArgs q = agg_dense_args(d, r, m->N, F);
+    q.adj = (unsigned*)m->adj_mask.p;
+    CHK(build_adj_masks(m, st, q));
+  }
   CHK(launch_node_fwd(m, st, 0, x, d.xe, nullptr, d.nbr, m->h[0]));
   CHK(launch_agg(m, st, d, r, m->N, F, m->h[0], F, nullptr, 0, nullptr, m->a[0], 0));
   for (int s = 1; s <= L; ++s) {
@@ -877,6 +939,7 @@ int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
 
 int presize(v2x_model* m, const DevBatch& d) {
   CHK(ensure_rows(m, d.R));
+  if (use_dense_agg(d, m->F)) CHK(ensure(m, m->adj_mask, (size_t)d.R * ((d.max_nodes + 31) / 32) * 4));
   const IdxMap x = idx_map(m, d, Range{0, d.B});
   CHK(ensure_slabs(m, max_slabs(m, x.n_idx, x.grid_y)));
   return V2X_OK;
@@ -970,7 +1033,7 @@ void v2x_destroy(v2x_model* m) {
   for (float* p : ptrs) if (p) hipFree(p);
   for (float* p : m->h) if (p) hipFree(p);
   for (float* p : m->a) if (p) hipFree(p);
-  DevBuf* bufs[] = {&m->st_xe, &m->st_nbr, &m->st_goff, &m->st_rp, &m->st_ci, &m->st_y, &m->st_q};
+  DevBuf* bufs[] = {&m->st_xe, &m->st_nbr, &m->st_goff, &m->st_rp, &m->st_ci, &m->st_y, &m->st_q, &m->adj_mask};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   delete m;
 }

@@ -43,6 +43,38 @@ def synth_batch(rng, B, N, C=4):
     return x, e, adj, y
 
 
+def synth_ragged(rng, B, lo, hi, C=4):
+    """BASELINE config 5: N_g ~ U{lo..hi} links per graph, reference topology (in-degree N_g-2),
+    packed with CSR offsets."""
+    sizes = rng.integers(lo, hi + 1, size=B)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    R = int(offs[-1])
+    cols, deg = [], []
+    for n in sizes:
+        dest = rng.integers(0, n - 1, size=n)
+        dest = dest + (dest >= np.arange(n))
+        adj = ~np.eye(n, dtype=bool)
+        adj[dest, np.arange(n)] = False
+        p, q = np.nonzero(adj.T)                  # rows of adj.T = destinations, ascending sources inside
+        cols.append(q.astype(np.int32))
+        deg.append(adj.sum(axis=0))
+    row_ptr = np.concatenate([[0], np.cumsum(np.concatenate(deg))]).astype(np.int32)
+    x = np.concatenate([rng.normal(0.84, 0.39, size=(R, C)), rng.normal(0.60, 0.21, size=(R, C)),
+                        np.full((R, 1), 10.0)], axis=1).astype(np.float32)
+    e = rng.normal(0.88, 0.11, size=(R, C)).astype(np.float32)
+    y = rng.normal(2.5, 1.0, size=(R, C)).astype(np.float32)
+    return sizes, offs, row_ptr, np.concatenate(cols), x, e, y
+
+
+def algorithmic_flops(name, R, F, L, C=4, Dn=9, De=4):
+    """fp32 flops per launch of the dense kernels of the wide-feature path (SURVEY.md 8(d9) terms x rows)."""
+    gnn = 2 * R * (2 * F + Dn + De) * F
+    table = {"k_node_fwd": gnn, "k_wgrad_gnn": gnn, "k_node_dgrad": 2 * R * F * 2 * F,
+             "k_dense0_fwd": 2 * R * (2 * F + Dn) * 80, "k_wgrad_dense0": 2 * R * (2 * F + Dn) * 80,
+             "k_dense0_dgrad": 2 * R * 80 * 2 * F}
+    return table.get(name)
+
+
 def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     """Unique fp32/int32 bytes a kernel must move per launch (inputs read once + outputs written once;
     weights are cache-resident and not counted) -- the per-graph terms of SURVEY.md 8(d8) x B graphs.
@@ -70,7 +102,7 @@ def hbm_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled
     per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE); only valid for the default workload."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    default = (args.batch, args.nodes, args.feat, args.layers, args.share_weights) == (4096, 20, 64, 2, False)
+    default = (args.batch, args.nodes, args.feat, args.layers, args.share_weights, args.ragged) == (4096, 20, 64, 2, False, None)
     if not default or not os.path.exists(path):
         return None
     try:
@@ -130,7 +162,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5"], default="cfg2",
+                    help="BASELINE.json configs[1] (default, the metric's configuration), [3] (100 links x 256 features x "
+                         "3 layers, 8192/8 graphs per GPU) or [4] (8-128 links per graph, shared weights, 16384/8 per GPU)")
+    ap.add_argument("--ragged", type=int, nargs=2, metavar=("LO", "HI"), default=None,
+                    help="variable-size graphs with LO..HI links (needs --share-weights)")
     args = ap.parse_args()
+    if args.workload == "cfg4":
+        args.nodes, args.feat, args.layers, args.batch = 100, 256, 3, 1024
+    elif args.workload == "cfg5":
+        args.ragged, args.feat, args.layers, args.batch, args.share_weights = [8, 128], 64, 2, 2048, True
+    ragged = args.ragged is not None
+    if ragged and not args.share_weights:
+        raise SystemExit("--ragged needs --share-weights")
 
     import torch
     import v2xgnn
@@ -156,24 +200,39 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     N, F, L, B = args.nodes, args.feat, args.layers, args.batch
-    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=args.share_weights)
+    spec = GnnSpec(n_nodes=1 if ragged else N, feat_dim=F, n_mp_layers=L, share_weights=args.share_weights,
+                   variable_graphs=ragged)
     eng = GnnEngine(spec, device=local, use_graph=not args.no_graph)
     wrng = np.random.default_rng(1001)             # identical weights on every rank
     shapes = v2xgnn.keras_list_shapes(spec)
     eng.set_weights([np.zeros(s, np.float32) if len(s) == 1 else
                      wrng.uniform(-np.sqrt(6.0 / sum(s)), np.sqrt(6.0 / sum(s)), size=s).astype(np.float32) for s in shapes])
-    x, e, adj, y = synth_batch(np.random.default_rng(1001 + 7919 * rank), B, N)
-    pb = PackedBatch.from_dense(x, e, adj)
+    drng = np.random.default_rng(1001 + 7919 * rank)
+    if ragged:
+        sizes, offs, row_ptr, col_idx, x, e, y = synth_ragged(drng, B, args.ragged[0], args.ragged[1])
+        pb = PackedBatch(B, 0, v2xgnn.pack_xe(x, e), row_ptr, col_idx, int((sizes * (sizes - 2)).max()),
+                         graph_off=offs, max_nodes=int(sizes.max()))
+        n_rows_local = int(offs[-1])
+    else:
+        x, e, adj, y = synth_batch(drng, B, N)
+        pb = PackedBatch.from_dense(x, e, adj)
+        n_rows_local = B * N
     db = eng.to_device(pb)
     yd = torch.from_numpy(y).to(db.device)
-    n_global = B * world
+    n_global = B * world                          # graphs (the metric's unit)
+    n_denom = n_global                            # what the Huber mean divides by: graphs, or node rows when ragged
+    if ragged:
+        t = torch.tensor([n_rows_local], dtype=torch.int64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(t)
+        n_denom = int(t.item())
     trainer = DataParallelTrainer(eng, force=force_dp) if (world > 1 or force_dp) else None
 
     def one_step():
         if trainer is not None:
-            trainer.train_step(db, yd, n_graphs_global=n_global, want_loss=False)
+            trainer.train_step(db, yd, n_graphs_global=n_denom, want_loss=False)
         else:
-            eng.train_step(db, yd, n_global=n_global, want_loss=False)
+            eng.train_step(db, yd, n_global=n_denom, want_loss=False)
 
     stream = torch.cuda.Stream(device=local)
     with torch.cuda.stream(stream):
@@ -199,7 +258,7 @@ def main():
     value = n_global * args.steps / elapsed
 
     # sanity: the timed steps really trained (finite loss, weights moved)
-    loss = eng.forward_backward(db, yd, n_global=n_global)
+    loss = eng.forward_backward(db, yd, n_global=n_denom)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(loss).all()), "non-finite loss after the timed steps"
 
@@ -210,24 +269,38 @@ def main():
         eng.profile(True)
         with torch.cuda.stream(stream):
             for _ in range(min(args.steps, 50)):
-                eng.train_step(db, yd, n_global=n_global, want_loss=False)
+                eng.train_step(db, yd, n_global=n_denom, want_loss=False)
             torch.cuda.synchronize()
         prof = eng.profile_read()
         eng.profile(False)
         tot = sum(ms for _, ms in prof.values())
         kernels = {k: {"calls": c, "avg_us": round(1e3 * ms / c, 2), "share": round(ms / tot, 3)} for k, (c, ms) in
                    sorted(prof.items(), key=lambda kv: -kv[1][1])}
-        dom = max((k for k in prof if algorithmic_bytes(k, B, N, F, E, L) is not None), key=lambda k: prof[k][1])
-        calls, ms = prof[dom]
-        bytes_per_launch = algorithmic_bytes(dom, B, N, F, E, L)
-        achieved = bytes_per_launch / (1e-3 * ms / calls) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": hbm_traffic(dom, args),
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(1e3 * ms / calls, 2),
-                    "step_hbm_frac": round(step_bytes_per_graph(N, F, L, E // B) * (value / world) / 1e9 / HBM_PEAK_GBS, 4)}
+        Bq, Nq = (1, n_rows_local) if ragged else (B, N)       # the byte model only needs rows = Bq*Nq and E
+        step_bytes = (sum(step_bytes_per_graph(int(n), F, L, int(n) * (int(n) - 2)) for n in sizes) / B if ragged
+                      else step_bytes_per_graph(N, F, L, E // B))
+        if F >= 128:
+            # wide features: the dense contractions dominate and are fp32-MFMA bound
+            dom = max((k for k in prof if algorithmic_flops(k, n_rows_local, F, L) is not None), key=lambda k: prof[k][1])
+            calls, ms = prof[dom]
+            fl = algorithmic_flops(dom, n_rows_local, F, L)
+            achieved = fl / (1e-3 * ms / calls) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": FP32_MFMA_PEAK_TF,
+                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                        "algorithmic_flops_per_launch": int(fl), "avg_launch_us": round(1e3 * ms / calls, 2),
+                        "step_hbm_frac": round(step_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)}
+        else:
+            dom = max((k for k in prof if algorithmic_bytes(k, Bq, Nq, F, E, L) is not None), key=lambda k: prof[k][1])
+            calls, ms = prof[dom]
+            bytes_per_launch = algorithmic_bytes(dom, Bq, Nq, F, E, L)
+            achieved = bytes_per_launch / (1e-3 * ms / calls) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": hbm_traffic(dom, args),
+                        "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(1e3 * ms / calls, 2),
+                        "step_hbm_frac": round(step_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not ragged:
         cpu = cpu_baseline(N, F, L, args.share_weights, B, args.cpu_seconds)
 
     if rank == 0:
@@ -235,9 +308,11 @@ def main():
                "value": round(value, 1), "unit": "graph-instances/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "BASELINE.json configs[1]: %d V2V links, feat_dim=%d, %d-layer GNN, batch %d "
+               "config": {"workload": "BASELINE.json configs[%d]: %s V2V links, feat_dim=%d, %d-layer GNN, batch %d "
                                       "synthetic graphs per GPU, fit step = fwd+Huber+bwd+Adam%s"
-                                      % (N, F, L, B, "+RCCL grad all-reduce" if world > 1 else ""),
+                                      % ({"cfg2": 1, "cfg4": 3, "cfg5": 4}[args.workload],
+                                         "%d-%d" % tuple(args.ragged) if ragged else str(N), F, L, B,
+                                         "+RCCL grad all-reduce" if world > 1 else ""),
                           "weights": "shared" if args.share_weights else "per-node (reference semantics)",
                           "global_batch": n_global, "n_params": eng.n_params,
                           "launch": "eager" if args.no_graph else "hipGraph replay",

@@ -963,39 +963,81 @@ struct AdamArgs {
   // blocks [n_adam_blocks, gridDim.x) reduce the per-row Huber sums to per-output means
   int n_adam_blocks;
   const float* rowloss; float* loss; int loss_n_idx, loss_stride; float loss_scale;
+  int loss_split; float* loss_part; unsigned* loss_cnt;  // ranges per output (> 1 only with a single output)
+  int groups;                                            // threads per float4 column (1, 4 or 16): split of the slab sum
 };
 
 __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
   if ((int)blockIdx.x >= a.n_adam_blocks) {      // loss role (deterministic tree reduction)
     __shared__ float red[256];
-    const int slot = blockIdx.x - a.n_adam_blocks;
+    __shared__ int is_last;
+    const int lb = blockIdx.x - a.n_adam_blocks;
+    const int slot = lb / a.loss_split, part = lb - slot * a.loss_split;
+    const int per = (a.loss_n_idx + a.loss_split - 1) / a.loss_split;
+    const int i1 = min((part + 1) * per, a.loss_n_idx);
     float s = 0.f;
-    for (int i = threadIdx.x; i < a.loss_n_idx; i += 256) s += a.rowloss[(int64_t)i * a.loss_stride + slot];
+    for (int i = part * per + threadIdx.x; i < i1; i += 256) s += a.rowloss[(int64_t)i * a.loss_stride + slot];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
       if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
       __syncthreads();
     }
-    if (threadIdx.x == 0) a.loss[slot] = red[0] * a.loss_scale;
+    if (a.loss_split == 1) {
+      if (threadIdx.x == 0) a.loss[slot] = red[0] * a.loss_scale;
+      return;
+    }
+    // one long output (ragged batches: a single mean over all node rows) is cut into loss_split ranges; the LAST
+    // workgroup to finish adds the partials in range order (agent-scope atomics: partials cross XCD L2s)
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(a.loss_part + part, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned ticket = __hip_atomic_fetch_add(a.loss_cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      is_last = ticket == (unsigned)a.loss_split - 1;
+      if (is_last) {
+        float t = 0.f;
+        for (int k = 0; k < a.loss_split; ++k) t += __hip_atomic_load(a.loss_part + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.loss[slot] = t * a.loss_scale;
+        __hip_atomic_store(a.loss_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     return;
   }
-  for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < a.n4; i += (int64_t)a.n_adam_blocks * 256) {
-    float4 g;
+  // `groups` threads share one float4 column and split its slabs (few parameters + many slabs = shared weights at a
+  // large batch: without the split 37 workgroups would each walk ~180 slabs serially); partials are combined through
+  // LDS in a fixed order, so the result does not depend on scheduling.
+  __shared__ float4 part[256];
+  const int G = a.groups, cols = 256 / G;
+  const int col = threadIdx.x % cols, grp = threadIdx.x / cols;
+  for (int64_t base = (int64_t)blockIdx.x * cols; base < a.n4; base += (int64_t)a.n_adam_blocks * cols) {
+    const int64_t i = base + col;
+    const bool act = i < a.n4;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     if (a.slab) {
-      g = make_float4(0.f, 0.f, 0.f, 0.f);
-      int l = 0;
-      while (l + 1 < a.n_layers && i >= a.layer_end4[l]) ++l;
-      const int ns = a.layer_slabs[l];
-      for (int c = 0; c < ns; ++c) {
-        const float4 t = reinterpret_cast<const float4*>(a.slab + c * a.slab_stride)[i];
-        g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+      if (act) {
+        int l = 0;
+        while (l + 1 < a.n_layers && i >= a.layer_end4[l]) ++l;
+        const int ns = a.layer_slabs[l];
+        for (int c = grp; c < ns; c += G) {
+          const float4 t = reinterpret_cast<const float4*>(a.slab + c * a.slab_stride)[i];
+          g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+        }
       }
-      reinterpret_cast<float4*>(a.grad)[i] = g;
-    } else {
+      if (G > 1) {
+        part[threadIdx.x] = g;
+        __syncthreads();
+        if (grp == 0) {
+          for (int k = 1; k < G; ++k) {
+            const float4 t = part[k * cols + col];
+            g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
+          }
+        }
+        __syncthreads();
+      }
+      if (act && grp == 0) reinterpret_cast<float4*>(a.grad)[i] = g;
+    } else if (act && grp == 0) {
       g = reinterpret_cast<const float4*>(a.grad)[i];
     }
-    if (a.do_adam) {
+    if (a.do_adam && act && grp == 0) {
       float4 m = reinterpret_cast<float4*>(a.mom)[i], v = reinterpret_cast<float4*>(a.vel)[i];
       float4 p = reinterpret_cast<float4*>(a.param)[i];
       const float b1 = a.beta1, b2 = a.beta2, ob1 = 1.f - a.beta1, ob2 = 1.f - a.beta2;

@@ -60,6 +60,7 @@ struct v2x_model {
   hipStream_t side = nullptr;   // weight-gradient kernels run here, forked/joined around the data chain
   std::vector<hipEvent_t> ev;   // fork / per-stage / join events of the side stream
   float* loss_dev = nullptr;
+  float* loss_part = nullptr;  // 64 partial sums + the arrival counter of the split loss reduction
   float* zero_buf = nullptr;   // 4 KiB of zeros
   float* slab = nullptr; int slab_cap = 0;
   // staging for host-side inputs
@@ -775,12 +776,20 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
     a.lr_t = (float)(m->cfg.lr * std::sqrt(1.0 - std::pow((double)m->cfg.beta2, t)) / (1.0 - std::pow((double)m->cfg.beta1, t)));
     a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
   }
-  int blocks = (int)((a.n4 + 255) / 256);
+  int max_slabs_used = 0;
+  for (int l = 0; l < a.n_layers; ++l) max_slabs_used = std::max(max_slabs_used, a.layer_slabs[l]);
+  a.groups = 1;
+  if (a.slab && a.n4 < 256 * 1024 && max_slabs_used >= 16) a.groups = a.n4 < 64 * 1024 ? 16 : 4;
+  const int cols = 256 / a.groups;
+  int blocks = (int)((a.n4 + cols - 1) / cols);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   a.n_adam_blocks = blocks;
   a.rowloss = m->rowloss; a.loss = m->loss_dev; a.loss_n_idx = lj.n_idx; a.loss_stride = lj.stride; a.loss_scale = lj.scale;
-  LAUNCH(m, do_adam ? (n_slabs > 0 ? "k_reduce_adam" : "k_adam") : "k_grad_reduce", k_reduce_adam, dim3(blocks + lj.n_out), 0, st, a);
+  a.loss_split = (lj.n_out == 1 && lj.n_idx > 16384) ? 64 : 1;
+  a.loss_part = m->loss_part; a.loss_cnt = reinterpret_cast<unsigned*>(m->loss_part + 64);
+  LAUNCH(m, do_adam ? (n_slabs > 0 ? "k_reduce_adam" : "k_adam") : "k_grad_reduce", k_reduce_adam,
+         dim3(blocks + lj.n_out * a.loss_split), 0, st, a);
   return V2X_OK;
 }
 
@@ -1007,9 +1016,10 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   };
   const size_t pb = (size_t)m->P * sizeof(float);
   if (dev_alloc(m, &m->params, m->P) || dev_alloc(m, &m->grads, m->P) || dev_alloc(m, &m->mom, m->P) ||
-      dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1) || dev_alloc(m, &m->zero_buf, 1024))
+      dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1) || dev_alloc(m, &m->zero_buf, 1024) ||
+      dev_alloc(m, &m->loss_part, 128))
     return fail("allocation");
-  if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
+  if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->loss_part, 0, 512) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
   if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return fail("side stream");
   m->ev.resize(m->L + 4);
@@ -1026,7 +1036,7 @@ void v2x_destroy(v2x_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
   for (auto& r : m->prof_recs) { hipEventDestroy(r.ev0); hipEventDestroy(r.ev1); }
   float* ptrs[] = {m->params, m->grads, m->mom, m->vel, m->z1, m->z2, m->z3, m->q, m->dq, m->dz1, m->dz2, m->dz3,
-                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf};
+                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part};
   for (float* p : m->dpre) if (p) hipFree(p);
   for (auto& e : m->ev) if (e) hipEventDestroy(e);
   if (m->side) hipStreamDestroy(m->side);

@@ -252,9 +252,11 @@ def test_grad_tensor_aliases_library_memory():
     assert (eng.get_grad_flat() == 3.0).all()
 
 
-def test_ragged_graphs_shared_weights_vs_oracle():
+@pytest.mark.parametrize("dense", [False, True])
+def test_ragged_graphs_shared_weights_vs_oracle(dense):
     """BASELINE config 5 shape: graphs of different sizes packed with graph_off, shared weights.  Forward, loss and
-    every gradient against the CSR oracle (single Huber mean over all rows x channels)."""
+    every gradient against the CSR oracle (single Huber mean over all rows x channels).  dense: the reference
+    topology (in-degree n-2) -> MFMA aggregation; otherwise sparse random graphs -> gather form."""
     import ctypes as C
     from oracle.spec import GnnSpec as OSpec
     F = 64
@@ -266,7 +268,13 @@ def test_ragged_graphs_shared_weights_vs_oracle():
     R = int(offs[-1])
     row_ptr, cols, max_e = [0], [], 0
     for n in sizes:
-        adj = rng.uniform(size=(n, n)) < min(0.5, 6.0 / max(n, 1))
+        if dense:
+            adj = ~np.eye(n, dtype=bool)
+            for qq in range(n):
+                if n > 1:
+                    adj[rng.choice([p for p in range(n) if p != qq]), qq] = False
+        else:
+            adj = rng.uniform(size=(n, n)) < min(0.5, 6.0 / max(n, 1))
         e_g = 0
         for q in range(n):
             src = np.nonzero(adj[:, q])[0]
@@ -318,3 +326,24 @@ def test_rccl_path_single_rank(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["global_batch"] == 256
+
+
+def test_ragged_large_batch_loss_is_split_reduced():
+    """> 16k node rows with one Huber mean: the loss reduction is cut into ranges combined by the last workgroup.
+    Checked against numpy on the engine's own q, twice (the arrival counter must re-arm itself)."""
+    import bench
+    rng = np.random.default_rng(9)
+    sizes, offs, row_ptr, col_idx, x, e, y = bench.synth_ragged(rng, 500, 8, 128)
+    assert offs[-1] > 16384
+    spec = GnnSpec(n_nodes=1, feat_dim=64, share_weights=True, variable_graphs=True)
+    pb = PackedBatch(len(sizes), 0, v2xgnn.pack_xe(x, e), row_ptr, col_idx, int((sizes * (sizes - 2)).max()),
+                     graph_off=offs, max_nodes=int(sizes.max()))
+    eng = GnnEngine(spec)
+    eng.set_weights(oc.params_to_list(f32_params(spec, rng)))
+    q = eng.forward(pb).astype(np.float64)
+    ab = np.abs(q - y)
+    quad = np.minimum(ab, 1.0)
+    ref = (0.5 * quad * quad + (ab - quad)).mean()
+    for _ in range(2):
+        loss = eng.forward_backward(pb, y)
+        assert_close(loss, [ref], 1e-5, 1e-7, "split loss reduction")

@@ -38,10 +38,21 @@ class GnnQModel(object):
     """Keras-`Model`-like object over one GnnEngine."""
 
     def __init__(self, spec: GnnSpec, device=0, seed=None, use_graph=False, validate_adjacency=True,
-                 lr=1e-3, beta_1=0.5, beta_2=0.999, epsilon=1e-7):
+                 lr=1e-3, beta_1=0.5, beta_2=0.999, epsilon=1e-7, data_parallel=False, process_group=None, engine=None):
+        """data_parallel: every fit step shards the minibatch over the ranks of `process_group` (default group) and
+        all-reduces the gradient (v2xgnn.dp); all ranks must call fit with the SAME full minibatch.
+        engine: an object with GnnEngine's interface (the CPU tests inject one); default: the gfx950 engine,
+        which raises without a GPU."""
         self.spec = spec
-        self.engine = GnnEngine(spec, device=device, use_graph=use_graph, lr=lr, beta_1=beta_1, beta_2=beta_2,
-                                epsilon=epsilon)             # Adam(lr=0.001, beta_1=0.5, beta_2=0.999) BS_brain.py:212
+        self.engine = engine if engine is not None else GnnEngine(
+            spec, device=device, use_graph=use_graph, lr=lr, beta_1=beta_1, beta_2=beta_2,
+            epsilon=epsilon)                                 # Adam(lr=0.001, beta_1=0.5, beta_2=0.999) BS_brain.py:212
+        self.trainer = None
+        if data_parallel:
+            from .dp import DataParallelTrainer
+            import os
+            self.trainer = DataParallelTrainer(self.engine, process_group=process_group,
+                                               force=os.environ.get("V2X_FORCE_DP") == "1")
         self.validate_adjacency = validate_adjacency
         N = spec.n_nodes
         self.input_names = []
@@ -79,6 +90,16 @@ class GnnQModel(object):
             cols.append(a)
         return np.stack(cols, axis=1)        # [B, N, C]
 
+    def _train_step(self, pb, y):
+        """One optimizer step on the whole minibatch `pb` -> per-output losses (of the whole minibatch)."""
+        if self.trainer is None:
+            return self.engine.train_step(pb, y)
+        if pb.n_graphs % self.trainer.world:
+            raise ValueError("data-parallel fit: batch of %d graphs is not divisible by %d ranks"
+                             % (pb.n_graphs, self.trainer.world))
+        sb, sy = self.trainer.shard(pb, y)
+        return self.trainer.train_step(sb, sy, n_graphs_global=pb.n_graphs)
+
     # ------------------------------------------------------------------ Keras surface
     def predict(self, x, batch_size=None, verbose=0):
         """-> list of N fresh, writable float32 arrays [B, C] (the caller mutates them in place,
@@ -114,7 +135,7 @@ class GnnQModel(object):
                     bx, be, ba, by = xs[sel], es[sel], adj[sel], yt[sel]
                     bn = None if nbr is None else nbr[sel]
                 pb = PackedBatch.from_dense(bx, be, ba, bn)
-                loss = self.engine.train_step(pb, by.reshape(-1, self.spec.n_channels))
+                loss = self._train_step(pb, by.reshape(-1, self.spec.n_channels))
                 tot += np.asarray(loss, np.float64) * len(sel)
             tot /= B
             hist.epoch.append(ep)
@@ -135,8 +156,8 @@ class GnnQModel(object):
     def fit_arrays(self, x, e, adj, y, nbr=None):
         """One Adam step on the whole batch (what the reference's fit call amounts to, BS_brain.py:218-223);
         y [B, N, C].  -> History with the same keys as fit."""
-        loss = self.engine.train_step(PackedBatch.from_dense(x, e, adj, nbr),
-                                      np.asarray(y).reshape(-1, self.spec.n_channels))
+        loss = self._train_step(PackedBatch.from_dense(x, e, adj, nbr),
+                                np.asarray(y, np.float32).reshape(-1, self.spec.n_channels))
         loss = np.asarray(loss, np.float64)
         hist = History()
         hist.epoch.append(0)
@@ -173,7 +194,8 @@ class BS(object):
     """Same constructor / attributes / methods as the reference class (BS_brain.py:90-239)."""
 
     def __init__(self, num_d2d, input_node_info, input_edge_info, num_d2d_feedback, num_d2d_neighbor, num_ch,
-                 device=0, seed=None, n_mp_layers=2, share_weights=False, use_graph=False):
+                 device=0, seed=None, n_mp_layers=2, share_weights=False, use_graph=False, data_parallel=False,
+                 process_group=None, engine_factory=None):
         self.num_D2D = num_d2d
         self.num_Neighbor = num_d2d_neighbor
         self.num_CH = num_ch
@@ -189,6 +211,7 @@ class BS(object):
                              input_node_info=input_node_info, input_edge_info=input_edge_info,
                              n_neighbor=num_d2d_neighbor)
         self._device, self._use_graph = device, use_graph
+        self._dp, self._group, self._engine_factory = data_parallel, process_group, engine_factory
         ss = np.random.SeedSequence(seed).spawn(2)
         self._seeds = [int(s.generate_state(1)[0]) for s in ss]
         self.model = self._create_model()
@@ -196,7 +219,9 @@ class BS(object):
 
     def _create_model(self):
         seed = self._seeds.pop(0) if self._seeds else None
-        return GnnQModel(self._spec, device=self._device, seed=seed, use_graph=self._use_graph)
+        engine = self._engine_factory(self._spec) if self._engine_factory is not None else None
+        return GnnQModel(self._spec, device=self._device, seed=seed, use_graph=self._use_graph,
+                         data_parallel=self._dp, process_group=self._group, engine=engine)
 
     def train_dnn(self, data_train, labels, batch_size):
         epochs = 1

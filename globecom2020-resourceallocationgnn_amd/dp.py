@@ -9,6 +9,7 @@ differentiates its shard of the GLOBAL Huber mean (n_global = B), so the sum of 
 gradients is exactly the single-GPU gradient and no rescale is needed.  The target-network
 sync stays a local device-to-device copy.
 """
+import numpy as np
 
 
 class DataParallelTrainer(object):
@@ -44,9 +45,11 @@ class DataParallelTrainer(object):
             if want_loss and loss is not None:
                 import torch
                 if not torch.is_tensor(loss):
-                    loss_t = torch.as_tensor(loss)
+                    # host-side loss (numpy batches): reduce it on the device the gradient lives on (RCCL has no
+                    # CPU tensors; gloo takes the CPU tensor as is)
+                    loss_t = torch.as_tensor(np.asarray(loss, np.float64), device=self._grad.device)
                     self.dist.all_reduce(loss_t, op=self.dist.ReduceOp.SUM, group=self.group)
-                    loss = loss_t.numpy()
+                    loss = loss_t.cpu().numpy()
                 else:
                     self.dist.all_reduce(loss, op=self.dist.ReduceOp.SUM, group=self.group)
         self.backend.apply_gradients()

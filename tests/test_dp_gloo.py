@@ -13,40 +13,12 @@ import torch.multiprocessing as mp
 from v2xgnn import GnnSpec, PackedBatch
 from v2xgnn.dp import DataParallelTrainer
 from oracle import compact as oc
-from oracle.keras_semantics import KerasAdam
+from oracle_engine import OracleEngine
 from util import ospec, random_inputs
 
 
-class OracleBackend(object):
-    """Implements the backend protocol of DataParallelTrainer with the CPU oracle."""
-
-    def __init__(self, spec, params):
-        self.spec, self.os = spec, ospec(spec)
-        self.params = oc.cast_params(params, np.float64)
-        self.opt = KerasAdam()
-        n = sum(a.size for a in oc.param_arrays(self.params))
-        self._g = torch.zeros(n, dtype=torch.float64)
-
-    def forward_backward(self, batch, y, n_global=None, want_loss=True):
-        graph = ((np.arange(batch.n_graphs + 1) * batch.n_nodes).astype(np.int32), batch.row_ptr, batch.col_idx)
-        M = oc.csr_to_matrix(*graph, dtype=np.float64)
-        x, e = batch.xe[:, :9].astype(np.float64), batch.xe[:, 9:13].astype(np.float64)
-        q, cache = oc.forward(self.os, self.params, x, e, M)
-        loss, dq = oc.huber_loss_and_grad(self.os, q, np.asarray(y, np.float64), n_global)
-        g = oc.backward(self.os, self.params, cache, dq)
-        self._g.copy_(torch.from_numpy(np.concatenate([a.ravel() for a in oc.param_arrays(g)])))
-        return loss
-
-    def grad_tensor(self):
-        return self._g
-
-    def apply_gradients(self):
-        flat = self._g.numpy()
-        grads, pos = [], 0
-        for a in oc.param_arrays(self.params):
-            grads.append(flat[pos:pos + a.size].reshape(a.shape))
-            pos += a.size
-        self.opt.step(oc.param_arrays(self.params), grads)
+def OracleBackend(spec, params):
+    return OracleEngine(spec, params)
 
 
 def _data(spec, B):

@@ -74,3 +74,21 @@ def test_twenty_link_agent_step():
     result, q_mean, q_max, _, _ = agent.replay()
     assert len(q_mean) == 20
     assert all(np.isfinite(result.history['D%d_Decide_Output_loss' % (k + 1)][0]) for k in range(20))
+
+
+def test_dqn_driver_twenty_links_rccl_single_rank():
+    """BASELINE config 3 plumbing on one GPU: the training driver under torch.distributed.run with backend nccl (RCCL),
+    20 links x 64 features, data-parallel fit path forced on with one rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, V2X_FORCE_DP="1", MASTER_ADDR="127.0.0.1", PYTHONPATH=root)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", "-m", "v2xgnn.rl.train", "--links", "20", "--feedback", "64", "--batch", "512",
+           "--episodes", "1", "--train-steps", "2", "--use-graph"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["links"] == 20 and res["env_steps"] == 100 and len(res["mean_loss_last_episode"]) == 20
+    assert all(np.isfinite(v) and v >= 0 for v in res["mean_loss_last_episode"])

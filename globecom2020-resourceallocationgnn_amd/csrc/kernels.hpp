@@ -675,6 +675,153 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
   V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, inA, inB, load_in, compute)
 }
 
+// Training form: forward + Huber + reverse chain of the decision MLP in ONE pass over the rows (the hidden
+// activations never leave the registers between the two directions; z1..z3 and the pre-activation gradients are
+// still written once for k_wgrad).  Saves a launch and the read-back of q, z1, z2, z3 per fit step.
+template <int F>
+struct MlpTrainIn { f32x4 z0[2 * (F / 16) + 1]; f32x4 y; int64_t row; };
+
+template <int F>
+__global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
+  using L = MlpLds<F>;
+  constexpr int FB = F / 16, KB1 = 2 * FB + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int slot = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, kg = lane >> 4;
+  const int n_tiles = (a.n_idx + 15) >> 4;
+  const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+  const int t_end = min((int)(blockIdx.x + 1) * per, n_tiles);
+  const int cq = 4 * kg < a.C ? 4 * kg : 0;
+
+  auto load_in = [&](int t, MlpTrainIn<F>& in) {
+    const int idx = min(t * 16 + j, a.n_idx - 1);
+    const int64_t row = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
+    in.row = row;
+#pragma unroll
+    for (int b = 0; b < FB; ++b) in.z0[b] = ld4(a.h + row * F + b * 16 + 4 * kg);
+    in.z0[FB] = ld4(a.xe + row * XE + 4 * kg);
+#pragma unroll
+    for (int b = 0; b < FB; ++b) in.z0[FB + 1 + b] = ld4(a.agg + row * F + b * 16 + 4 * kg);
+    in.y = ld4(a.y + row * a.C + cq);
+  };
+  auto compute = [&](int t, const MlpTrainIn<F>& in) {
+    const bool valid = t * 16 + j < a.n_idx;
+    const int64_t row = in.row;
+    // ================= forward
+    f32x4 z1[1][5];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) z1[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < KB1; ++kb) {
+      f32x4 blk[1] = {in.z0[kb]};
+      mfma_cols<1, 5>(smem + L::W1, LD1, kb, j, kg, blk, z1);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      z1[0][nt] = relu4(z1[0][nt] + ld4(smem + L::B1 + nt * 16 + 4 * kg));
+      if (valid) st4(a.z1 + row * H1 + nt * 16 + 4 * kg, z1[0][nt]);
+    }
+    f32x4 z2[1][3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) z2[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) {
+      f32x4 blk[1] = {z1[0][kb]};
+      mfma_cols<1, 3>(smem + L::W2, LD2, kb, j, kg, blk, z2);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      z2[0][nt] = relu4(z2[0][nt] + ld4(smem + L::B2 + nt * 16 + 4 * kg));
+      if (valid && nt * 16 + 4 * kg < H2) st4(a.z2 + row * H2 + nt * 16 + 4 * kg, z2[0][nt]);
+    }
+    f32x4 z3[1][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) z3[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+      f32x4 blk[1] = {z2[0][kb]};
+      mfma_cols<1, 2>(smem + L::W3, LD3, kb, j, kg, blk, z3);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      z3[0][nt] = relu4(z3[0][nt] + ld4(smem + L::B3 + nt * 16 + 4 * kg));
+      if (valid && nt * 16 + 4 * kg < H3) st4(a.z3 + row * H3 + nt * 16 + 4 * kg, z3[0][nt]);
+    }
+    f32x4 qa[1][1];
+    qa[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x4 blk[1] = {z3[0][kb]};
+      mfma_cols<1, 1>(smem + L::W4, LD4, kb, j, kg, blk, qa);
+    }
+    const f32x4 qv = qa[0][0] + ld4(smem + L::B4 + 4 * kg);
+    if (valid && 4 * kg < a.C) st4(a.q + row * a.C + 4 * kg, qv);
+    // ================= Huber (delta = 1) and the reverse chain
+    f32x4 g4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (4 * kg < a.C) {
+      float ls = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float err = qv[c] - in.y[c];
+        const float ab = fabsf(err), quad = fminf(ab, 1.f);
+        ls += 0.5f * quad * quad + (ab - quad);
+        g4[c] = fminf(fmaxf(err, -1.f), 1.f) * a.inv_denom;
+      }
+      if (valid) {
+        st4(a.dq + row * a.C + 4 * kg, g4);
+        a.rowloss[row] = ls;
+      }
+    }
+    const auto lin = [](int nt) { return nt * 16; };
+    f32x4 d3[2][1];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) d3[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_rows_multi<2>(smem + L::W4, LD4, lin, 0, j, kg, g4, d3);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const bool in_range = nt * 16 + 4 * kg < H3;
+      d3[nt][0] = in_range ? gate4(d3[nt][0], z3[0][nt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (valid && in_range) st4(a.dz3 + row * H3 + nt * 16 + 4 * kg, d3[nt][0]);
+    }
+    f32x4 d2[3][1];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) d2[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) mfma_rows_multi<3>(smem + L::W3, LD3, lin, kb, j, kg, d3[kb][0], d2);
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const bool in_range = nt * 16 + 4 * kg < H2;
+      d2[nt][0] = in_range ? gate4(d2[nt][0], z2[0][nt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (valid && in_range) st4(a.dz2 + row * H2 + nt * 16 + 4 * kg, d2[nt][0]);
+    }
+    f32x4 d1[5][1];
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) d1[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) mfma_rows_multi<5>(smem + L::W2, LD2, lin, kb, j, kg, d2[kb][0], d1);
+#pragma unroll
+    for (int nt = 0; nt < 5; ++nt) {
+      d1[nt][0] = gate4(d1[nt][0], z1[0][nt]);
+      if (valid) st4(a.dz1 + row * H1 + nt * 16 + 4 * kg, d1[nt][0]);
+    }
+    const auto skip_xe = [](int nt) { return nt < FB ? nt * 16 : F + XE + (nt - FB) * 16; };
+    f32x4 o[2 * FB][1];
+#pragma unroll
+    for (int nt = 0; nt < 2 * FB; ++nt) o[nt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 5; ++kb) mfma_rows_multi<2 * FB>(smem + L::W1, LD1, skip_xe, kb, j, kg, d1[kb][0], o);
+#pragma unroll
+    for (int nt = 0; nt < 2 * FB; ++nt)
+      if (valid) st4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt][0]);
+  };
+
+  MlpTrainIn<F> inA, inB;
+  mlp_fill_lds<F>(smem, a, slot, true);
+  __syncthreads();
+  V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, inA, inB, load_in, compute)
+}
+
 // =====================================================================================
 // k_wgrad : dW[k][n] = sum_rows in[row][k] * dpre[row][n],  db[n] = sum_rows dpre[row][n]
 //           per (row-chunk, slot) partial written to a slab; k_reduce_adam sums the slabs

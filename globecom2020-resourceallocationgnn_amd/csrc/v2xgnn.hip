@@ -172,6 +172,7 @@ void set_attrs_f() {
   allow_big_lds((const void*)k_gemm_rows<F, true, false, true>);
   allow_big_lds((const void*)k_mlp_fwd<F>);
   allow_big_lds((const void*)k_mlp_bwd<F>);
+  allow_big_lds((const void*)k_mlp_train<F>);
   allow_big_lds((const void*)k_wgrad<F, false>);
   allow_big_lds((const void*)k_wgrad<F, true>);
 }
@@ -594,6 +595,32 @@ int launch_mlp_f(v2x_model* m, hipStream_t st, MlpArgs& a, int grid_y, bool bwd)
   return V2X_OK;
 }
 
+// forward + Huber + backward of the decision MLP in one launch (narrow features only)
+template <int F>
+int launch_mlp_train_f(v2x_model* m, hipStream_t st, MlpArgs& a, int grid_y) {
+  const size_t lds = (size_t)MlpLds<F>::TOTAL * 4;
+  static const int wgs_per_cu = env_int("V2X_MLP_WGS_PER_CU", 2);
+  const int gx = persistent_wgs_per_slot(a.n_idx, grid_y, wgs_per_cu);
+  auto k = k_mlp_train<F>;
+  LAUNCH(m, "k_mlp_train", k, dim3(gx, grid_y), lds, st, a);
+  return V2X_OK;
+}
+
+bool mlp_fused_training(const v2x_model* m) {
+  static const bool off = getenv("V2X_MLP_SPLIT") != nullptr;
+  return !off && m->F <= 64;
+}
+
+int launch_mlp_train(v2x_model* m, hipStream_t st, MlpArgs& a) {
+  const int gy = m->S == 1 ? 1 : m->N;
+  switch (m->F) {
+    case 16: return launch_mlp_train_f<16>(m, st, a, gy);
+    case 32: return launch_mlp_train_f<32>(m, st, a, gy);
+    case 64: return launch_mlp_train_f<64>(m, st, a, gy);
+  }
+  FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
+}
+
 int launch_mlp(v2x_model* m, hipStream_t st, MlpArgs& a, bool bwd) {
   const int gy = m->S == 1 ? 1 : m->N;
   if (is_wide(m)) {
@@ -800,7 +827,7 @@ LossJob loss_job(const v2x_model* m, const DevBatch& d, int n_global) {
 }
 
 // ------------------------------------------------------------------------------------ passes
-int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r) {
+int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool with_mlp = true) {
   const int F = m->F, L = m->L;
   const IdxMap x = idx_map(m, d, r);
   if (use_dense_agg(d, F)) {
@@ -814,6 +841,7 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r) {
     CHK(launch_node_fwd(m, st, s, x, d.xe, m->h[s - 1], m->a[s - 1], m->h[s]));
     CHK(launch_agg(m, st, d, r, m->N, F, m->h[s], F, nullptr, 0, nullptr, m->a[s], 0));
   }
+  if (!with_mlp) return V2X_OK;          // training: the MLP runs fused with its backward (k_mlp_train)
   MlpArgs a;
   mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
   CHK(launch_mlp(m, st, a, false));
@@ -846,16 +874,23 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
   a.y = y_dev;
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
-  CHK(launch_mlp(m, st, a, true));
+  if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
+  else CHK(launch_mlp(m, st, a, true));
   CHK(fork());
   CHK(wgrad_mlp(m, sw, x, d.xe, m->h[L], m->a[L]));        // 4 Dense layers, one launch, side stream
+  // V2X_WG_PER_STAGE=1: every GNN stage's weight gradient goes to the side stream as soon as its dpre exists
+  // (overlaps the remaining agg/dgrad chain) instead of one fused launch after the chain
+  static const bool per_stage = env_int("V2X_WG_PER_STAGE", 0) != 0;
+  const bool split = two && per_stage && !is_wide(m);
   for (int s = L; s >= 1; --s) {
     // dpre_s = (dh_direct + Agg^T(dagg)) * relu'(h_s)
     CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, s < L ? m->h[s] : nullptr, m->dpre[s], 1));
+    if (split) { CHK(fork()); CHK(wgrad_gnn(m, sw, s, x, d.xe, m->h[s - 1], m->a[s - 1], m->dpre[s])); }
     CHK(launch_dgrad(m, st, s, x, m->dpre[s], m->gha));
   }
   CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, m->h[0], m->dpre[0], 1));
-  CHK(wgrad_gnn_all(m, st, x, d));                          // all L+1 GNN stages, one launch
+  if (split) { CHK(fork()); CHK(wgrad_gnn(m, sw, 0, x, d.xe, nullptr, d.nbr, m->dpre[0])); }
+  else CHK(wgrad_gnn_all(m, st, x, d));                     // all L+1 GNN stages, one launch
   if (two) {                      // join: st waits for the side stream
     hipEvent_t e = m->ev[evi++];
     HIPCHK(m, hipEventRecord(e, sw));
@@ -867,7 +902,7 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
 // forward (+ backward) of the whole batch; everything is joined back into `st`
 int run_step(v2x_model* m, hipStream_t st, const DevBatch& d, bool bwd, const float* y_dev, int n_global) {
   const Range all{0, d.B};
-  CHK(run_forward(m, st, d, all));
+  CHK(run_forward(m, st, d, all, !(bwd && mlp_fused_training(m))));
   if (bwd) {
     const bool two = !m->prof && m->side && getenv("V2X_SINGLE_STREAM") == nullptr;
     CHK(run_backward(m, st, two ? m->side : st, d, all, y_dev, n_global));
@@ -1022,7 +1057,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->loss_part, 0, 512) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
   if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return fail("side stream");
-  m->ev.resize(m->L + 4);
+  m->ev.resize(2 * m->L + 6);
   for (auto& e : m->ev)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event");
   *out = m;
@@ -1229,10 +1264,14 @@ int v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_global, const floa
   if (n_global <= 0) n_global = m->cfg.variable_graphs ? n_rows : n_rows / m->N;
   MlpArgs a;
   mlp_args(m, a, x, xe, h, agg);
-  CHK(launch_mlp(m, st, a, false));
   a.y = y;
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
-  CHK(launch_mlp(m, st, a, true));
+  if (mlp_fused_training(m)) {
+    CHK(launch_mlp_train(m, st, a));
+  } else {
+    CHK(launch_mlp(m, st, a, false));
+    CHK(launch_mlp(m, st, a, true));
+  }
   CHK(wgrad_mlp(m, st, x, xe, h, agg));
   if (grad_out) CHK(launch_reduce_adam(m, st, 1, false, grad_out));
   if (dh) CHK(copy_cols(m, dh, m->F, m->gha, 2 * m->F, 0, n_rows, st));

@@ -1228,4 +1228,35 @@ __global__ __launch_bounds__(256) void k_loss_reduce(const float* rowloss, float
   if (threadIdx.x == 0) loss[slot] = red[0] * inv_denom;
 }
 
+// =====================================================================================
+// DQN replay glue (Agent.replay, BS_brain.py:573-692) for transitions resident in HBM
+// =====================================================================================
+// dst[i] = src[idx[i]], rows of `words` 4-byte words; VEC = 4 when rows are 16-byte multiples (coalesced float4)
+template <int VEC>
+__global__ __launch_bounds__(256) void k_gather_rows(const uint32_t* src, const int32_t* idx, uint32_t* dst,
+                                                     int64_t n_idx, int64_t words) {
+  const int64_t per_row = words / VEC;
+  const int64_t total = n_idx * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per_row, c = (i - r * per_row) * VEC;
+    const int64_t s = (int64_t)idx[r] * words + c;
+    if (VEC == 4) *reinterpret_cast<uint4*>(dst + r * words + c) = *reinterpret_cast<const uint4*>(src + s);
+    else dst[r * words + c] = src[s];
+  }
+}
+
+// one thread per (graph, node) row
+__global__ __launch_bounds__(256) void k_dqn_targets(const float* q, const float* qn, const int32_t* action,
+                                                     const double* reward, double gamma, int n_rows, int n_nodes,
+                                                     int C, float* y) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_rows) return;
+  float mx = qn[(int64_t)row * C];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, qn[(int64_t)row * C + c]);
+  // numpy semantics of `r + gamma * max(p_)` with p_ float32 and r float64: fp32 product, double sum, fp32 feed
+  const float t = (float)(reward[row / n_nodes] + (double)((float)gamma * mx));
+  const int a = action[row];
+  for (int c = 0; c < C; ++c) y[(int64_t)row * C + c] = c == a ? t : q[(int64_t)row * C + c];
+}
+
 }  // namespace v2x

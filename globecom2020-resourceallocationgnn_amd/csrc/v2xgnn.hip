@@ -1302,6 +1302,39 @@ int v2x_adam_step(float* param, const float* grad, float* mom, float* vel, int64
   return V2X_OK;
 }
 
+// ---------------------------------------------------------------------------- DQN replay glue
+int v2x_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_idx, int64_t row_bytes, void* stream) {
+  v2x_model* nullm = nullptr;
+  if (!src || !idx || !dst || n_idx <= 0 || row_bytes <= 0 || (row_bytes & 3))
+    FAIL(nullm, V2X_EINVAL, "gather_rows: null pointer, empty selection or row_bytes not a multiple of 4");
+  const int64_t words = row_bytes / 4;
+  const bool vec = (row_bytes & 15) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0;
+  const int64_t total = n_idx * (vec ? words / 4 : words);
+  int blocks = (int)std::min<int64_t>((total + 255) / 256, 8192);
+  if (vec)
+    hipLaunchKernelGGL(k_gather_rows<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, idx,
+                       (uint32_t*)dst, n_idx, words);
+  else
+    hipLaunchKernelGGL(k_gather_rows<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, idx,
+                       (uint32_t*)dst, n_idx, words);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) FAIL(nullm, V2X_EHIP, "gather_rows launch failed: %s", hipGetErrorString(e));
+  return V2X_OK;
+}
+
+int v2x_dqn_targets(const float* q, const float* q_next, const int32_t* action, const double* reward, double gamma,
+                    int32_t n_graphs, int32_t n_nodes, int32_t n_channels, float* y_out, void* stream) {
+  v2x_model* nullm = nullptr;
+  if (!q || !q_next || !action || !reward || !y_out || n_graphs <= 0 || n_nodes <= 0 || n_channels <= 0)
+    FAIL(nullm, V2X_EINVAL, "dqn_targets: bad argument");
+  const int n_rows = n_graphs * n_nodes;
+  hipLaunchKernelGGL(k_dqn_targets, dim3((n_rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, q_next, action,
+                     reward, gamma, n_rows, n_nodes, n_channels, y_out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) FAIL(nullm, V2X_EHIP, "dqn_targets launch failed: %s", hipGetErrorString(e));
+  return V2X_OK;
+}
+
 // ---------------------------------------------------------------------------- measurement
 int v2x_profile_enable(v2x_model* m, int enable) {
   if (!m) FAIL(m, V2X_EINVAL, "null model");

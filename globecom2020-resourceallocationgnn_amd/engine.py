@@ -41,6 +41,17 @@ class DeviceBatch(object):
         if self.col_idx is not None and self.col_idx.numel() == 0:
             self.col_idx = torch.zeros(1, dtype=torch.int32, device=self.device)
 
+    @classmethod
+    def from_tensors(cls, n_graphs, n_nodes, xe, row_ptr, col_idx, max_edges, nbr=None, graph_off=None, max_nodes=None):
+        """Wrap tensors that are ALREADY resident in HBM (float32 xe [R,16], int32 CSR); no copies."""
+        self = cls.__new__(cls)
+        self.n_graphs, self.n_nodes, self.n_rows = int(n_graphs), int(n_nodes), int(xe.shape[0])
+        self.n_edges = int(col_idx.numel()) if max_edges > 0 else 0
+        self.max_nodes, self.max_edges = int(max_nodes if max_nodes is not None else n_nodes), int(max_edges)
+        self.device = xe.device
+        self.xe, self.nbr, self.row_ptr, self.col_idx, self.graph_off = xe, nbr, row_ptr, col_idx, graph_off
+        return self
+
 
 def _batch_struct(b):
     s = _lib.Batch()

@@ -56,6 +56,8 @@ SYMBOLS = [
     ("v2x_mlp_fwd", C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
     ("v2x_mlp_huber_bwd", C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("v2x_adam_step", C.c_int, [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _P]),
+    ("v2x_gather_rows", C.c_int, [_P, _P, _P, _L, _L, _P]),
+    ("v2x_dqn_targets", C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("v2x_profile_enable", C.c_int, [_P, C.c_int]),
     ("v2x_profile_read", C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(_L), C.c_int]),
 ]
@@ -75,6 +77,12 @@ def load_library():
     if not os.path.exists(path):
         raise V2XError("HIP extension %s is missing: build it with `make -C %s` (no CPU fallback exists)"
                        % (path, os.path.join(_HERE, "csrc")))
+    # PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so).  Whichever copy of that soname is mapped
+    # first serves the whole process, and torch does not find its GPUs through /opt/rocm's copy: load torch's first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(path)
     except OSError as exc:

@@ -32,19 +32,22 @@ class Memory(object):
         if len(self.samples) > self.capacity:
             self.samples.pop(0)
 
-    def sample(self, n):
-        """n distinct samples when enough are stored, otherwise n draws with replacement -- the same global
+    def sample_indices(self, n):
+        """n distinct positions when enough are stored, otherwise n draws with replacement -- the same global
         numpy RNG calls as the reference (:261, :268)."""
         if len(self.samples) >= n:
-            idx = np.random.choice(len(self.samples), n, replace=False)
-        else:
-            idx = [np.random.randint(0, len(self.samples)) for _ in range(n)]
-        return [self.samples[i] for i in idx]
+            return np.random.choice(len(self.samples), n, replace=False)
+        return np.array([np.random.randint(0, len(self.samples)) for _ in range(n)])
+
+    def sample(self, n):
+        return [self.samples[i] for i in self.sample_indices(n)]
 
 
 class Agent(object):
     def __init__(self, num_d2d, num_ch, num_neighbor, num_d2d_feedback, environment, curr_rl_config, brain=None,
-                 **brain_kwargs):
+                 device_replay='auto', **brain_kwargs):
+        """device_replay: keep the replay memory in HBM (rl/replay.py) and run replay() without the minibatch
+        visiting the host; 'auto' = whenever the brain runs on the gfx950 engine."""
         self.epsilon = MAX_EPSILON
         self.num_step = 0
         self.num_CH = num_ch
@@ -67,6 +70,14 @@ class Agent(object):
         self.v2v_weight = curr_rl_config.v2v_weight
         self.v2i_weight = curr_rl_config.v2i_weight
         self.num_Episodes, self.num_Train_Step, self.num_transition = 1, 1, 50
+        engine = getattr(getattr(self.brain, 'model', None), 'engine', None)
+        on_gpu = hasattr(engine, '_h') and self.num_Neighbor == 1
+        self.device_replay = None
+        if device_replay is True or (device_replay == 'auto' and on_gpu):
+            if not on_gpu:
+                raise ValueError("device_replay needs a brain on the gfx950 engine")
+            from .replay import DeviceReplay
+            self.device_replay = DeviceReplay(MEMORY_CAPACITY, self.num_D2D, device=engine.device)
 
     # ------------------------------------------------------------------ observation
     def get_state(self, idx):
@@ -179,13 +190,21 @@ class Agent(object):
             rewards[self.train_step] = reward
             next_state, _ = self.observe()
             states_ = np.concatenate((next_state.reshape(1, -1), adj.reshape(1, -1)), axis=-1)   # same adjacency (:547)
-            self.train_observe([states, action.reshape(1, -1), reward, states_])
+            if self.device_replay is not None:
+                dn = self.brain.num_One_Node_Input
+                self.device_replay.add(d2d_state[:, :dn], d2d_state[:, dn:], adj, action.reshape(-1), reward,
+                                       next_state[:, :dn], next_state[:, dn:])
+                self.train_observe(None)               # the host list only keeps the FIFO bookkeeping
+            else:
+                self.train_observe([states, action.reshape(1, -1), reward, states_])
         return rewards
 
     # ------------------------------------------------------------------ learning
     def replay(self):
         """One DQN update on a replay minibatch (BS_brain.py:555-748): y = Q(s) with the taken action's entry
         replaced by r + gamma * max_a' Q_target(s', a')."""
+        if self.device_replay is not None:
+            return self._replay_on_device()
         n, d = self.num_D2D, self.brain.num_One_D2D_Input
         batch = self.memory.sample(self.batch_size)
         B = len(batch)
@@ -210,6 +229,41 @@ class Agent(object):
         q_max_mean = np.sum(np.max(y, axis=2), axis=1) / B
         # the reference reads "original" Q statistics from p AFTER it was overwritten in place (:684-690, :743-746)
         return result, q_mean, q_max_mean, q_mean.copy(), q_max_mean.copy()
+
+    def _replay_on_device(self):
+        """replay() with the minibatch gathered, scored, labelled and fitted in HBM.  Under data parallelism every
+        rank draws the same indices and processes only its own contiguous share of them."""
+        from ..bs_brain import History
+        n, B = self.num_D2D, self.batch_size
+        model, target = self.brain.model, self.brain.target_model
+        idx = self.memory.sample_indices(B)
+        trainer = model.trainer
+        if trainer is not None and trainer.world > 1:
+            if B % trainer.world:
+                raise ValueError("batch %d not divisible by %d ranks" % (B, trainer.world))
+            per = B // trainer.world
+            idx = idx[trainer.rank * per:(trainer.rank + 1) * per]
+        rep = self.device_replay
+        sb, sb_next, action, reward = rep.sample(idx)
+        q = model.engine.forward(sb)                                  # online  [k*n, C]
+        q_next = target.engine.forward(sb_next)                       # target  (adjacency reused, :583)
+        y = rep.dqn_targets(q, q_next, action, reward, self.gamma)
+        if trainer is not None:
+            loss = trainer.train_step(sb, y, n_graphs_global=B)
+        else:
+            loss = model.engine.train_step(sb, y)
+        yv = y.view(len(idx), n, -1).double()
+        stats = rep.torch.stack([yv.sum(dim=(0, 2)) / self.num_Actions, yv.max(dim=2).values.sum(dim=0)])
+        if trainer is not None and trainer.world > 1:
+            trainer.dist.all_reduce(stats, group=trainer.group)
+        stats = (stats / B).cpu().numpy()
+        loss = np.asarray(loss.cpu().numpy() if hasattr(loss, 'cpu') else loss, np.float64)
+        result = History()
+        result.epoch.append(0)
+        result.history['loss'] = [float(loss.sum())]
+        for k, name in enumerate(model.output_names):
+            result.history[name + '_loss'] = [float(loss[k])]
+        return result, stats[0], stats[1], stats[0].copy(), stats[1].copy()
 
     def train(self, num_episodes, num_train_steps, save_dir=None, save_interval=5, verbose=False):
         """BS_brain.py:750-910 without the plotting / pickling: episodes x train steps x (50 transitions + 1 replay),

@@ -15,10 +15,43 @@ import random
 import numpy as np
 
 
+_TWOPI = 2.0 * np.pi
+_mt = np.random.RandomState(0)        # scratch generator: only ever runs on a state borrowed from the stdlib one
+
+
+def _uniforms(k):
+    """k draws of stdlib random.random(), produced in bulk: CPython's generator and numpy's legacy RandomState are the
+    same MT19937 with the same 53-bit double construction, so the stdlib state is lent to numpy and handed back."""
+    ver, st, gauss_next = random.getstate()
+    _mt.set_state(('MT19937', np.array(st[:-1], dtype=np.uint32), st[-1]))
+    u = _mt.random_sample(k)
+    _, keys, pos = _mt.get_state()[:3]
+    random.setstate((ver, tuple(keys.tolist()) + (int(pos),), gauss_next))
+    return u
+
+
 def _gauss(shape, sigma):
-    """row-major array of random.gauss(0, sigma) draws == the nested loops of RandomGenerate (Environment.py:14-42)"""
+    """row-major array of random.gauss(0, sigma) draws == the nested loops of RandomGenerate (Environment.py:14-42).
+    Same stream and same pairing as CPython's gauss() (cos value now, sin value cached for the next call), computed
+    with array math instead of one Python call per element (1.9 M calls per 500 simulator steps at 20 links)."""
     n = int(np.prod(shape))
-    return np.array([random.gauss(0, sigma) for _ in range(n)], dtype=np.float64).reshape(shape)
+    out = np.empty(n, dtype=np.float64)
+    inst = random._inst
+    i = 0
+    if n and inst.gauss_next is not None:
+        out[0] = inst.gauss_next * sigma
+        inst.gauss_next = None
+        i = 1
+    pairs = (n - i + 1) // 2
+    if pairs:
+        u = _uniforms(2 * pairs)
+        x2pi = u[0::2] * _TWOPI
+        g2rad = np.sqrt(-2.0 * np.log(1.0 - u[1::2]))
+        z = np.stack([np.cos(x2pi) * g2rad, np.sin(x2pi) * g2rad], axis=1).reshape(-1)
+        out[i:] = z[:n - i] * sigma
+        if (n - i) & 1:
+            random._inst.gauss_next = float(z[-1])
+    return out.reshape(shape)
 
 
 class Vehicle(object):

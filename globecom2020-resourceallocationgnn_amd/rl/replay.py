@@ -1,0 +1,138 @@
+"""Device-resident replay memory: the transitions `Agent.train_observe` stores (BS_brain.py:245-270, :552) kept in
+HBM in the engine's packed layout, so that a replay step (BS_brain.py:555-748) is gather -> online forward -> target
+forward -> target rule -> fit without the minibatch ever visiting the host.
+
+torch tensors own the memory; every data movement on the device is one of the C-ABI kernels
+`v2x_gather_rows` / `v2x_dqn_targets` (include/v2xgnn.h).  Sampling indices still come from the caller's numpy RNG
+(same draws as `Memory.sample`), 4 bytes per sampled transition.
+
+Layout per transition (n links, E = edges of the graph, constant per memory -- the reference topology has in-degree
+n-2 for every link):  xe[n][16] of s, xe'[n][16] of s', col_idx[E] (CSR by destination, graph-local sources),
+action[n] int32, reward double.  New transitions are staged on the host and flushed in one copy per tensor before
+the next sample (the reference stores 50 transitions between replays, BS_brain.py:758).
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import lib as _lib
+from ..engine import DeviceBatch, current_stream_ptr
+from ..packing import adj_to_csr, pack_xe
+
+
+class DeviceReplay(object):
+    def __init__(self, capacity, n_nodes, device=0):
+        import torch
+        self.torch = torch
+        self.capacity, self.n = int(capacity), int(n_nodes)
+        self.device = torch.device("cuda:%d" % device) if isinstance(device, int) else torch.device(device)
+        self._lib = _lib.load_library()
+        self.size, self.head = 0, 0            # stored transitions; slot the next transition goes to (ring)
+        self.n_edges = None
+        self._alloc = 0
+        self._stage = []
+        self._row_ptr = {}
+
+    # ------------------------------------------------------------------ storage
+    def _grow(self, need):
+        """Storage grows geometrically up to `capacity` (the reference's 1e6-transition cap would be 4.1 GB at 20 links)."""
+        if need <= self._alloc:
+            return
+        torch, n, E = self.torch, self.n, self.n_edges
+        new = min(self.capacity, max(need, 2 * self._alloc, 4096))
+        def grow(old, shape, dtype):
+            t = torch.zeros((new,) + shape, dtype=dtype, device=self.device)
+            if old is not None:
+                t[:old.shape[0]] = old
+            return t
+        first = self._alloc == 0
+        self.xe = grow(None if first else self.xe, (n, 16), torch.float32)
+        self.xe_next = grow(None if first else self.xe_next, (n, 16), torch.float32)
+        self.col = grow(None if first else self.col, (max(E, 1),), torch.int32)
+        self.action = grow(None if first else self.action, (n,), torch.int32)
+        self.reward = grow(None if first else self.reward, (), torch.float64)
+        self._alloc = new
+
+    def add(self, x, e, adj, action, reward, x_next, e_next):
+        """x, x_next [n, Dn]; e, e_next [n, De]; adj [n, n] (Adj[p, q] = 1: p sends to q); action [n]; reward scalar."""
+        row_ptr, col, _ = adj_to_csr(np.asarray(adj)[None])
+        if self.n_edges is None:
+            self.n_edges = int(col.shape[0])
+        if col.shape[0] != self.n_edges or np.any(np.diff(row_ptr) != self.n_edges // max(self.n, 1)):
+            raise ValueError("DeviceReplay needs the same in-degree for every link of every transition "
+                             "(reference topology: n-2); got a graph with %d edges" % col.shape[0])
+        self._stage.append((pack_xe(np.asarray(x, np.float32), np.asarray(e, np.float32)),
+                            pack_xe(np.asarray(x_next, np.float32), np.asarray(e_next, np.float32)),
+                            col.astype(np.int32), np.asarray(action, np.int32).reshape(-1), float(reward)))
+
+    def __len__(self):
+        return min(self.capacity, self.size + len(self._stage))
+
+    def flush(self):
+        """Staged transitions -> HBM (one copy per tensor; ring wrap handled by splitting at the end of the storage)."""
+        if not self._stage:
+            return
+        torch = self.torch
+        k = len(self._stage)
+        self._grow(min(self.capacity, self.size + k))
+        cols = [np.stack([s[i] for s in self._stage]) for i in range(4)]
+        cols.append(np.array([s[4] for s in self._stage], np.float64))
+        dst = (self.xe, self.xe_next, self.col, self.action, self.reward)
+        pos, done = self.head, 0
+        while done < k:
+            m = min(k - done, self._alloc - pos)
+            for t, a in zip(dst, cols):
+                t[pos:pos + m].copy_(torch.from_numpy(np.ascontiguousarray(a[done:done + m])))
+            pos, done = pos + m, done + m
+            if pos == self.capacity:                   # full ring: overwrite the oldest transitions
+                pos = 0
+        self.head = pos
+        self.size = min(self.capacity, self.size + k)
+        self._stage = []
+
+    # ------------------------------------------------------------------ sampling
+    def _gather(self, src, idx_dev, k):
+        torch = self.torch
+        out = torch.empty((k,) + tuple(src.shape[1:]), dtype=src.dtype, device=self.device)
+        row_bytes = src[0].numel() * src.element_size() if src.dim() > 1 else src.element_size()
+        rc = self._lib.v2x_gather_rows(src.data_ptr(), idx_dev.data_ptr(), out.data_ptr(), k, row_bytes,
+                                       current_stream_ptr(self.device.index))
+        _lib.check(self._lib, rc, None)
+        return out
+
+    def row_ptr(self, k):
+        if k not in self._row_ptr:
+            deg = self.n_edges // self.n
+            self._row_ptr[k] = (self.torch.arange(k * self.n + 1, dtype=self.torch.int32, device=self.device) * deg)
+        return self._row_ptr[k]
+
+    def logical_to_slot(self, idx):
+        """Index into the FIFO order (0 = oldest stored transition, as in `Memory.samples`) -> storage slot."""
+        idx = np.asarray(idx, np.int64)
+        start = self.head if self.size == self.capacity else 0
+        return ((start + idx) % self.capacity).astype(np.int32)
+
+    def sample(self, idx):
+        """-> (batch of s, batch of s', action [k, n] int32, reward [k] float64), all in HBM."""
+        self.flush()
+        torch = self.torch
+        k = len(idx)
+        idx_dev = torch.from_numpy(self.logical_to_slot(idx)).to(self.device)
+        xe = self._gather(self.xe, idx_dev, k).view(k * self.n, 16)
+        xe_next = self._gather(self.xe_next, idx_dev, k).view(k * self.n, 16)
+        col = self._gather(self.col, idx_dev, k).view(-1)
+        action = self._gather(self.action, idx_dev, k)
+        reward = self._gather(self.reward, idx_dev, k)
+        rp = self.row_ptr(k)
+        mk = lambda t: DeviceBatch.from_tensors(k, self.n, t, rp, col, self.n_edges)
+        return mk(xe), mk(xe_next), action, reward
+
+    def dqn_targets(self, q, q_next, action, reward, gamma):
+        """The target rule (BS_brain.py:684-692) on device: y = q with y[b, k, a[b, k]] = r[b] + gamma * max q'[b, k]."""
+        k, n, Cc = action.shape[0], self.n, q.shape[1]
+        y = self.torch.empty_like(q)
+        rc = self._lib.v2x_dqn_targets(q.data_ptr(), q_next.data_ptr(), action.data_ptr(), reward.data_ptr(),
+                                       C.c_double(float(gamma)), k, n, Cc, y.data_ptr(),
+                                       current_stream_ptr(self.device.index))
+        _lib.check(self._lib, rc, None)
+        return y

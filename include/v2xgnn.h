@@ -12,6 +12,8 @@
  *   v2x_copy_weights              <- BS.update_target_model      BS_brain.py:237-239
  *   v2x_get_weights/set_weights   <- get_weights / set_weights / save_weights / load_weights
  *                                                                BS_brain.py:239,863,869,1254
+ *   v2x_gather_rows / v2x_dqn_targets
+ *                                 <- Agent.replay batching + target rule  BS_brain.py:573-692
  *   v2x_agg_* / v2x_node_update_* / v2x_mlp_* / v2x_adam_step
  *                                 <- the implicit TF op set of GNNLayer.call (:44-51),
  *                                    AggLayer.call (:69-76), Dense (:176-179), huber (:86-87),
@@ -156,6 +158,21 @@ int  v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_graphs_global, co
 int  v2x_adam_step(float* param, const float* grad, float* mom, float* vel, int64_t n,
                    int64_t iteration /* 1-based t */, float lr, float beta1, float beta2, float eps,
                    void* stream);
+
+/* ---- DQN replay glue on device ------------------------------------------------------------
+ * Counterparts of the minibatch assembly (BS_brain.py:573-640: per-sample Python loops filling the
+ * 13 input arrays) and of the target rule (BS_brain.py:670-692) of Agent.replay, for transitions
+ * that stay resident in HBM.  All pointers [dev].                                              */
+/* dst[i][0..row_bytes) = src[idx[i]][0..row_bytes)   (row_bytes a multiple of 4)               */
+int  v2x_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_idx, int64_t row_bytes,
+                     void* stream);
+/* y = q (online net on s), except y[b][k][action[b][k]] = reward[b] + gamma * max_c q_next[b][k][c]
+ * (q_next: target net on s'); evaluated like the reference's numpy expression (fp32 product, double
+ * sum, rounded to fp32 when fed).  q, q_next, y: [n_graphs*n_nodes][n_channels]; action: [n_graphs][n_nodes];
+ * reward: [n_graphs] double.                                                                    */
+int  v2x_dqn_targets(const float* q, const float* q_next, const int32_t* action, const double* reward,
+                     double gamma, int32_t n_graphs, int32_t n_nodes, int32_t n_channels, float* y_out,
+                     void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* When enabled, every kernel launch of this model is bracketed by HIP events on its stream

@@ -11,7 +11,7 @@ from util import assert_fwd_close
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed, batch=64, n_veh=4, feat=16):
+def _setup(seed, batch=64, n_veh=4, feat=16, device_replay='auto'):
     from v2xgnn.rl import Agent, RL_Config
     from test_rl_env import make_env
     random.seed(seed)
@@ -21,7 +21,7 @@ def _setup(seed, batch=64, n_veh=4, feat=16):
     env = make_env()
     if n_veh != env.n_Veh:
         env.new_random_game(n_veh)
-    agent = Agent(n_veh, env.n_RB, env.n_Neighbor, feat, env, cfg, seed=seed)
+    agent = Agent(n_veh, env.n_RB, env.n_Neighbor, feat, env, cfg, seed=seed, device_replay=device_replay)
     return agent, env, cfg
 
 
@@ -49,7 +49,7 @@ def test_compact_path_equals_dict_path_and_oracle():
     from oracle import compact
     from oracle.spec import GnnSpec as OSpec
     from v2xgnn.packing import PackedBatch
-    agent, env, cfg = _setup(12)
+    agent, env, cfg = _setup(12, device_replay=False)
     agent.generate_d2d_transition(40)
     batch = agent.memory.sample(32)
     s = np.stack([b[0][0] for b in batch])
@@ -92,3 +92,65 @@ def test_dqn_driver_twenty_links_rccl_single_rank():
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["links"] == 20 and res["env_steps"] == 100 and len(res["mean_loss_last_episode"]) == 20
     assert all(np.isfinite(v) and v >= 0 for v in res["mean_loss_last_episode"])
+
+
+@pytest.mark.parametrize("n_veh,feat,batch,n_trans", [(4, 16, 64, 40), (20, 64, 96, 130)])
+def test_device_replay_equals_host_replay(n_veh, feat, batch, n_trans):
+    """The HBM-resident replay step (gather -> online/target forward -> target rule -> fit, rl/replay.py) against the
+    host path that reproduces the reference's payloads: same sampled transitions, same targets, same update."""
+    out = []
+    for dev in (False, True):
+        agent, env, cfg = _setup(21, batch=batch, n_veh=n_veh, feat=feat, device_replay=dev)
+        assert (agent.device_replay is not None) == dev
+        agent.num_Episodes, agent.num_Train_Step = 1, 4
+        steps = []
+        for _ in range(3):                                  # first replay samples with replacement, later ones without
+            agent.generate_d2d_transition(n_trans)
+            result, q_mean, q_max, _, _ = agent.replay()
+            steps.append((np.array([result.history['D%d_Decide_Output_loss' % (k + 1)][0] for k in range(n_veh)]),
+                          q_mean, q_max))
+        out.append((steps, np.concatenate([w.ravel() for w in agent.brain.model.get_weights()])))
+    for (l0, m0, x0), (l1, m1, x1) in zip(out[0][0], out[1][0]):
+        assert np.allclose(l0, l1, rtol=2e-4, atol=1e-6)
+        assert np.allclose(m0, m1, rtol=1e-5, atol=1e-6) and np.allclose(x0, x1, rtol=1e-5, atol=1e-6)
+    assert np.allclose(out[0][1], out[1][1], rtol=1e-3, atol=2e-5)
+
+
+def test_device_replay_ring_and_gather():
+    """Ring overwrite + logical (FIFO) indexing of the HBM replay memory and the two glue kernels against numpy."""
+    import torch
+    from v2xgnn.rl.replay import DeviceReplay
+    rng = np.random.default_rng(3)
+    n, cap = 5, 37
+    rep = DeviceReplay(cap, n)
+    adj = np.ones((n, n)) - np.eye(n)
+    for q in range(n):
+        adj[(q + 1) % n, q] = 0
+    log = []
+    for i in range(90):                                     # wraps the 37-slot ring twice, flushed in uneven groups
+        x, e = rng.normal(size=(n, 9)), rng.normal(size=(n, 4))
+        x2, e2 = rng.normal(size=(n, 9)), rng.normal(size=(n, 4))
+        a, r = rng.integers(0, 4, size=n), float(rng.normal())
+        rep.add(x, e, adj, a, r, x2, e2)
+        log.append((x, e, a, r, x2, e2))
+        if i % 7 == 3:
+            rep.flush()
+    assert len(rep) == cap
+    kept = log[-cap:]                                       # FIFO: logical index 0 = oldest surviving transition
+    idx = rng.integers(0, cap, size=50)
+    sb, sb_next, action, reward = rep.sample(idx)
+    xe = sb.xe.cpu().numpy().reshape(50, n, 16)
+    xe2 = sb_next.xe.cpu().numpy().reshape(50, n, 16)
+    for k, i in enumerate(idx):
+        x, e, a, r, x2, e2 = kept[i]
+        assert np.array_equal(xe[k, :, :9], x.astype(np.float32)) and np.array_equal(xe[k, :, 9:13], e.astype(np.float32))
+        assert np.array_equal(xe2[k, :, :9], x2.astype(np.float32)) and np.all(xe[k, :, 13:] == 0)
+        assert np.array_equal(action[k].cpu().numpy(), a) and float(reward[k]) == r
+    assert sb.n_edges == 50 * n * (n - 2) and np.array_equal(sb.row_ptr.cpu().numpy(), np.arange(50 * n + 1) * (n - 2))
+    q = torch.from_numpy(rng.normal(size=(50 * n, 4)).astype(np.float32)).cuda()
+    qn = torch.from_numpy(rng.normal(size=(50 * n, 4)).astype(np.float32)).cuda()
+    y = rep.dqn_targets(q, qn, action, reward, 0.37).cpu().numpy()
+    ref = q.cpu().numpy().copy()
+    tgt = (reward.cpu().numpy()[:, None] + 0.37 * qn.cpu().numpy().reshape(50, n, 4).max(axis=2)).astype(np.float32)
+    ref.reshape(50, n, 4)[np.arange(50)[:, None], np.arange(n)[None, :], action.cpu().numpy()] = tgt
+    assert np.array_equal(y, ref)

@@ -105,6 +105,18 @@ class Agent(object):
         n, C, nn = self.num_D2D, self.num_CH, self.num_Neighbor
         power = self.env.V2V_power_dB_List[self.env.fixed_v2v_power_index]
         state = np.zeros((n, self.brain.num_One_D2D_Input))
+        if nn == 1:                                   # all links at once (same arithmetic as get_state)
+            A, Bc = 80, 60
+            v2v, v2i = self.env.V2V_channels_with_fastfading, self.env.V2I_channels_with_fastfading
+            k = np.arange(n)
+            dst = np.array([self.env.vehicles[i].destinations[0] for i in range(n)])
+            ch = (v2v[k, dst, :] - A) / Bc
+            edge = (((np.sum(v2v[:, dst, :], axis=0) - v2v[dst, dst, :]) - (n - 1) * A) / Bc - ch) / (n - 2)
+            state[:, 0:C] = ch
+            state[:, C:2 * C] = (v2i - A) / Bc
+            state[:, 2 * C] = power
+            state[:, 2 * C + 1:] = edge
+            return state, self.adjacency()
         for k in range(n):
             ch, v2i, edge = np.zeros((nn, C)), None, np.zeros((nn, C))
             for m in range(nn):

@@ -211,11 +211,13 @@ class Environ(object):
         pos = np.array([c.position for c in self.vehicles], dtype=np.float64)
         vel = np.asarray([c.velocity for c in self.vehicles])
         dd = 0.002 * vel
+        n = self.n_Veh
+        g = _gauss((n + n * n,), 1.0)     # ONE bulk draw, consumed in the reference's order: V2I shadow, then V2V shadow
         self._v2i_shadow = (np.exp(-1 * (dd / self.V2I_DECORR)) * self._v2i_shadow
-                            + np.sqrt(1 - np.exp(-2 * (dd / self.V2I_DECORR))) * _gauss((self.n_Veh,), self.V2I_SHADOW_STD))
+                            + np.sqrt(1 - np.exp(-2 * (dd / self.V2I_DECORR))) * (g[:n] * self.V2I_SHADOW_STD))
         ddm = dd[:, None] + dd[None, :]
         self._v2v_shadow = (np.exp(-1 * (ddm / self.V2V_DECORR)) * self._v2v_shadow
-                            + np.sqrt(1 - np.exp(-2 * (ddm / self.V2V_DECORR))) * _gauss((self.n_Veh, self.n_Veh), self.V2V_SHADOW_STD))
+                            + np.sqrt(1 - np.exp(-2 * (ddm / self.V2V_DECORR))) * (g[n:].reshape(n, n) * self.V2V_SHADOW_STD))
         self.V2V_channels_abs = self._v2v_pathloss(pos) + self._v2v_shadow + 50 * np.identity(len(self.vehicles))
         self.V2I_channels_abs = self._v2i_pathloss(pos) + self._v2i_shadow
 
@@ -223,9 +225,11 @@ class Environ(object):
         """Large-scale update + Rayleigh fast fading per resource block (Environment.py:395-406, :88-92, :160-165)."""
         self.renew_channel()
         n, rb = self.n_Veh, self.n_RB
-        re, im = _gauss((n, rb), 1), _gauss((n, rb), 1)
+        g = _gauss((2 * n * rb + 2 * n * n * rb,), 1)       # one bulk draw: V2I re, V2I im, V2V re, V2V im
+        a, b = n * rb, n * n * rb
+        re, im = g[:a].reshape(n, rb), g[a:2 * a].reshape(n, rb)
         v2i_ff = 20 * np.log10(np.abs(1 / np.sqrt(2) * (re + 1j * im)))
-        re, im = _gauss((n, n, rb), 1), _gauss((n, n, rb), 1)
+        re, im = g[2 * a:2 * a + b].reshape(n, n, rb), g[2 * a + b:].reshape(n, n, rb)
         v2v_ff = 20 * np.log10(np.abs(1 / np.sqrt(2) * (re + 1j * im)))
         self.V2V_channels_with_fastfading = self.V2V_channels_abs[:, :, None] - v2v_ff
         self.V2I_channels_with_fastfading = self.V2I_channels_abs[:, None] - v2i_ff

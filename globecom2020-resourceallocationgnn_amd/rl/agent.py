@@ -315,18 +315,44 @@ class Agent(object):
         d2d_state, adj = self.observe()
         return self._feed(d2d_state[None], adj[None])
 
-    def test_run(self, num_episodes, num_test_step):
-        """Greedy policy vs the random-action baseline (BS_brain.py:986-1162 without the 4^4 brute force)."""
+    def test_run(self, num_episodes, num_test_step, opt_flag=False):
+        """Evaluation loop (BS_brain.py:986-1162): greedy policy of the trained network vs the random-action baseline
+        and, with opt_flag, the brute-force optimum over all C^N joint actions (the reference hard-codes 4^4,
+        :1071-1078; here any N with C^N <= 65536).  Same return tuple as the reference: 15 arrays with opt_flag,
+        10 without."""
+        n, C = self.num_D2D, self.num_CH
         self.num_Episodes, self.num_Test_Step = num_episodes, num_test_step
-        rl, rnd = np.zeros((num_episodes, num_test_step)), np.zeros((num_episodes, num_test_step))
+        w_v2v, w_v2i = self.v2v_weight, self.v2i_weight
+
+        def book():
+            return [np.zeros(num_episodes), np.zeros((num_episodes, num_test_step)), np.zeros((num_episodes, num_test_step, n)),
+                    np.zeros((num_episodes, num_test_step, C)), np.zeros((num_episodes, num_test_step, C))]
+
+        def record(b, ep, st, v2v, v2i, interference):
+            b[1][ep, st] = w_v2v * np.sum(v2v) + w_v2i * np.sum(v2i)
+            b[0][ep] += b[1][ep, st]
+            b[2][ep, st, :] = np.sum(v2v, axis=1)
+            b[3][ep, st, :] = v2i
+            b[4][ep, st, :] = interference
+
+        rl, ra, opt = book(), book(), book()
+        if opt_flag:
+            if C ** n > 65536:
+                raise ValueError("brute-force search over %d^%d joint actions is not feasible" % (C, n))
+            import itertools
+            joint = np.array(list(itertools.product(range(C), repeat=n)), int)          # link 0 most significant (:1071-1078)
         for ep in range(num_episodes):
             self.env.new_random_game(self.num_D2D)
             for st in range(num_test_step):
+                record(ra, ep, st, *self.dump_act(self.select_action_random(None)))
+                if opt_flag:
+                    res = [self.dump_act(a.reshape(n, 1)) for a in joint]
+                    rewards = np.array([w_v2v * np.sum(r[0]) + w_v2i * np.sum(r[1]) for r in res])
+                    best = int(np.argmax(rewards))
+                    if rewards[best] > 0:                                                 # at least one feasible solution
+                        record(opt, ep, st, *res[best])
                 d2d_state, adj = self.observe()
-                v2v, v2i, _ = self.dump_act(self.select_action_random(None))
-                rnd[ep, st] = self.v2v_weight * np.sum(v2v) + self.v2i_weight * np.sum(v2i)
                 q = self._predict(d2d_state[None], adj[None])[:, 0, :]
-                action = np.argmax(q, axis=1).reshape(self.num_D2D, self.num_Neighbor).astype(int)
-                v2v, v2i, _ = self.act(action)
-                rl[ep, st] = self.v2v_weight * np.sum(v2v) + self.v2i_weight * np.sum(v2i)
-        return rl, rnd
+                action = np.argmax(q, axis=1).reshape(n, self.num_Neighbor).astype(int)
+                record(rl, ep, st, *self.act(action))
+        return tuple(rl + ra + opt) if opt_flag else tuple(rl + ra)

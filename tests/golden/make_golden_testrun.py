@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Capture the reference's evaluation loop `Agent.test_run` (BS_brain.py:986-1162: greedy policy vs the random-action
+and brute-force baselines) on the reference simulator with the recording fake brain of make_golden.py.
+
+Runs ONLY in the build container (imports /root/reference); writes tests/golden/golden_testrun_n4.npz.
+    python tests/golden/make_golden_testrun.py
+"""
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg                                               # noqa: E402  (stubs + FakeBS + make_env)
+
+NAMES = ['Expect_Return', 'Reward', 'Per_V2V_Rate', 'Per_V2I_Rate', 'Per_V2B_Interference',
+         'RA_Expect_Return', 'RA_Reward', 'RA_Per_V2V_Rate', 'RA_Per_V2I_Rate', 'RA_Per_V2B_Interference',
+         'Opt_Expect_Return', 'Opt_Reward', 'Opt_Per_V2V_Rate', 'Opt_Per_V2I_Rate', 'Opt_Per_V2B_Interference']
+
+
+def main():
+    mg.install_stubs()
+    sys.path.insert(0, mg.REF)
+    import Environment
+    import Sim_Config
+    import BS_brain
+    seed = 4242
+    random.seed(seed)
+    np.random.seed(seed)
+    cfg = Sim_Config.RL_Config()
+    cfg.set_train_value(16, 0.5, 32, 1, 0.1)
+    env = mg.make_env(Environment)
+    BS_brain.BS = mg.FakeBS
+    BS_brain.Memory.samples = []
+    agent = BS_brain.Agent(env.n_Veh, env.n_RB, env.n_Neighbor, cfg.Num_Feedback, env, cfg)
+    out = agent.test_run(3, 7, True)
+    fx = {'seed': seed, 'episodes': 3, 'steps': 7}
+    for name, v in zip(NAMES, out):
+        fx[name] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, 'golden_testrun_n4.npz'), **fx)
+    print('wrote golden_testrun_n4.npz', {k: np.asarray(v).shape for k, v in fx.items()})
+
+
+if __name__ == '__main__':
+    main()

@@ -41,8 +41,16 @@ def test_training_loop_runs_and_learns_signal(tmp_path):
     tag = '-Episode-2-Step-5-Batch-64.h5'
     assert os.path.exists(os.path.join(str(tmp_path), 'Q-Network_model_weights' + tag))
     assert os.path.exists(os.path.join(str(tmp_path), 'Target-Network_model_weights' + tag))
-    rl, rnd = agent.test_run(1, 5)
-    assert rl.shape == rnd.shape == (1, 5) and np.all(np.isfinite(rl))
+    # evaluation driver on the weights just saved (counterpart of RL_Run_main.py)
+    from v2xgnn.rl.run import load_trained_model, run_test
+    cfg.Num_Episodes, cfg.Num_Train_Steps = 2, 5
+    cfg.set_test_values(1, 4, True, 1, 0.1)
+    agent2 = load_trained_model(env, cfg, str(tmp_path), seed=99)
+    for a, b in zip(w1, agent2.brain.model.get_weights()):
+        assert np.array_equal(a, b)
+    res = run_test(cfg, agent2)
+    assert res['Reward'].shape == res['RA_Reward'].shape == res['Opt_Reward'].shape == (1, 4)
+    assert np.all(res['Opt_Reward'] >= res['Reward'] - 1e-9) and np.all(res['Opt_Reward'] >= res['RA_Reward'] - 1e-9)
 
 
 def test_compact_path_equals_dict_path_and_oracle():

@@ -113,3 +113,24 @@ def test_epsilon_schedule_and_random_actions():
     agent.num_step = 400
     agent.select_action_while_training(state)
     assert agent.epsilon == 0.01
+
+
+def test_test_run_matches_reference_evaluation_loop():
+    """Greedy / random-action / brute-force-optimal evaluation (BS_brain.py:986-1162) against the reference's own run
+    (tests/golden/make_golden_testrun.py: same simulator seed, same fake-brain stream)."""
+    g = np.load(os.path.join(GOLDEN, 'golden_testrun_n4.npz'))
+    seed = int(g['seed'])
+    random.seed(seed)
+    np.random.seed(seed)
+    cfg = RL_Config()
+    cfg.set_train_value(16, 0.5, 32, 1, 0.1)
+    env = make_env()
+    brain = RecordingBrain(env.n_Veh, 3, 1, cfg.Num_Feedback, env.n_Neighbor, env.n_RB)
+    agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, cfg.Num_Feedback, env, cfg, brain=brain)
+    out = agent.test_run(int(g['episodes']), int(g['steps']), True)
+    names = ['Expect_Return', 'Reward', 'Per_V2V_Rate', 'Per_V2I_Rate', 'Per_V2B_Interference']
+    assert len(out) == 15
+    for i, name in enumerate([p + n for p in ('', 'RA_', 'Opt_') for n in names]):
+        assert out[i].shape == g[name].shape, name
+        assert np.allclose(out[i], g[name], rtol=1e-9, atol=1e-12), name
+    assert len(agent.test_run(1, 2, False)) == 10

@@ -201,6 +201,154 @@ __global__ __launch_bounds__(256) void k_agg(AggArgs a_in) {
   }
 }
 
+// Small-tile form of k_agg (the 20-link graphs of the headline configuration): the workgroup's whole tile -- <= 1024
+// float4 of features, <= 255 rows, <= 1024 edges, <= 4 destination rows per worker -- is fetched with EVERY global
+// load issued before the first wait (features, row pointers, edge sources and the epilogue operands of all the
+// worker's rows), then written to LDS.  In k_agg the same data arrives through 5+ dependent HBM round trips (the
+// staging loops wait for each load before the LDS store), which is most of that kernel's 17-23 us.
+// HAS_ADD / HAS_MASK are compile-time: `ptr ? load : 0` makes hipcc branch around every load and wait for it.
+template <bool TRANSPOSE, bool HAS_ADD, bool HAS_MASK>
+__global__ __launch_bounds__(256) void k_agg_small(AggArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sT = smem;                                         // [rows_cap][F]
+  int* sRp = reinterpret_cast<int*>(sT + a.rows_cap * a.F); // [rows_cap+1]
+  int* sCol = sRp + a.rows_cap + 1;                         // [edges_cap]
+  unsigned* sM = reinterpret_cast<unsigned*>(sCol + a.edges_cap);  // [rows_cap][mask_words]
+
+  const int tid = threadIdx.x;
+  const int g0 = a.g_base + blockIdx.x * a.gpw;
+  const int g1 = min(g0 + a.gpw, a.g_end);
+  const int r_begin = a.graph_off ? a.graph_off[g0] : g0 * a.n_nodes;
+  const int r_end = a.graph_off ? a.graph_off[g1] : g1 * a.n_nodes;
+  const int nrows = r_end - r_begin;
+  const int LPR = 1 << a.lpr_shift;
+  const int nf4 = nrows << a.lpr_shift;
+
+  // worker = LPR lanes owning up to 4 destination rows of one graph
+  const int worker = tid >> a.lpr_shift, li4 = (tid & (LPR - 1)) << 2;
+  const int nworkers = 256 >> a.lpr_shift;
+  const int wpg = nworkers / a.gpw;
+  const int gi = worker / wpg, wr = worker - gi * wpg;
+  const bool have_graph = g0 + gi < g1;
+  const int gcl = min(g0 + gi, g1 - 1);
+  const int gb = (a.graph_off ? a.graph_off[gcl] : gcl * a.n_nodes) - r_begin;
+  const int ng = (a.graph_off ? a.graph_off[gcl + 1] : (gcl + 1) * a.n_nodes) - r_begin - gb;
+
+  // ---- issue every global load.  (The empty asm statements "use" the loaded registers: without them LLVM sinks
+  //      each load into the conditional LDS store that consumes it and the loads serialise again.)
+#define V2X_PIN4(v) asm volatile("" : "+v"((v).x), "+v"((v).y), "+v"((v).z), "+v"((v).w))
+  // (wave-uniform addresses -> scalar loads: their wait does not hold up the vector loads below)
+  const int e_begin = a.row_ptr[__builtin_amdgcn_readfirstlane(r_begin)];
+  const int e_end = a.row_ptr[__builtin_amdgcn_readfirstlane(r_end)];
+  float4 fv[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int i = min(tid + 256 * p, nf4 - 1);
+    const int r = i >> a.lpr_shift, c = (i & (LPR - 1)) << 2;
+    fv[p] = *reinterpret_cast<const float4*>(a.src + (int64_t)(r_begin + r) * a.src_stride + c);
+  }
+  int rpv = a.row_ptr[r_begin + min(tid, nrows)];
+  float4 addv[4], mkv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int64_t row = r_begin + gb + min(wr + k * wpg, ng - 1);
+    if (HAS_ADD) addv[k] = *reinterpret_cast<const float4*>(a.add + row * a.add_stride + li4);
+    else addv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HAS_MASK) mkv[k] = *reinterpret_cast<const float4*>(a.mask + row * a.F + li4);
+    else mkv[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+  const int nedges = e_end - e_begin;
+  int cv[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) cv[p] = a.col_idx[e_begin + min(tid + 256 * p, max(nedges - 1, 0))];   // col_idx holds >= 1 entry
+#pragma unroll
+  for (int p = 0; p < 4; ++p) { V2X_PIN4(fv[p]); asm volatile("" : "+v"(cv[p])); }
+  asm volatile("" : "+v"(rpv));
+  if (HAS_ADD || HAS_MASK) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { if (HAS_ADD) V2X_PIN4(addv[k]); if (HAS_MASK) V2X_PIN4(mkv[k]); }
+  }
+#undef V2X_PIN4
+  // ---- LDS
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int i = tid + 256 * p;
+    if (i < nf4) *reinterpret_cast<float4*>(sT + (i >> a.lpr_shift) * a.F + ((i & (LPR - 1)) << 2)) = fv[p];
+  }
+  if (tid <= nrows) sRp[tid] = rpv - e_begin;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+    if (tid + 256 * p < nedges) sCol[tid + 256 * p] = cv[p];
+  if (TRANSPOSE)
+    for (int i = tid; i < nrows * a.mask_words; i += 256) sM[i] = 0u;
+  __syncthreads();
+
+  if (TRANSPOSE) {
+    // transposed adjacency as per-source bit masks: every edge is one integer atomicOr (order-independent)
+    for (int i = tid; i < nrows * 32; i += 256) {
+      const int r = i >> 5, sl = i & 31;
+      int gj = 0, gbj = 0;
+      if (a.graph_off) { while (gj + 1 < g1 - g0 && a.graph_off[g0 + gj + 1] - r_begin <= r) ++gj; gbj = a.graph_off[g0 + gj] - r_begin; }
+      else { gj = r / a.n_nodes; gbj = gj * a.n_nodes; }
+      const int ql = r - gbj;
+      for (int e = sRp[r] + sl; e < sRp[r + 1]; e += 32)
+        atomicOr(&sM[(gbj + sCol[e]) * a.mask_words + (ql >> 5)], 1u << (ql & 31));
+    }
+    __syncthreads();
+  }
+  if (!have_graph) return;
+
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int q = wr + k * wpg;
+    if (q >= ng) break;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!TRANSPOSE) {
+      const int e1 = sRp[gb + q + 1];
+      int e = sRp[gb + q];
+      for (; e + 4 <= e1; e += 4) {
+        const int p0 = sCol[e], p1 = sCol[e + 1], p2 = sCol[e + 2], p3 = sCol[e + 3];
+        const float4 v0 = *reinterpret_cast<const float4*>(sT + (gb + p0) * a.F + li4);
+        const float4 v1 = *reinterpret_cast<const float4*>(sT + (gb + p1) * a.F + li4);
+        const float4 v2 = *reinterpret_cast<const float4*>(sT + (gb + p2) * a.F + li4);
+        const float4 v3 = *reinterpret_cast<const float4*>(sT + (gb + p3) * a.F + li4);
+        acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+        acc.x += v1.x; acc.y += v1.y; acc.z += v1.z; acc.w += v1.w;
+        acc.x += v2.x; acc.y += v2.y; acc.z += v2.z; acc.w += v2.w;
+        acc.x += v3.x; acc.y += v3.y; acc.z += v3.z; acc.w += v3.w;
+      }
+      for (; e < e1; ++e) {
+        const float4 v = *reinterpret_cast<const float4*>(sT + (gb + sCol[e]) * a.F + li4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    } else {
+      for (int wd = 0; wd < a.mask_words; ++wd) {
+        unsigned mbits = sM[(gb + q) * a.mask_words + wd];
+        const float* base = sT + (gb + (wd << 5)) * a.F + li4;
+        while (mbits) {
+          const int b0 = __builtin_ctz(mbits); mbits &= mbits - 1;
+          const int b1 = mbits ? __builtin_ctz(mbits) : -1; if (mbits) mbits &= mbits - 1;
+          const int b2 = mbits ? __builtin_ctz(mbits) : -1; if (mbits) mbits &= mbits - 1;
+          const int b3 = mbits ? __builtin_ctz(mbits) : -1; if (mbits) mbits &= mbits - 1;
+          const float4 v0 = *reinterpret_cast<const float4*>(base + b0 * a.F);
+          const float4 v1 = *reinterpret_cast<const float4*>(base + (b1 < 0 ? b0 : b1) * a.F);
+          const float4 v2 = *reinterpret_cast<const float4*>(base + (b2 < 0 ? b0 : b2) * a.F);
+          const float4 v3 = *reinterpret_cast<const float4*>(base + (b3 < 0 ? b0 : b3) * a.F);
+          const float m1 = b1 < 0 ? 0.f : 1.f, m2 = b2 < 0 ? 0.f : 1.f, m3 = b3 < 0 ? 0.f : 1.f;
+          acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+          acc.x += v1.x * m1; acc.y += v1.y * m1; acc.z += v1.z * m1; acc.w += v1.w * m1;
+          acc.x += v2.x * m2; acc.y += v2.y * m2; acc.z += v2.z * m2; acc.w += v2.w * m2;
+          acc.x += v3.x * m3; acc.y += v3.y * m3; acc.z += v3.z * m3; acc.w += v3.w * m3;
+        }
+      }
+    }
+    acc.x += addv[k].x; acc.y += addv[k].y; acc.z += addv[k].z; acc.w += addv[k].w;
+    acc.x = mkv[k].x > 0.f ? acc.x : 0.f; acc.y = mkv[k].y > 0.f ? acc.y : 0.f;
+    acc.z = mkv[k].z > 0.f ? acc.z : 0.f; acc.w = mkv[k].w > 0.f ? acc.w : 0.f;
+    *reinterpret_cast<float4*>(a.out + (int64_t)(r_begin + gb + q) * a.F + li4) = acc;
+  }
+}
+
 // =====================================================================================
 // k_gemm_rows : node update  out = act(sum_seg in_seg . W_seg + b)  and its data-gradient
 // =====================================================================================

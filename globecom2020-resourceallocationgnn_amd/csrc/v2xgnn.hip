@@ -371,6 +371,8 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, 
   if (F < 16 || F > 256 || (F & (F - 1))) FAIL(m, V2X_EINVAL, "agg: feat_dim must be a power of two in [16,256]");
   static const bool attrs_once = [] {        // the per-kernel entry points can get here without any model
     allow_big_lds((const void*)k_agg<false>); allow_big_lds((const void*)k_agg<true>);
+    allow_big_lds((const void*)k_agg_small<false, false, false>); allow_big_lds((const void*)k_agg_small<true, true, true>);
+    allow_big_lds((const void*)k_agg_small<true, true, false>); allow_big_lds((const void*)k_agg_small<true, false, false>);
     allow_big_lds((const void*)k_agg_dense<false>); allow_big_lds((const void*)k_agg_dense<true>);
     return true;
   }();
@@ -421,6 +423,22 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, 
                      (size_t)a.edges_cap * 4 + (transpose ? (size_t)a.rows_cap * a.mask_words * 4 : 0);
   if (lds > 160 * 1024) FAIL(m, V2X_EINVAL, "agg: graph tile (%zu B) exceeds the 160 KiB LDS", lds);
   const dim3 grid((r.ng + gpw - 1) / gpw);
+  // small tiles (the 20-link graphs of the headline configuration): everything fetched before the first wait
+  static const bool small_off = getenv("V2X_AGG_NO_SMALL") != nullptr;
+  const int wpg = nworkers / gpw;
+  const bool small = !small_off && d.ci != nullptr && (a.rows_cap << sh) <= 1024 && a.rows_cap + 1 <= 256 && a.edges_cap <= 1024 &&
+                     (d.max_nodes + wpg - 1) / wpg <= 4;
+  if (small) {
+#define V2X_AGG_SMALL(T, A, M, NAME) { auto k = k_agg_small<T, A, M>; LAUNCH(m, NAME, k, grid, lds, st, a); return V2X_OK; }
+    if (!transpose) {
+      if (!add && !mask) V2X_AGG_SMALL(false, false, false, "k_agg_fwd")
+    } else {
+      if (add && mask) V2X_AGG_SMALL(true, true, true, "k_agg_bwd")
+      if (add && !mask) V2X_AGG_SMALL(true, true, false, "k_agg_bwd")
+      if (!add && !mask) V2X_AGG_SMALL(true, false, false, "k_agg_bwd")
+    }
+#undef V2X_AGG_SMALL
+  }
   if (transpose) { auto k = k_agg<true>; LAUNCH(m, "k_agg_bwd", k, grid, lds, st, a); }
   else { auto k = k_agg<false>; LAUNCH(m, "k_agg_fwd", k, grid, lds, st, a); }
   return V2X_OK;

@@ -368,12 +368,17 @@ struct GemmArgs {
 // tiles (wave-interleaved); LOAD(t, buf) issues the global loads of tile t, COMPUTE(t, buf) consumes them.  The
 // steady state is branch-free (loads of tile t+4 are issued, THEN tile t is computed under a counted vmcnt;
 // sched_barrier pins that order) and the last one or two tiles are peeled.
-#define V2X_TILE_PIPELINE(T0, T_END, BUF_A, BUF_B, LOAD, COMPUTE)                     \
+// V2X_TILE_PROLOGUE issues the first tile's loads and is placed BEFORE the weight staging, so that both sets of
+// loads are in flight together; V2X_TILE_LOOP follows the barrier.
+#define V2X_TILE_PROLOGUE(T0, T_END, BUF_A, LOAD)                                     \
+  const int t_ = (T0);                                                                \
+  const int nt_ = t_ < (T_END) ? ((T_END) - t_ + 3) >> 2 : 0;                         \
+  if (nt_ > 0) LOAD(t_, BUF_A);                                                       \
+  __builtin_amdgcn_sched_barrier(0);
+
+#define V2X_TILE_LOOP(BUF_A, BUF_B, LOAD, COMPUTE)                                    \
   {                                                                                   \
-    int t_ = (T0);                                                                    \
-    const int nt_ = t_ < (T_END) ? ((T_END) - t_ + 3) >> 2 : 0;                       \
     int k_ = 0;                                                                       \
-    if (nt_ > 0) LOAD(t_, BUF_A);                                                     \
     for (; k_ + 2 < nt_; k_ += 2) {                                                   \
       LOAD(t_ + 4 * (k_ + 1), BUF_B);                                                 \
       __builtin_amdgcn_sched_barrier(0);                                              \
@@ -489,10 +494,11 @@ __global__ __launch_bounds__(256) void k_gemm_rows(GemmArgs a) {
   auto load_t = [&](int t, Tile& x) { load_tile(t, x.bf, x.row); };
   auto comp_t = [&](int t, const Tile& x) { compute_store(t, x.bf, x.row); };
   Tile tA, tB;
+  V2X_TILE_PROLOGUE(blockIdx.x * per + wv, t_end, tA, load_t)
   fill_weight_image<KP, F, LDW>(sW, Wg, a.pad, F);
   if (!DGRAD) fill_bias(sB, F, Wg + (int64_t)a.pad.k_real * F, F);
   __syncthreads();
-  V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, tA, tB, load_t, comp_t)
+  V2X_TILE_LOOP(tA, tB, load_t, comp_t)
 }
 
 // =====================================================================================
@@ -709,9 +715,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd(MlpArgs a) {
   };
 
   MlpFwdIn<F> inA, inB;
+  V2X_TILE_PROLOGUE(blockIdx.x * per + wv, t_end, inA, load_in)
   mlp_fill_lds<F>(smem, a, slot, true);
   __syncthreads();
-  V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, inA, inB, load_in, compute)
+  V2X_TILE_LOOP(inA, inB, load_in, compute)
 }
 
 template <int F>
@@ -818,9 +825,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
   };
 
   MlpBwdIn<F> inA, inB;
+  V2X_TILE_PROLOGUE(blockIdx.x * per + wv, t_end, inA, load_in)
   mlp_fill_lds<F>(smem, a, slot, false);
   __syncthreads();
-  V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, inA, inB, load_in, compute)
+  V2X_TILE_LOOP(inA, inB, load_in, compute)
 }
 
 // Training form: forward + Huber + reverse chain of the decision MLP in ONE pass over the rows (the hidden
@@ -965,9 +973,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
   };
 
   MlpTrainIn<F> inA, inB;
+  V2X_TILE_PROLOGUE(blockIdx.x * per + wv, t_end, inA, load_in)
   mlp_fill_lds<F>(smem, a, slot, true);
   __syncthreads();
-  V2X_TILE_PIPELINE(blockIdx.x * per + wv, t_end, inA, inB, load_in, compute)
+  V2X_TILE_LOOP(inA, inB, load_in, compute)
 }
 
 // =====================================================================================
@@ -1219,11 +1228,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
 // Every launch of this path costs ~6-8 us of fixed latency, so the 4 Dense layers (and the L+1 GNN stages)
 // share one launch each instead of 4 (L+1).  Kernarg structs indexed by blockIdx.z would be copied to scratch
 // (runtime-indexed array): the role's descriptor is read through the constant-address-space kernarg pointer.
-constexpr int WG_MAX_ROLES = 4;
+constexpr int WG_MAX_ROLES = 8;
 struct WgradMulti { WgradArgs w[WG_MAX_ROLES]; };
 enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 3, WG_KIND_DENSE2 = 4, WG_KIND_DENSE3 = 5 };
 
-template <int F, bool DENSE>
+// MODE 0: the GNN stages, 1: the Dense layers, 2: both families in one launch (roles ordered heaviest first)
+template <int F, int MODE>
 __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef const __attribute__((address_space(4))) unsigned* CWords;
@@ -1234,14 +1244,15 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
   unsigned* dstw = reinterpret_cast<unsigned*>(&a);
 #pragma unroll
   for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
-  if constexpr (!DENSE) {
-    if (a.kind == WG_KIND_GNN) wgrad_body<F, XE, F, F>(a, smem, blockIdx.x, blockIdx.y);
-    else wgrad_body<XE, F, 0, F>(a, smem, blockIdx.x, blockIdx.y);
-  } else {
+  if constexpr (MODE != 1) {
+    if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F>(a, smem, blockIdx.x, blockIdx.y); return; }
+  }
+  if constexpr (MODE != 0) {
     if (a.kind == WG_KIND_DENSE0) wgrad_body<F, XE, F, H1>(a, smem, blockIdx.x, blockIdx.y);
     else if (a.kind == WG_KIND_DENSE1) wgrad_body<H1, 0, 0, H2P>(a, smem, blockIdx.x, blockIdx.y);
     else if (a.kind == WG_KIND_DENSE2) wgrad_body<H2P, 0, 0, H3P>(a, smem, blockIdx.x, blockIdx.y);
-    else wgrad_body<H3P, 0, 0, CP>(a, smem, blockIdx.x, blockIdx.y);
+    else if (a.kind == WG_KIND_DENSE3) wgrad_body<H3P, 0, 0, CP>(a, smem, blockIdx.x, blockIdx.y);
   }
 }
 

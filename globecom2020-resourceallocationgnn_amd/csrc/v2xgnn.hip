@@ -173,8 +173,9 @@ void set_attrs_f() {
   allow_big_lds((const void*)k_mlp_fwd<F>);
   allow_big_lds((const void*)k_mlp_bwd<F>);
   allow_big_lds((const void*)k_mlp_train<F>);
-  allow_big_lds((const void*)k_wgrad<F, false>);
-  allow_big_lds((const void*)k_wgrad<F, true>);
+  allow_big_lds((const void*)k_wgrad<F, 0>);
+  allow_big_lds((const void*)k_wgrad<F, 1>);
+  allow_big_lds((const void*)k_wgrad<F, 2>);
 }
 
 void set_attrs(int F) {
@@ -188,7 +189,7 @@ void set_attrs(int F) {
   if (F >= 128) {                     // wide path: tail MLP kernels + the narrow weight-gradient kernel for Dense 1..3
     allow_big_lds((const void*)k_mlp_fwd<0>);
     allow_big_lds((const void*)k_mlp_bwd<0>);
-    allow_big_lds((const void*)k_wgrad<64, true>);
+    allow_big_lds((const void*)k_wgrad<64, 1>);
   }
 }
 
@@ -693,17 +694,19 @@ int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti
   }
   const size_t lds = (size_t)(maxt * 64 * 4 + 5 * 16) * 4;      // accumulator exchange + bias
   const dim3 grid(nc, x.grid_y, n_roles);
-  const bool dense = mu.w[0].kind >= WG_KIND_DENSE0;
+  bool dense = false, gnn = false;
+  for (int i = 0; i < n_roles; ++i) (mu.w[i].kind >= WG_KIND_DENSE0 ? dense : gnn) = true;
 #define V2X_WG_CASE(FF)                                                              \
   if (m->F == FF) {                                                                  \
-    if (dense) { auto k = k_wgrad<FF, true>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
-    else { auto k = k_wgrad<FF, false>; LAUNCH(m, name, k, grid, lds, st, mu); }       \
+    if (dense && gnn) { auto k = k_wgrad<FF, 2>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
+    else if (dense) { auto k = k_wgrad<FF, 1>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
+    else { auto k = k_wgrad<FF, 0>; LAUNCH(m, name, k, grid, lds, st, mu); }           \
     return V2X_OK;                                                                   \
   }
   V2X_WG_CASE(16) V2X_WG_CASE(32) V2X_WG_CASE(64)
 #undef V2X_WG_CASE
   if (is_wide(m) && dense) {            // Dense 1..3 only (their operand widths do not depend on F)
-    auto k = k_wgrad<64, true>;
+    auto k = k_wgrad<64, 1>;
     LAUNCH(m, name, k, grid, lds, st, mu);
     return V2X_OK;
   }
@@ -794,6 +797,32 @@ int wgrad_mlp(v2x_model* m, hipStream_t st, const IdxMap& x, const float* xe, co
   WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0}};
   CHK(wgrad_role(m, m->dense[3], WG_KIND_DENSE3, x, total, s3, 1, m->dq, m->C, mu.w[3]));
   return launch_wgrad_multi(m, st, x, mu, 4, "k_wgrad_dense");
+}
+
+// every layer's weight gradient in ONE launch (single-stream backward): roles heaviest first, because workgroups
+// are dispatched in blockIdx.z order and the launch is as long as its last-finishing workgroup
+bool wgrad_all_fits(const v2x_model* m) { return !is_wide(m) && m->L + 1 + 4 <= WG_MAX_ROLES; }
+
+int wgrad_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch& d) {
+  const int F = m->F, L = m->L;
+  int total = 0;
+  for (int i = 0; i < 4; ++i) total += layer_work(m->dense[i]);
+  for (int s = 0; s <= L; ++s) total += layer_work(m->gnn[s]);
+  WgradMulti mu;
+  memset(&mu, 0, sizeof(mu));
+  int n = 0;
+  WgSeg s0[3] = {WgSeg{m->h[L], F, F, 0}, WgSeg{d.xe, XE, XE, F}, WgSeg{m->a[L], F, F, F + XE}};
+  CHK(wgrad_role(m, m->dense[0], WG_KIND_DENSE0, x, total, s0, 3, m->dz1, H1, mu.w[n++]));
+  for (int s = L; s >= 1; --s)
+    CHK(wgrad_gnn_role(m, s, x, total, d.xe, m->h[s - 1], m->a[s - 1], m->dpre[s], mu.w[n++]));
+  CHK(wgrad_gnn_role(m, 0, x, total, d.xe, nullptr, d.nbr, m->dpre[0], mu.w[n++]));
+  WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0}};
+  CHK(wgrad_role(m, m->dense[1], WG_KIND_DENSE1, x, total, s1, 1, m->dz2, H2, mu.w[n++]));
+  WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0}};
+  CHK(wgrad_role(m, m->dense[2], WG_KIND_DENSE2, x, total, s2, 1, m->dz3, H3, mu.w[n++]));
+  WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0}};
+  CHK(wgrad_role(m, m->dense[3], WG_KIND_DENSE3, x, total, s3, 1, m->dq, m->C, mu.w[n++]));
+  return launch_wgrad_multi(m, st, x, mu, n, "k_wgrad_all");
 }
 
 struct LossJob { int n_out, n_idx, stride; float scale; };   // n_out == 0: no loss role
@@ -894,8 +923,9 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
   if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
   else CHK(launch_mlp(m, st, a, true));
+  const bool merged = !two && wgrad_all_fits(m) && env_int("V2X_WG_SPLIT", 0) == 0;
   CHK(fork());
-  CHK(wgrad_mlp(m, sw, x, d.xe, m->h[L], m->a[L]));        // 4 Dense layers, one launch, side stream
+  if (!merged) CHK(wgrad_mlp(m, sw, x, d.xe, m->h[L], m->a[L]));        // 4 Dense layers, one launch (side stream if two)
   // V2X_WG_PER_STAGE=1: every GNN stage's weight gradient goes to the side stream as soon as its dpre exists
   // (overlaps the remaining agg/dgrad chain) instead of one fused launch after the chain
   static const bool per_stage = env_int("V2X_WG_PER_STAGE", 0) != 0;
@@ -908,6 +938,7 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   }
   CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, m->h[0], m->dpre[0], 1));
   if (split) { CHK(fork()); CHK(wgrad_gnn(m, sw, 0, x, d.xe, nullptr, d.nbr, m->dpre[0])); }
+  else if (merged) CHK(wgrad_all(m, st, x, d));             // every layer, one launch
   else CHK(wgrad_gnn_all(m, st, x, d));                     // all L+1 GNN stages, one launch
   if (two) {                      // join: st waits for the side stream
     hipEvent_t e = m->ev[evi++];
@@ -922,7 +953,9 @@ int run_step(v2x_model* m, hipStream_t st, const DevBatch& d, bool bwd, const fl
   const Range all{0, d.B};
   CHK(run_forward(m, st, d, all, !(bwd && mlp_fused_training(m))));
   if (bwd) {
-    const bool two = !m->prof && m->side && getenv("V2X_SINGLE_STREAM") == nullptr;
+    // measured: with the current kernels the side-stream overlap of the Dense weight gradients no longer pays
+    // (0.397 vs 0.390 ms/step), so one stream is the default; V2X_TWO_STREAMS=1 restores the fork/join
+    const bool two = !m->prof && m->side && getenv("V2X_TWO_STREAMS") != nullptr;
     CHK(run_backward(m, st, two ? m->side : st, d, all, y_dev, n_global));
   }
   return V2X_OK;

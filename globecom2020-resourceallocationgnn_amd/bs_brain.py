@@ -177,15 +177,54 @@ class GnnQModel(object):
     def set_weights(self, weights):
         self.engine.set_weights(weights)
 
+    def keras_layer_table(self):
+        """[(layer name, [weight names])] of the layers that own weights, in the order of get_weights() -- the names
+        Keras gives the reference model's layers (BS_brain.py:121-200; auto-named layers get their class's snake-case
+        name and a running index)."""
+        sp = self.spec
+        slots = range(1, sp.n_nodes + 1) if not sp.share_weights else [None]
+        table, gnn_uid, dense_uid = [], 0, 0
+        for stage in range(sp.n_mp_layers + 1):
+            for k in slots:
+                if stage == 0:
+                    name = 'D%d_GNN' % k if k else 'GNN'
+                else:
+                    gnn_uid += 1
+                    name = 'gnn_layer_%d' % gnn_uid
+                table.append((name, ['%s/%s:0' % (name, w) for w in ('W1', 'W2', 'W3', 'bias')]))
+        for layer in range(4):
+            for k in slots:
+                if layer == 3:
+                    name = 'D%d_Decide_Output' % k if k else 'Decide_Output'
+                else:
+                    dense_uid += 1
+                    name = 'dense_%d' % dense_uid
+                table.append((name, ['%s/kernel:0' % name, '%s/bias:0' % name]))
+        return table
+
     def save_weights(self, filepath, overwrite=True):
-        """Weights only, like Keras `save_weights` (no optimizer state: BS_brain.py:853-870).
-        h5py is not available on the target image, so the container is NumPy's .npz written
-        under exactly the name the caller gives (including the reference's '.h5' names)."""
-        arrays = {('w%03d' % i): w for i, w in enumerate(self.get_weights())}
+        """Weights only, like Keras `save_weights` (no optimizer state: BS_brain.py:853-870).  A '.h5' / '.hdf5' name
+        is written as a Keras-layout HDF5 file through libhdf5 (h5weights.py) when that library can be loaded;
+        otherwise (and for any other name) the container is NumPy's .npz under exactly the name the caller gives."""
+        from . import h5weights
+        weights = self.get_weights()
+        if str(filepath).lower().endswith(('.h5', '.hdf5', '.keras.h5')) and h5weights.available():
+            it = iter(weights)
+            layers = [(ln, [(wn, next(it)) for wn in wns]) for ln, wns in self.keras_layer_table()]
+            h5weights.save_keras_weights(filepath, layers)
+            return
+        arrays = {('w%03d' % i): w for i, w in enumerate(weights)}
         with open(filepath, 'wb') as f:
             np.savez(f, **arrays)
 
     def load_weights(self, filepath):
+        """Keras-layout HDF5 (matched to the model by ORDER of the weighted layers, as Keras does) or the .npz
+        container written by save_weights; the format is detected from the file signature."""
+        from . import h5weights
+        if h5weights.is_hdf5(filepath):
+            layers = h5weights.load_keras_weights(filepath)
+            self.set_weights([arr for _, ws in layers for _, arr in ws])
+            return
         with np.load(filepath) as z:
             self.set_weights([z['w%03d' % i] for i in range(len(z.files))])
 

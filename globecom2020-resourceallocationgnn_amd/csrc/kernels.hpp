@@ -1056,7 +1056,7 @@ __device__ __forceinline__ void wg_load(WgOperand<W>& o, const WgSrc& src, unsig
 // tiles with a barrier per tile; a 2 x 2 tile split over the waves that loads every operand twice; dword-only
 // fragment loads; single buffering at 4 waves/SIMD -- waves sharing a SIMD run in lockstep, so occupancy alone
 // does not overlap memory and MFMA phases.)
-template <int K0, int K1, int K2, int NW>
+template <int K0, int K1, int K2, int NW, int DEPTH = 2>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, const int bx, const int slot) {
   constexpr int T0 = K0 / 16, T1 = K1 / 16, T2 = K2 / 16, KT = T0 + T1 + T2, NT = NW / 16;
   if (bx >= a.n_chunks) return;                                  // roles have work-proportional grids
@@ -1119,28 +1119,66 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   // This wave's blocks: wv, wv+4, ...  The loads of the next block are issued, THEN the MFMAs of the current one
   // run (sched_barrier pins that order; a load under an `if` would force vmcnt(0) at the join).
   const int nb = n_full > wv ? (n_full - wv + 3) >> 2 : 0;
+  // Three register buffers, TWO blocks of loads in flight while a third is multiplied: the launch is bound by HBM
+  // latency x bytes in flight per CU (324 MB per step through ~10 B/clk/CU) at least as much as by the MFMA pipe,
+  // and one wave per SIMD (512-VGPR budget) is the only place to hold more bytes in flight.
+  // (DEPTH 3 where the operand buffers fit the 256 architectural VGPRs next to the accumulators; DEPTH 2 otherwise)
   Block b0, b1;
-  if (nb > 0) load_full(wv, b0);
+#define V2X_SB __builtin_amdgcn_sched_barrier(0)
   int k = 0;
+  if constexpr (DEPTH == 2) {
+    if (nb > 0) load_full(wv, b0);
 #pragma unroll 1
-  for (; k + 2 < nb; k += 2) {
-    load_full(wv + 4 * (k + 1), b1);
-    __builtin_amdgcn_sched_barrier(0);
+    for (; k + 2 < nb; k += 2) {
+      load_full(wv + 4 * (k + 1), b1); V2X_SB;
+      mfma_block(b0); V2X_SB;
+      load_full(wv + 4 * (k + 2), b0); V2X_SB;
+      mfma_block(b1); V2X_SB;
+    }
+    if (nb - k == 2) {                                             // peeled tail: 2 or 1 blocks left
+      load_full(wv + 4 * (k + 1), b1); V2X_SB;
+      mfma_block(b0);
+      mfma_block(b1);
+    } else if (nb - k == 1) {
+      mfma_block(b0);
+    }
+  } else if (nb == 1) {
+    load_full(wv, b0);
+    V2X_SB;
     mfma_block(b0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_full(wv + 4 * (k + 2), b0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(b1);
-    __builtin_amdgcn_sched_barrier(0);
+  } else if (nb >= 2) {
+    Block b2;
+    load_full(wv, b0);
+    load_full(wv + 4, b1);
+    V2X_SB;
+#pragma unroll 1
+    for (; k + 4 < nb; k += 3) {             // invariant: b0 = block k, b1 = block k+1 (loaded or in flight)
+      load_full(wv + 4 * (k + 2), b2); V2X_SB;
+      mfma_block(b0); V2X_SB;
+      load_full(wv + 4 * (k + 3), b0); V2X_SB;
+      mfma_block(b1); V2X_SB;
+      load_full(wv + 4 * (k + 4), b1); V2X_SB;
+      mfma_block(b2); V2X_SB;
+    }
+    const int rem = nb - k;                  // 2, 3 or 4 blocks left
+    if (rem == 2) {
+      mfma_block(b0);
+      mfma_block(b1);
+    } else if (rem == 3) {
+      load_full(wv + 4 * (k + 2), b2); V2X_SB;
+      mfma_block(b0);
+      mfma_block(b1);
+      mfma_block(b2);
+    } else {
+      load_full(wv + 4 * (k + 2), b2); V2X_SB;
+      mfma_block(b0); V2X_SB;
+      load_full(wv + 4 * (k + 3), b0); V2X_SB;
+      mfma_block(b1);
+      mfma_block(b2);
+      mfma_block(b0);
+    }
   }
-  if (nb - k == 2) {                                             // peeled tail: 2 or 1 blocks left
-    load_full(wv + 4 * (k + 1), b1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(b0);
-    mfma_block(b1);
-  } else if (nb - k == 1) {
-    mfma_block(b0);
-  }
+#undef V2X_SB
   if (n_full * WG_TR < n_rows_here && wv == (n_full & 3)) {      // partial last block of the chunk
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -1245,8 +1283,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
 #pragma unroll
   for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
   if constexpr (MODE != 1) {
-    if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F>(a, smem, blockIdx.x, blockIdx.y); return; }
-    if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
   }
   if constexpr (MODE != 0) {
     if (a.kind == WG_KIND_DENSE0) wgrad_body<F, XE, F, H1>(a, smem, blockIdx.x, blockIdx.y);

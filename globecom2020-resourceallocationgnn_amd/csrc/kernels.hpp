@@ -1308,6 +1308,7 @@ struct AdamArgs {
   int n_adam_blocks;
   const float* rowloss; float* loss; int loss_n_idx, loss_stride; float loss_scale;
   int loss_split; float* loss_part; unsigned* loss_cnt;  // ranges per output (> 1 only with a single output)
+  const float* grad_direct;                              // where slab-less layers left their gradient
   int groups;                                            // threads per float4 column (1, 4 or 16): split of the slab sum
 };
 
@@ -1356,6 +1357,7 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
     const int64_t i = base + col;
     const bool act = i < a.n4;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool direct = false;
     if (a.slab) {
       if (act) {
         int l = 0;
@@ -1365,6 +1367,9 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
           const float4 t = reinterpret_cast<const float4*>(a.slab + c * a.slab_stride)[i];
           g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
         }
+        // a layer with no slabs had its gradient written straight into the gradient buffer (wide path, one row split)
+        if (ns == 0 && grp == 0) g = reinterpret_cast<const float4*>(a.grad_direct)[i];
+        direct = ns == 0 && a.grad == a.grad_direct;       // already where it belongs: no copy
       }
       if (G > 1) {
         part[threadIdx.x] = g;
@@ -1377,7 +1382,7 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
         }
         __syncthreads();
       }
-      if (act && grp == 0) reinterpret_cast<float4*>(a.grad)[i] = g;
+      if (act && grp == 0 && !direct) reinterpret_cast<float4*>(a.grad)[i] = g;
     } else if (act && grp == 0) {
       g = reinterpret_cast<const float4*>(a.grad)[i];
     }
@@ -1395,6 +1400,14 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
       reinterpret_cast<float4*>(a.param)[i] = p;
     }
   }
+}
+
+// dst[slot * slot_stride + i] = 0 for i < count (count, slot_stride multiples of 4): zero gradient of weight rows
+// whose input segment is absent
+__global__ __launch_bounds__(256) void k_zero_rows(float* dst, int64_t slot_stride, int64_t count) {
+  float* p = dst + blockIdx.y * slot_stride;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < count; i += (int64_t)gridDim.x * 1024)
+    *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // scalar tail-safe Adam for arbitrary n (v2x_adam_step entry point)

@@ -506,7 +506,7 @@ int wide_splits(int n_idx, int n_tiles, int n_slots) {
 }
 
 int wide_wgrad(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, const WideSeg* segs, const int* seg_kpad,
-               int n_seg, const float* dpre, int d_stride, const char* name) {
+               int n_seg, const float* dpre, int d_stride, const char* name, int zero_row0 = 0, int zero_rows = 0) {
   WideWgradArgs a;
   memset(&a, 0, sizeof(a));
   int kt = 0;
@@ -521,6 +521,18 @@ int wide_wgrad(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, con
   a.n_split = sp;
   a.rows_per_split = ((x.n_idx + sp - 1) / sp + WW_TR - 1) / WW_TR * WW_TR;
   ld.n_slabs = sp;
+  if (sp == 1) {            // no partial sums to add: write the gradient buffer itself (saves a 2 x P-float round trip)
+    a.slab = m->grads;
+    ld.n_slabs = 0;
+  }
+  if (zero_rows > 0) {      // weight rows of an absent (identically zero) input segment: exact zero gradient
+    const int64_t count = (int64_t)zero_rows * ld.n_out;
+    for (int c = 0; c < sp; ++c) {
+      float* dst = a.slab + (int64_t)c * a.slab_stride + ld.off + (int64_t)zero_row0 * ld.n_out;
+      const dim3 zg((unsigned)std::min<int64_t>((count / 4 + 255) / 256, 64), x.grid_y);
+      hipLaunchKernelGGL(k_zero_rows, zg, dim3(256), 0, st, dst, ld.slot_stride, count);
+    }
+  }
   LAUNCH(m, name, k_wide_wgrad, dim3(kt, nt, x.grid_y * sp), 0, st, a);
   return V2X_OK;
 }
@@ -734,8 +746,9 @@ int wide_wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, con
     s[n] = WideSeg{agg_prev, F, F}; kp[n++] = F + XE;
   } else {
     s[n] = WideSeg{xe, XE, XE}; kp[n++] = 0;
-    // neighbour-init absent (the reference always feeds zeros): its weight rows get an exact zero gradient
-    s[n] = WideSeg{agg_prev ? agg_prev : m->zero_buf, agg_prev ? F : 0, F}; kp[n++] = XE;
+    if (agg_prev) { s[n] = WideSeg{agg_prev, F, F}; kp[n++] = XE; }
+    // neighbour-init absent (the reference always feeds zeros): its F weight rows (real rows Dn+De ..) are memset
+    else return wide_wgrad(m, st, m->gnn[0], x, s, kp, n, dpre, F, "k_wgrad_embed", m->Dn + m->De, F);
   }
   return wide_wgrad(m, st, m->gnn[stage], x, s, kp, n, dpre, F, stage ? "k_wgrad_gnn" : "k_wgrad_embed");
 }
@@ -860,6 +873,7 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
   if (blocks < 1) blocks = 1;
   a.n_adam_blocks = blocks;
   a.rowloss = m->rowloss; a.loss = m->loss_dev; a.loss_n_idx = lj.n_idx; a.loss_stride = lj.stride; a.loss_scale = lj.scale;
+  a.grad_direct = m->grads;
   a.loss_split = (lj.n_out == 1 && lj.n_idx > 16384) ? 64 : 1;
   a.loss_part = m->loss_part; a.loss_cnt = reinterpret_cast<unsigned*>(m->loss_part + 64);
   LAUNCH(m, do_adam ? (n_slabs > 0 ? "k_reduce_adam" : "k_adam") : "k_grad_reduce", k_reduce_adam,

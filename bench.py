@@ -95,6 +95,8 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
         "k_wgrad_embed": wg_embed,
         "k_wgrad_dense": 4 * R * (Dn + 2 * F + 80) + 4 * R * (80 + 40) + 4 * R * (40 + 20) + 4 * R * (20 + C),
     }
+    table["k_wgrad_all"] = table["k_wgrad_gnn"] + table["k_wgrad_dense"]        # every layer's weight gradient, one launch
+    table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"] - 4 * R * C  # fwd + Huber + bwd fused: q is not re-read
     return table.get(name)
 
 

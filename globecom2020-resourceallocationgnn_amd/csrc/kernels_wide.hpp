@@ -100,8 +100,10 @@ __global__ __launch_bounds__(256) void k_wide_gemm(WideGemmArgs a) {
 #pragma unroll 1
   for (int kc = 0; kc < n_chunks; ++kc) {
     const int buf = kc & 1;
-    const bool more = kc + 1 < n_chunks;
-    if (more) gload(kc + 1, va, vb0, vb1);
+    // unconditional (clamped) prefetch: a load under `if` makes hipcc wait for it at the join, i.e. BEFORE the
+    // MFMAs it is supposed to overlap; the last iteration re-loads its own chunk into the idle buffer
+    gload(min(kc + 1, n_chunks - 1), va, vb0, vb1);
+    __builtin_amdgcn_sched_barrier(0);
     float w[4][4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
@@ -116,7 +118,8 @@ __global__ __launch_bounds__(256) void k_wide_gemm(WideGemmArgs a) {
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) acc[rt][nt] = V2X_MFMA(w[nt][s], b[rt][s], acc[rt][nt]);
-    if (more) lstore(buf ^ 1, va, vb0, vb1);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(buf ^ 1, va, vb0, vb1);
     __syncthreads();
   }
 
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(256) void k_wide_wgrad(WideWgradArgs a) {
 #pragma unroll 1
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
-    const bool more = c + 1 < n_chunks;
-    if (more) gload(c + 1, vx, vd);
+    gload(min(c + 1, n_chunks - 1), vx, vd);          // unconditional, clamped (see k_wide_gemm)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < WW_TR / 4; ++s) {
       const float xa = sX[buf][(4 * s + kg) * WW_LD + 16 * wv + j];
@@ -223,7 +226,8 @@ __global__ __launch_bounds__(256) void k_wide_wgrad(WideWgradArgs a) {
 #pragma unroll
       for (int r = 0; r < WW_TR; ++r) bsum += sD[buf][r * WW_LD + tid];
     }
-    if (more) lstore(buf ^ 1, vx, vd);
+    __builtin_amdgcn_sched_barrier(0);
+    lstore(buf ^ 1, vx, vd);
     __syncthreads();
   }
 

@@ -32,6 +32,7 @@ class DeviceReplay(object):
         self._alloc = 0
         self._stage = []
         self._row_ptr = {}
+        self._bufs = {}
 
     # ------------------------------------------------------------------ storage
     def _grow(self, need):
@@ -91,9 +92,14 @@ class DeviceReplay(object):
         self._stage = []
 
     # ------------------------------------------------------------------ sampling
-    def _gather(self, src, idx_dev, k):
+    def _gather(self, src, idx_dev, k, name):
+        """Gather into a buffer that is REUSED for every minibatch of k transitions: stable device pointers let the
+        engine replay its captured hipGraph instead of re-capturing one per replay step."""
         torch = self.torch
-        out = torch.empty((k,) + tuple(src.shape[1:]), dtype=src.dtype, device=self.device)
+        key = (name, k)
+        if key not in self._bufs:
+            self._bufs[key] = torch.empty((k,) + tuple(src.shape[1:]), dtype=src.dtype, device=self.device)
+        out = self._bufs[key]
         row_bytes = src[0].numel() * src.element_size() if src.dim() > 1 else src.element_size()
         rc = self._lib.v2x_gather_rows(src.data_ptr(), idx_dev.data_ptr(), out.data_ptr(), k, row_bytes,
                                        current_stream_ptr(self.device.index))
@@ -118,11 +124,11 @@ class DeviceReplay(object):
         torch = self.torch
         k = len(idx)
         idx_dev = torch.from_numpy(self.logical_to_slot(idx)).to(self.device)
-        xe = self._gather(self.xe, idx_dev, k).view(k * self.n, 16)
-        xe_next = self._gather(self.xe_next, idx_dev, k).view(k * self.n, 16)
-        col = self._gather(self.col, idx_dev, k).view(-1)
-        action = self._gather(self.action, idx_dev, k)
-        reward = self._gather(self.reward, idx_dev, k)
+        xe = self._gather(self.xe, idx_dev, k, 'xe').view(k * self.n, 16)
+        xe_next = self._gather(self.xe_next, idx_dev, k, 'xe_next').view(k * self.n, 16)
+        col = self._gather(self.col, idx_dev, k, 'col').view(-1)
+        action = self._gather(self.action, idx_dev, k, 'action')
+        reward = self._gather(self.reward, idx_dev, k, 'reward')
         rp = self.row_ptr(k)
         mk = lambda t: DeviceBatch.from_tensors(k, self.n, t, rp, col, self.n_edges)
         return mk(xe), mk(xe_next), action, reward
@@ -130,7 +136,9 @@ class DeviceReplay(object):
     def dqn_targets(self, q, q_next, action, reward, gamma):
         """The target rule (BS_brain.py:684-692) on device: y = q with y[b, k, a[b, k]] = r[b] + gamma * max q'[b, k]."""
         k, n, Cc = action.shape[0], self.n, q.shape[1]
-        y = self.torch.empty_like(q)
+        if ('y', k) not in self._bufs:
+            self._bufs[('y', k)] = self.torch.empty_like(q)
+        y = self._bufs[('y', k)]
         rc = self._lib.v2x_dqn_targets(q.data_ptr(), q_next.data_ptr(), action.data_ptr(), reward.data_ptr(),
                                        C.c_double(float(gamma)), k, n, Cc, y.data_ptr(),
                                        current_stream_ptr(self.device.index))

@@ -259,8 +259,9 @@ __global__ __launch_bounds__(256) void k_agg_small(AggArgs a) {
   }
   const int nedges = e_end - e_begin;
   int cv[4];
+  const int e_safe = nedges > 0 ? e_begin : 0;        // an edge-less tile reads entry 0 (col_idx holds >= 1 entry)
 #pragma unroll
-  for (int p = 0; p < 4; ++p) cv[p] = a.col_idx[e_begin + min(tid + 256 * p, max(nedges - 1, 0))];   // col_idx holds >= 1 entry
+  for (int p = 0; p < 4; ++p) cv[p] = a.col_idx[e_safe + min(tid + 256 * p, max(nedges - 1, 0))];
 #pragma unroll
   for (int p = 0; p < 4; ++p) { V2X_PIN4(fv[p]); asm volatile("" : "+v"(cv[p])); }
   asm volatile("" : "+v"(rpv));

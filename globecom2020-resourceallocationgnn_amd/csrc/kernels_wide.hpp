@@ -31,13 +31,19 @@ struct WideGemmArgs {
   int n_idx, row_stride, base_mul, idx_base;
 };
 
-constexpr int WD_TM = 128, WD_TN = 64, WD_KC = 16, WD_LDA = WD_TN + 4, WD_LDB = WD_KC + 4;
+constexpr int WD_TM = 128, WD_KC = 16, WD_LDB = WD_KC + 4;
 
-template <bool TRANS>
-__global__ __launch_bounds__(256) void k_wide_gemm(WideGemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float sA[2][WD_KC * WD_LDA];   // weights  [k][n]
+// NT = output tile width in 16-column MFMA tiles (5: Dense-0's 80 outputs, 8: F = 128, 16: 256 columns).  The tile
+// spans the layer's WHOLE output width where it can: a 64-column tile made every activation row travel through
+// L2/HBM once per 64 output columns (4x at F = 256, 1.3 GB per launch at 100 links x 1024 graphs -- that traffic,
+// not the MFMA pipe, set the 278 us), and 16-column tiles x 16 give 128 MFMAs per wave between barriers instead of 32.
+template <bool TRANS, int NT>
+__global__ __launch_bounds__(256, 2) void k_wide_gemm(WideGemmArgs a) {
+  constexpr int TN = 16 * NT, LDA = TN + 4;
+  constexpr int PA = (64 * NT + 255) / 256;                      // float4 passes of the weight chunk [16][TN]
+  __shared__ __attribute__((aligned(16))) float sA[2][WD_KC * LDA];      // weights  [k][n]
   __shared__ __attribute__((aligned(16))) float sB[2][WD_TM * WD_LDB];   // activations [row][k]
-  const int slot = blockIdx.z, m0 = blockIdx.x * WD_TM, n0 = blockIdx.y * WD_TN;
+  const int slot = blockIdx.z, m0 = blockIdx.x * WD_TM, n0 = blockIdx.y * TN;
   const float* Wg = a.W + slot * a.slot_stride;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, kg = lane >> 4;
 
@@ -45,17 +51,9 @@ __global__ __launch_bounds__(256) void k_wide_gemm(WideGemmArgs a) {
   const int rB = tid >> 2, cB = (tid & 3) << 2;                 // activation rows rB and rB + 64, 4 k-columns
   const int64_t rowg0 = (int64_t)(a.idx_base + min(m0 + rB, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
   const int64_t rowg1 = (int64_t)(a.idx_base + min(m0 + rB + 64, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
-  // weights, forward: k row tid>>4, 4 output columns; transposed: output column tid>>2, 4 k values
-  const int kaF = tid >> 4, naF = (tid & 15) << 2;
-  const int naT = tid >> 2, kaT = (tid & 3) << 2;
-  const int colF = n0 + naF;
-  const bool okF = colF < a.n_real;
-  const int nT = n0 + naT;
-  const bool okT = nT < a.n_out;
-  const int wrowT = okT ? (nT < a.split ? nT : nT + a.skip) : 0;
 
   const int n_chunks = a.k_total / WD_KC;
-  auto gload = [&](int kc, float4& va, float4& vb0, float4& vb1) {
+  auto gload = [&](int kc, float4 (&va)[PA], float4& vb0, float4& vb1) {
     int kcol = kc * WD_KC;
     const float* p = a.seg[0].ptr; int st = a.seg[0].stride;
     if (a.n_seg > 1 && kcol >= a.seg[0].width) {
@@ -64,36 +62,50 @@ __global__ __launch_bounds__(256) void k_wide_gemm(WideGemmArgs a) {
     }
     vb0 = *reinterpret_cast<const float4*>(p + rowg0 * st + kcol + cB);
     vb1 = *reinterpret_cast<const float4*>(p + rowg1 * st + kcol + cB);
-    if (!TRANS) {
-      const int rr = real_row(a.pad, kc * WD_KC + kaF);
-      const bool ok = okF && rr >= 0;
-      const float4 t = *reinterpret_cast<const float4*>(Wg + (ok ? (int64_t)rr * a.n_real + colF : 0));
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int i = tid + 256 * q;
+      bool ok;
+      int64_t off;
+      if (!TRANS) {                        // k row i / (4 NT), 4 output columns
+        const int ka = i / (4 * NT), col = n0 + ((i % (4 * NT)) << 2);
+        const int rr = real_row(a.pad, kc * WD_KC + min(ka, WD_KC - 1));
+        ok = i < 64 * NT && col < a.n_real && rr >= 0;
+        off = (int64_t)rr * a.n_real + col;
+      } else {                             // output column i >> 2, 4 k values
+        const int nT = n0 + (i >> 2), ka = (i & 3) << 2;
+        ok = i < 64 * NT && nT < a.n_out;
+        off = (int64_t)(nT < a.split ? nT : nT + a.skip) * a.n_real + kc * WD_KC + ka;
+      }
+      const float4 t = *reinterpret_cast<const float4*>(Wg + (ok ? off : 0));
       const float mk = ok ? 1.f : 0.f;
-      va = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
-    } else {
-      const float4 t = *reinterpret_cast<const float4*>(Wg + (int64_t)wrowT * a.n_real + kc * WD_KC + kaT);
-      const float mk = okT ? 1.f : 0.f;
-      va = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
+      va[q] = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
     }
   };
-  auto lstore = [&](int buf, const float4& va, const float4& vb0, const float4& vb1) {
+  auto lstore = [&](int buf, const float4 (&va)[PA], const float4& vb0, const float4& vb1) {
     *reinterpret_cast<float4*>(&sB[buf][rB * WD_LDB + cB]) = vb0;
     *reinterpret_cast<float4*>(&sB[buf][(rB + 64) * WD_LDB + cB]) = vb1;
-    if (!TRANS) {
-      *reinterpret_cast<float4*>(&sA[buf][kaF * WD_LDA + naF]) = va;
-    } else {
-      sA[buf][(kaT + 0) * WD_LDA + naT] = va.x; sA[buf][(kaT + 1) * WD_LDA + naT] = va.y;
-      sA[buf][(kaT + 2) * WD_LDA + naT] = va.z; sA[buf][(kaT + 3) * WD_LDA + naT] = va.w;
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const int i = tid + 256 * q;
+      if (i >= 64 * NT) continue;
+      if (!TRANS) {
+        *reinterpret_cast<float4*>(&sA[buf][(i / (4 * NT)) * LDA + ((i % (4 * NT)) << 2)]) = va[q];
+      } else {
+        const int na = i >> 2, ka = (i & 3) << 2;
+        sA[buf][(ka + 0) * LDA + na] = va[q].x; sA[buf][(ka + 1) * LDA + na] = va[q].y;
+        sA[buf][(ka + 2) * LDA + na] = va[q].z; sA[buf][(ka + 3) * LDA + na] = va[q].w;
+      }
     }
   };
 
-  f32x4 acc[2][4];
+  f32x4 acc[2][NT];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 va, vb0, vb1;
+  float4 va[PA], vb0, vb1;
   gload(0, va, vb0, vb1);
   lstore(0, va, vb0, vb1);
   __syncthreads();
@@ -104,20 +116,19 @@ __global__ __launch_bounds__(256) void k_wide_gemm(WideGemmArgs a) {
     // MFMAs it is supposed to overlap; the last iteration re-loads its own chunk into the idle buffer
     gload(min(kc + 1, n_chunks - 1), va, vb0, vb1);
     __builtin_amdgcn_sched_barrier(0);
-    float w[4][4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) w[nt][s] = sA[buf][(4 * kg + s) * WD_LDA + nt * 16 + j];
     f32x4 b[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) b[rt] = ld4(&sB[buf][(32 * wv + 16 * rt + j) * WD_LDB + 4 * kg]);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < 4; ++s) {
+      float w[NT];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < NT; ++nt) w[nt] = sA[buf][(4 * kg + s) * LDA + nt * 16 + j];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) acc[rt][nt] = V2X_MFMA(w[nt][s], b[rt][s], acc[rt][nt]);
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) acc[rt][nt] = V2X_MFMA(w[nt], b[rt][s], acc[rt][nt]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     lstore(buf ^ 1, va, vb0, vb1);
     __syncthreads();
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(256) void k_wide_gemm(WideGemmArgs a) {
     if (idx >= a.n_idx) continue;
     const int64_t rowg = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = 0; nt < NT; ++nt) {
       const int col = n0 + nt * 16 + 4 * kg;
       if (col >= a.n_out) continue;
       f32x4 v = acc[rt][nt];
@@ -154,61 +165,81 @@ struct WideWgradArgs {
   int n_split, rows_per_split;           // rows_per_split is a multiple of 32
 };
 
-constexpr int WW_TR = 32, WW_LD = 64 + 4;
 
-__global__ __launch_bounds__(256) void k_wide_wgrad(WideWgradArgs a) {
-  __shared__ __attribute__((aligned(16))) float sX[2][WW_TR * WW_LD];
-  __shared__ __attribute__((aligned(16))) float sD[2][WW_TR * WW_LD];
+// KW = K-tile width (input features per workgroup: 64 or 128, a wave owns KW/64 strips of 16), NT = output tile width
+// in 16-column tiles (5: Dense-0, 8: F = 128, 16: 256 columns).  Whole-width output tiles for the same reason as in
+// k_wide_gemm: with 64 x 64 tiles every input tile was fetched once per 64 output columns and every dpre tile once
+// per 64 input features -- 1.9 GB per launch at 100 links x 1024 graphs x 256 features.
+template <int KW, int NT>
+__global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
+  constexpr int WW_TR = NT >= 16 ? 16 : 32;                      // rows per chunk (LDS budget: 2 workgroups per CU)
+  constexpr int KS = KW / 64, LDX = KW + 4, XP = KW * WW_TR / 1024;   // strips per wave, LDS stride, float4 passes of the X tile
+  constexpr int TN = 16 * NT, LDD = TN + 4, DP = (WW_TR * TN / 4 + 255) / 256;   // dpre tile [WW_TR][TN]
+  __shared__ __attribute__((aligned(16))) float sX[2][WW_TR * LDX];
+  __shared__ __attribute__((aligned(16))) float sD[2][WW_TR * LDD];
   const int slot = blockIdx.z / a.n_split, sp = blockIdx.z - slot * a.n_split;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, kg = lane >> 4;
   // K tile -> (segment, column offset, valid width)
   int kt = blockIdx.x;
   const float* xp = a.seg[0].ptr; int xst = a.seg[0].stride, xw = a.seg[0].width, kpad0 = a.seg_kpad[0];
   {
-    const int t0 = (a.seg[0].width + 63) >> 6;
+    const int t0 = (a.seg[0].width + KW - 1) / KW;
     if (a.n_seg > 1 && kt >= t0) {
       kt -= t0; xp = a.seg[1].ptr; xst = a.seg[1].stride; xw = a.seg[1].width; kpad0 = a.seg_kpad[1];
-      const int t1 = (a.seg[1].width + 63) >> 6;
+      const int t1 = (a.seg[1].width + KW - 1) / KW;
       if (a.n_seg > 2 && kt >= t1) { kt -= t1; xp = a.seg[2].ptr; xst = a.seg[2].stride; xw = a.seg[2].width; kpad0 = a.seg_kpad[2]; }
     }
   }
-  const int kcol0 = kt * 64, kw = min(64, xw - kcol0);
+  const int kcol0 = kt * KW, kw = min(KW, xw - kcol0);
   kpad0 += kcol0;
-  const int n0 = blockIdx.y * 64;
+  const int n0 = blockIdx.y * TN;
   const int i_begin = sp * a.rows_per_split, i_end = min(i_begin + a.rows_per_split, a.n_idx);
   const int n_chunks = (max(i_end - i_begin, 0) + WW_TR - 1) / WW_TR;
 
-  const int rL = tid >> 4, cL = (tid & 15) << 2;                // rows rL and rL + 16, 4 columns
-  const bool okx = cL < kw, okd = n0 + cL < a.n_real;
-  const int xcol = kcol0 + (okx ? cL : 0), dcol = okd ? n0 + cL : 0;
-  auto gload = [&](int c, float4 (&vx)[2], float4 (&vd)[2]) {
+  auto gload = [&](int c, float4 (&vx)[XP], float4 (&vd)[DP]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int idx = i_begin + c * WW_TR + rL + 16 * h;
-      const float mrow = idx < i_end ? 1.f : 0.f;
+    for (int p = 0; p < XP; ++p) {
+      const int i = tid + 256 * p, r = i / (KW / 4), cx = (i % (KW / 4)) << 2;
+      const int idx = i_begin + c * WW_TR + r;
+      const bool okx = cx < kw;
       const int64_t rowg = (int64_t)(a.idx_base + min(idx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
-      const float4 x = *reinterpret_cast<const float4*>(xp + rowg * xst + xcol);
-      const float4 d = *reinterpret_cast<const float4*>(a.dpre + rowg * a.d_stride + dcol);
-      const float mx = okx ? 1.f : 0.f, md = okd ? mrow : 0.f;
-      vx[h] = make_float4(x.x * mx, x.y * mx, x.z * mx, x.w * mx);
-      vd[h] = make_float4(d.x * md, d.y * md, d.z * md, d.w * md);
+      const float4 x = *reinterpret_cast<const float4*>(xp + rowg * xst + kcol0 + (okx ? cx : 0));
+      const float mx = okx ? 1.f : 0.f;              // (rows past the split are zeroed on the dpre side)
+      vx[p] = make_float4(x.x * mx, x.y * mx, x.z * mx, x.w * mx);
+    }
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+      const int i = tid + 256 * p, r = min(i / (TN / 4), WW_TR - 1), cd = n0 + ((i % (TN / 4)) << 2);
+      const int idx = i_begin + c * WW_TR + r;
+      const bool okd = i < WW_TR * TN / 4 && cd < a.n_real && idx < i_end;
+      const int64_t rowg = (int64_t)(a.idx_base + min(idx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
+      const float4 d = *reinterpret_cast<const float4*>(a.dpre + rowg * a.d_stride + (cd < a.n_real ? cd : 0));
+      const float md = okd ? 1.f : 0.f;
+      vd[p] = make_float4(d.x * md, d.y * md, d.z * md, d.w * md);
     }
   };
-  auto lstore = [&](int buf, const float4 (&vx)[2], const float4 (&vd)[2]) {
+  auto lstore = [&](int buf, const float4 (&vx)[XP], const float4 (&vd)[DP]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      *reinterpret_cast<float4*>(&sX[buf][(rL + 16 * h) * WW_LD + cL]) = vx[h];
-      *reinterpret_cast<float4*>(&sD[buf][(rL + 16 * h) * WW_LD + cL]) = vd[h];
+    for (int p = 0; p < XP; ++p) {
+      const int i = tid + 256 * p, r = i / (KW / 4), cx = (i % (KW / 4)) << 2;
+      *reinterpret_cast<float4*>(&sX[buf][r * LDX + cx]) = vx[p];
+    }
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+      const int i = tid + 256 * p;
+      if (i < WW_TR * TN / 4) *reinterpret_cast<float4*>(&sD[buf][(i / (TN / 4)) * LDD + ((i % (TN / 4)) << 2)]) = vd[p];
     }
   };
 
-  f32x4 acc[4];
+  f32x4 acc[KS][NT];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;                                             // column n0 + tid (threads < 64 of the kt == 0 tile)
-  const bool do_bias = blockIdx.x == 0 && tid < 64;
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[ks][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;                                             // column n0 + tid of the kt == 0 tile
+  const bool do_bias = blockIdx.x == 0 && tid < TN;
 
-  float4 vx[2], vd[2];
+  float4 vx[XP], vd[DP];
   if (n_chunks > 0) { gload(0, vx, vd); lstore(0, vx, vd); }
   __syncthreads();
 #pragma unroll 1
@@ -218,32 +249,40 @@ __global__ __launch_bounds__(256) void k_wide_wgrad(WideWgradArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < WW_TR / 4; ++s) {
-      const float xa = sX[buf][(4 * s + kg) * WW_LD + 16 * wv + j];
+      float xa[KS], db[NT];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = V2X_MFMA(xa, sD[buf][(4 * s + kg) * WW_LD + nt * 16 + j], acc[nt]);
+      for (int ks = 0; ks < KS; ++ks) xa[ks] = sX[buf][(4 * s + kg) * LDX + 64 * ks + 16 * wv + j];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) db[nt] = sD[buf][(4 * s + kg) * LDD + nt * 16 + j];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) acc[ks][nt] = V2X_MFMA(xa[ks], db[nt], acc[ks][nt]);
     }
     if (do_bias) {
 #pragma unroll
-      for (int r = 0; r < WW_TR; ++r) bsum += sD[buf][r * WW_LD + tid];
+      for (int r = 0; r < WW_TR; ++r) bsum += sD[buf][r * LDD + tid];
     }
     __builtin_amdgcn_sched_barrier(0);
     lstore(buf ^ 1, vx, vd);
     __syncthreads();
   }
 
-  // lane holds dW[kpad0 + 16*wv + 4*kg + r][n0 + nt*16 + j]
+  // lane holds dW[kpad0 + 64*ks + 16*wv + 4*kg + r][n0 + nt*16 + j]
   float* dst = a.slab + (int64_t)sp * a.slab_stride + a.layer_off + slot * a.slot_stride;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int kk = 16 * wv + 4 * kg + r;
-    const int rr = kk < kw ? real_row(a.pad, kpad0 + kk) : -1;
-    if (rr < 0) continue;
+  for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int col = n0 + nt * 16 + j;
-      if (col < a.n_real) dst[(int64_t)rr * a.n_real + col] = acc[nt][r];
+    for (int r = 0; r < 4; ++r) {
+      const int kk = 64 * ks + 16 * wv + 4 * kg + r;
+      const int rr = kk < kw ? real_row(a.pad, kpad0 + kk) : -1;
+      if (rr < 0) continue;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = n0 + nt * 16 + j;
+        if (col < a.n_real) dst[(int64_t)rr * a.n_real + col] = acc[ks][nt][r];
+      }
     }
-  }
   if (do_bias && n0 + tid < a.n_real) dst[(int64_t)a.pad.k_real * a.n_real + n0 + tid] = bsum;
 }
 

@@ -463,11 +463,22 @@ void set_idx(WideGemmArgs& a, const IdxMap& x) {
   a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.idx_base = x.idx_base;
 }
 
+// Output tile width in 16-column tiles.  Measured at 100 links x 1024 graphs x 256 features: whole-width (256-column)
+// tiles cut the operand re-reads 4x but leave 800 workgroups at 2 waves/SIMD and are SLOWER for the node update and
+// its data gradient (343 / 295 us vs 276 / 253 us with 64-column tiles at 5 waves/SIMD: L2 absorbs the re-reads);
+// Dense-0's 80 columns are one 5-tile strip instead of a 64 + 16 split (154 -> 110 us).
+int wide_nt(int n_out) { return n_out <= 80 ? 5 : 4; }
+
 int launch_wide_gemm(v2x_model* m, hipStream_t st, WideGemmArgs& a, int grid_z, bool trans, const char* name) {
-  const dim3 grid((a.n_idx + WD_TM - 1) / WD_TM, (a.n_out + WD_TN - 1) / WD_TN, grid_z);
-  if (trans) { auto k = k_wide_gemm<true>; LAUNCH(m, name, k, grid, 0, st, a); }
-  else { auto k = k_wide_gemm<false>; LAUNCH(m, name, k, grid, 0, st, a); }
-  return V2X_OK;
+  const int nt = wide_nt(a.n_out);
+  const dim3 grid((a.n_idx + WD_TM - 1) / WD_TM, (a.n_out + 16 * nt - 1) / (16 * nt), grid_z);
+#define V2X_WIDE_GEMM(T, NTV) { auto k = k_wide_gemm<T, NTV>; LAUNCH(m, name, k, grid, 0, st, a); return V2X_OK; }
+  if (!trans) {
+    if (nt == 5) V2X_WIDE_GEMM(false, 5)
+    V2X_WIDE_GEMM(false, 4)
+  }
+  V2X_WIDE_GEMM(true, 4)
+#undef V2X_WIDE_GEMM
 }
 
 // out = act([seg...] W + b) of layer `ld`
@@ -497,9 +508,10 @@ int wide_dgrad(v2x_model* m, hipStream_t st, const LayerDesc& ld, const IdxMap& 
   return launch_wide_gemm(m, st, a, x.grid_y, true, name);
 }
 
-// row splits of a wide weight gradient: enough workgroups to fill the chip a few times over
+// row splits of a wide weight gradient: enough workgroups to fill the chip; one split (= the gradient is written
+// in place, no slab to sum) as soon as tiles x slots alone do that
 int wide_splits(int n_idx, int n_tiles, int n_slots) {
-  int sp = (4 * n_cus() + n_tiles * n_slots - 1) / (n_tiles * n_slots);
+  int sp = (3 * n_cus() / 2 + n_tiles * n_slots - 1) / (n_tiles * n_slots);
   const int max_sp = (n_idx + 255) / 256;                      // at least 256 rows per split
   if (sp > max_sp) sp = max_sp;
   return sp < 1 ? 1 : sp;
@@ -509,17 +521,23 @@ int wide_wgrad(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, con
                int n_seg, const float* dpre, int d_stride, const char* name, int zero_row0 = 0, int zero_rows = 0) {
   WideWgradArgs a;
   memset(&a, 0, sizeof(a));
+  int k_width = 0;
+  for (int i = 0; i < n_seg; ++i) k_width += segs[i].width;
+  // weight gradients: 128 input features x the whole output width per workgroup (324 -> 315 us for a GNN stage,
+  // 180 -> 123 us for Dense-0); the 16-wide embed layer keeps 64 x 64 tiles
+  const int KW = k_width <= 64 ? 64 : 128;
   int kt = 0;
-  for (int i = 0; i < n_seg; ++i) { a.seg[i] = segs[i]; a.seg_kpad[i] = seg_kpad[i]; kt += (segs[i].width + 63) / 64; }
+  for (int i = 0; i < n_seg; ++i) { a.seg[i] = segs[i]; a.seg_kpad[i] = seg_kpad[i]; kt += (segs[i].width + KW - 1) / KW; }
   a.n_seg = n_seg;
   a.dpre = dpre; a.d_stride = d_stride; a.n_real = ld.n_out; a.pad = ld.pad;
   a.slab = m->slab; a.slab_stride = m->P; a.layer_off = ld.off; a.slot_stride = ld.slot_stride;
   a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.idx_base = x.idx_base;
-  const int nt = (ld.n_out + 63) / 64;
+  const int ntw = KW == 64 ? 4 : (ld.n_out <= 80 ? 5 : (ld.n_out <= 128 ? 8 : 16));   // output tile = ntw x 16 columns
+  const int nt = (ld.n_out + 16 * ntw - 1) / (16 * ntw);
   const int sp = wide_splits(x.n_idx, kt * nt, x.grid_y);
   if (sp > m->slab_cap) FAIL(m, V2X_ESTATE, "wide wgrad: slabs not pre-sized (%d > %d)", sp, m->slab_cap);
   a.n_split = sp;
-  a.rows_per_split = ((x.n_idx + sp - 1) / sp + WW_TR - 1) / WW_TR * WW_TR;
+  a.rows_per_split = ((x.n_idx + sp - 1) / sp + 31) / 32 * 32;
   ld.n_slabs = sp;
   if (sp == 1) {            // no partial sums to add: write the gradient buffer itself (saves a 2 x P-float round trip)
     a.slab = m->grads;
@@ -533,7 +551,11 @@ int wide_wgrad(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, con
       hipLaunchKernelGGL(k_zero_rows, zg, dim3(256), 0, st, dst, ld.slot_stride, count);
     }
   }
-  LAUNCH(m, name, k_wide_wgrad, dim3(kt, nt, x.grid_y * sp), 0, st, a);
+  const dim3 grid(kt, nt, x.grid_y * sp);
+  if (ntw == 4) { auto k = k_wide_wgrad<64, 4>; LAUNCH(m, name, k, grid, 0, st, a); }
+  else if (ntw == 5) { auto k = k_wide_wgrad<128, 5>; LAUNCH(m, name, k, grid, 0, st, a); }
+  else if (ntw == 8) { auto k = k_wide_wgrad<128, 8>; LAUNCH(m, name, k, grid, 0, st, a); }
+  else { auto k = k_wide_wgrad<128, 16>; LAUNCH(m, name, k, grid, 0, st, a); }
   return V2X_OK;
 }
 
@@ -1042,7 +1064,7 @@ GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
 int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   int chunk, nc = 1;
   for (int rows : {768, 1024}) nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
-  if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 2, n_slots));     // the fewest tiles (embed layer) split most
+  if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 1, n_slots));     // the fewest tiles (one) split most
   return nc + 1;
 }
 

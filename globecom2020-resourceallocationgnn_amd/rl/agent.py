@@ -37,7 +37,8 @@ class Memory(object):
         numpy RNG calls as the reference (:261, :268)."""
         if len(self.samples) >= n:
             return np.random.choice(len(self.samples), n, replace=False)
-        return np.array([np.random.randint(0, len(self.samples)) for _ in range(n)])
+        # (one vectorised call consumes the legacy generator exactly like n scalar randint calls; checked in the tests)
+        return np.random.randint(0, len(self.samples), size=n)
 
     def sample(self, n):
         return [self.samples[i] for i in self.sample_indices(n)]

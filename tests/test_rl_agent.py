@@ -94,6 +94,12 @@ def test_memory_capacity_and_sampling_branches():
     assert sorted(s[0] for s in m.sample(5)) == [3, 4, 5, 6, 7]          # without replacement
     assert len(m.sample(9)) == 9                                         # with replacement
     assert Memory(5).samples == []                                       # storage is per instance
+    # the vectorised with-replacement draw is the reference's scalar loop (BS_brain.py:266-269), same RNG consumption
+    np.random.seed(9)
+    ref = [np.random.randint(0, len(m.samples)) for _ in range(40)]
+    after = np.random.random()
+    np.random.seed(9)
+    assert list(m.sample_indices(40)) == ref and np.random.random() == after
 
 
 def test_epsilon_schedule_and_random_actions():

@@ -515,6 +515,11 @@ struct MlpArgs {
   float* dq; float* dz1; float* dz2; float* dz3; float* gha;   // gha[R][2F] = [dh | dagg]
   float* rowloss;                                       // [R] sum_c huber(y - q)
   int n_idx, row_stride, base_mul, idx_base;
+  // z2, z3, dz2, dz3, dq and rowloss are only ever touched slot by slot (this kernel writes them, k_wgrad reads
+  // them), so they are stored SLOT-MAJOR: row(slot, idx) = slot * srow_stride + idx.  In graph-major order a slot's
+  // rows lie N rows apart and a 16..160-byte row costs a whole 128-byte line per access (measured: 30 % more HBM
+  // traffic than the algorithmic bytes in the weight-gradient launch).  Shared weights: one slot, identical layout.
+  int64_t srow_stride;
 };
 
 template <int F>    // F == 0: "tail" form without the Dense-0 image (wide features: Dense-0 runs in k_wide_gemm)
@@ -656,6 +661,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd(MlpArgs a) {
   auto compute = [&](int t, const MlpFwdIn<F>& in) {
     const bool valid = t * 16 + j < a.n_idx;
     const int64_t row = in.row;
+    const int64_t srow = (int64_t)slot * a.srow_stride + a.idx_base + min(t * 16 + j, a.n_idx - 1);
     // ---- Dense 0: [2F+9] -> 80, relu
     f32x4 z1[1][5];
     if constexpr (F > 0) {
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd(MlpArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       z2[0][nt] = relu4(z2[0][nt] + ld4(smem + L::B2 + nt * 16 + 4 * kg));
-      if (valid && nt * 16 + 4 * kg < H2) st4(a.z2 + row * H2 + nt * 16 + 4 * kg, z2[0][nt]);
+      if (valid && nt * 16 + 4 * kg < H2) st4(a.z2 + srow * H2 + nt * 16 + 4 * kg, z2[0][nt]);
     }
     // ---- Dense 2: 40 -> 20 (32 padded), relu
     f32x4 z3[1][2];
@@ -701,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd(MlpArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       z3[0][nt] = relu4(z3[0][nt] + ld4(smem + L::B3 + nt * 16 + 4 * kg));
-      if (valid && nt * 16 + 4 * kg < H3) st4(a.z3 + row * H3 + nt * 16 + 4 * kg, z3[0][nt]);
+      if (valid && nt * 16 + 4 * kg < H3) st4(a.z3 + srow * H3 + nt * 16 + 4 * kg, z3[0][nt]);
     }
     // ---- Dense 3: 20 -> C (16 padded), linear
     f32x4 qa[1][1];
@@ -748,18 +754,20 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
     const int idx = min(t * 16 + j, a.n_idx - 1);
     const int64_t row = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
     in.row = row;
+    const int64_t srow = (int64_t)slot * a.srow_stride + a.idx_base + idx;
     in.q = ld4(a.q + row * a.C + cq);
     in.y = ld4(a.y + row * a.C + cq);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) in.z3[nt] = ld4(a.z3 + row * H3 + c3[nt]);
+    for (int nt = 0; nt < 2; ++nt) in.z3[nt] = ld4(a.z3 + srow * H3 + c3[nt]);
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) in.z2[nt] = ld4(a.z2 + row * H2 + c2[nt]);
+    for (int nt = 0; nt < 3; ++nt) in.z2[nt] = ld4(a.z2 + srow * H2 + c2[nt]);
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) in.z1[nt] = ld4(a.z1 + row * H1 + nt * 16 + 4 * kg);
   };
   auto compute = [&](int t, const MlpBwdIn<F>& in) {
     const bool valid = t * 16 + j < a.n_idx;
     const int64_t row = in.row;
+    const int64_t srow = (int64_t)slot * a.srow_stride + a.idx_base + min(t * 16 + j, a.n_idx - 1);
     f32x4 g4[1];        // dq block (16 wide, only channels < C non-zero)
     g4[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (4 * kg < a.C) {
@@ -772,8 +780,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
         g4[0][c] = fminf(fmaxf(err, -1.f), 1.f) * a.inv_denom;
       }
       if (valid) {
-        st4(a.dq + row * a.C + 4 * kg, g4[0]);
-        a.rowloss[row] = ls;      // C == 4: exactly one lane (kg == 0) per row
+        st4(a.dq + srow * a.C + 4 * kg, g4[0]);
+        a.rowloss[srow] = ls;      // C == 4: exactly one lane (kg == 0) per row
       }
     }
     // ---- Dense 3 backward: dz3 = (dq . W4^T) * (z3 > 0)
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
     for (int nt = 0; nt < 2; ++nt) {
       const bool in_range = nt * 16 + 4 * kg < H3;
       d3[nt][0] = in_range ? gate4(d3[nt][0], in.z3[nt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (valid && in_range) st4(a.dz3 + row * H3 + nt * 16 + 4 * kg, d3[nt][0]);
+      if (valid && in_range) st4(a.dz3 + srow * H3 + nt * 16 + 4 * kg, d3[nt][0]);
     }
     // ---- Dense 2 backward: dz2 = (dz3 . W3^T) * (z2 > 0)
     f32x4 d2[3][1];
@@ -798,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
     for (int nt = 0; nt < 3; ++nt) {
       const bool in_range = nt * 16 + 4 * kg < H2;
       d2[nt][0] = in_range ? gate4(d2[nt][0], in.z2[nt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (valid && in_range) st4(a.dz2 + row * H2 + nt * 16 + 4 * kg, d2[nt][0]);
+      if (valid && in_range) st4(a.dz2 + srow * H2 + nt * 16 + 4 * kg, d2[nt][0]);
     }
     // ---- Dense 1 backward: dz1 = (dz2 . W2^T) * (z1 > 0)
     f32x4 d1[5][1];
@@ -865,6 +873,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
   auto compute = [&](int t, const MlpTrainIn<F>& in) {
     const bool valid = t * 16 + j < a.n_idx;
     const int64_t row = in.row;
+    const int64_t srow = (int64_t)slot * a.srow_stride + a.idx_base + min(t * 16 + j, a.n_idx - 1);
     // ================= forward
     f32x4 z1[1][5];
 #pragma unroll
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       z2[0][nt] = relu4(z2[0][nt] + ld4(smem + L::B2 + nt * 16 + 4 * kg));
-      if (valid && nt * 16 + 4 * kg < H2) st4(a.z2 + row * H2 + nt * 16 + 4 * kg, z2[0][nt]);
+      if (valid && nt * 16 + 4 * kg < H2) st4(a.z2 + srow * H2 + nt * 16 + 4 * kg, z2[0][nt]);
     }
     f32x4 z3[1][2];
 #pragma unroll
@@ -903,7 +912,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       z3[0][nt] = relu4(z3[0][nt] + ld4(smem + L::B3 + nt * 16 + 4 * kg));
-      if (valid && nt * 16 + 4 * kg < H3) st4(a.z3 + row * H3 + nt * 16 + 4 * kg, z3[0][nt]);
+      if (valid && nt * 16 + 4 * kg < H3) st4(a.z3 + srow * H3 + nt * 16 + 4 * kg, z3[0][nt]);
     }
     f32x4 qa[1][1];
     qa[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -926,8 +935,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
         g4[c] = fminf(fmaxf(err, -1.f), 1.f) * a.inv_denom;
       }
       if (valid) {
-        st4(a.dq + row * a.C + 4 * kg, g4);
-        a.rowloss[row] = ls;
+        st4(a.dq + srow * a.C + 4 * kg, g4);
+        a.rowloss[srow] = ls;
       }
     }
     const auto lin = [](int nt) { return nt * 16; };
@@ -939,7 +948,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
     for (int nt = 0; nt < 2; ++nt) {
       const bool in_range = nt * 16 + 4 * kg < H3;
       d3[nt][0] = in_range ? gate4(d3[nt][0], z3[0][nt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (valid && in_range) st4(a.dz3 + row * H3 + nt * 16 + 4 * kg, d3[nt][0]);
+      if (valid && in_range) st4(a.dz3 + srow * H3 + nt * 16 + 4 * kg, d3[nt][0]);
     }
     f32x4 d2[3][1];
 #pragma unroll
@@ -950,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
     for (int nt = 0; nt < 3; ++nt) {
       const bool in_range = nt * 16 + 4 * kg < H2;
       d2[nt][0] = in_range ? gate4(d2[nt][0], z2[0][nt]) : (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (valid && in_range) st4(a.dz2 + row * H2 + nt * 16 + 4 * kg, d2[nt][0]);
+      if (valid && in_range) st4(a.dz2 + srow * H2 + nt * 16 + 4 * kg, d2[nt][0]);
     }
     f32x4 d1[5][1];
 #pragma unroll
@@ -984,7 +993,8 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
 // k_wgrad : dW[k][n] = sum_rows in[row][k] * dpre[row][n],  db[n] = sum_rows dpre[row][n]
 //           per (row-chunk, slot) partial written to a slab; k_reduce_adam sums the slabs
 // =====================================================================================
-struct WgSeg { const float* ptr; int stride; int width; int col; };   // width real cols, col = padded K offset
+struct WgSeg { const float* ptr; int stride; int width; int col; int slot_major; };   // width real cols, col = padded K offset;
+                                                                                     // slot_major: rows stored slot * srow_stride + idx (MlpArgs)
 struct WgradArgs {
   WgSeg seg[3]; int n_seg;
   const float* dpre; int d_stride; int n_real;    // dpre[R][n_real]
@@ -997,6 +1007,7 @@ struct WgradArgs {
   int idx_base, chunk_base;                       // sub-range of the batch; first slab index of this launch
   int n_chunks;                                   // workgroups (slabs) of THIS role; blockIdx.x >= n_chunks exits
   int kind;                                       // WG_KIND_*: selects the compile-time operand widths
+  int dpre_slot_major; int srow_stride;           // row layout of dpre / of slot-major segments
 };
 
 constexpr int WG_TR = 16;        // rows per MFMA block (chunk sizes are multiples of it)
@@ -1029,7 +1040,7 @@ struct WgOperand {
 
 // source of one operand: wave-uniform base + row stride, real width (columns >= width are clamped: the dW entries
 // they feed are never written)
-struct WgSrc { gfloat_p p; unsigned stride; int width; };
+struct WgSrc { gfloat_p p; unsigned stride; int width; unsigned rs, off; };   // row(idx) = idx * rs + off
 
 template <int W>
 __device__ __forceinline__ void wg_load(WgOperand<W>& o, const WgSrc& src, unsigned row, int s, int j, float mk) {
@@ -1075,8 +1086,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     src[i].p = (gfloat_p)(have ? a.seg[i].ptr : a.zeros);
     src[i].stride = have ? a.seg[i].stride : 0;
     src[i].width = have ? a.seg[i].width : 64;               // zero buffer: 64 floats, stride 0
+    const bool sm = have && a.seg[i].slot_major;
+    src[i].rs = sm ? 1u : (unsigned)a.row_stride;
+    src[i].off = sm ? (unsigned)slot * (unsigned)a.srow_stride : (unsigned)slot * (unsigned)a.base_mul;
   }
   srcn.p = (gfloat_p)a.dpre; srcn.stride = a.d_stride; srcn.width = a.n_real;
+  srcn.rs = a.dpre_slot_major ? 1u : (unsigned)a.row_stride;
+  srcn.off = a.dpre_slot_major ? (unsigned)slot * (unsigned)a.srow_stride : (unsigned)slot * (unsigned)a.base_mul;
 
   f32x4 acc[KT][NT];
 #pragma unroll
@@ -1105,15 +1121,15 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   };
   const int n_rows_here = max(i_end - i_begin, 0);
   const int n_full = n_rows_here / WG_TR;
-  const unsigned row_lane0 = (unsigned)(a.idx_base + i_begin + 4 * kg) * a.row_stride + slot * a.base_mul;
+  const unsigned idx_lane0 = (unsigned)(a.idx_base + i_begin + 4 * kg);
   auto load_full = [&](int blk, Block& b) {                      // full block: no clamps on rows, no masks
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const unsigned row = row_lane0 + (unsigned)(blk * WG_TR + s) * a.row_stride;
-      wg_load<K0>(b.k0, src[0], row, s, j, 1.f);
-      wg_load<K1>(b.k1, src[1], row, s, j, 1.f);
-      wg_load<K2>(b.k2, src[2], row, s, j, 1.f);
-      wg_load<NW>(b.n, srcn, row, s, j, 1.f);
+      const unsigned idx = idx_lane0 + (unsigned)(blk * WG_TR + s);
+      wg_load<K0>(b.k0, src[0], idx * src[0].rs + src[0].off, s, j, 1.f);
+      wg_load<K1>(b.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
+      wg_load<K2>(b.k2, src[2], idx * src[2].rs + src[2].off, s, j, 1.f);
+      wg_load<NW>(b.n, srcn, idx * srcn.rs + srcn.off, s, j, 1.f);
     }
   };
 
@@ -1185,11 +1201,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     for (int s = 0; s < 4; ++s) {
       const int ridx = i_begin + n_full * WG_TR + 4 * kg + s;
       const float mk = ridx < i_end ? 1.f : 0.f;                 // rows past the chunk contribute 0
-      const unsigned row = (unsigned)(a.idx_base + min(ridx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
-      wg_load<K0>(b0.k0, src[0], row, s, j, 1.f);
-      wg_load<K1>(b0.k1, src[1], row, s, j, 1.f);
-      wg_load<K2>(b0.k2, src[2], row, s, j, 1.f);
-      wg_load<NW>(b0.n, srcn, row, s, j, mk);
+      const unsigned idx = (unsigned)(a.idx_base + min(ridx, a.n_idx - 1));
+      wg_load<K0>(b0.k0, src[0], idx * src[0].rs + src[0].off, s, j, 1.f);
+      wg_load<K1>(b0.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
+      wg_load<K2>(b0.k2, src[2], idx * src[2].rs + src[2].off, s, j, 1.f);
+      wg_load<NW>(b0.n, srcn, idx * srcn.rs + srcn.off, s, j, mk);
     }
     mfma_block(b0);
   }
@@ -1308,6 +1324,7 @@ struct AdamArgs {
   // blocks [n_adam_blocks, gridDim.x) reduce the per-row Huber sums to per-output means
   int n_adam_blocks;
   const float* rowloss; float* loss; int loss_n_idx, loss_stride; float loss_scale;
+  int64_t loss_slot_stride;                              // rowloss index of (output slot, i) = slot * loss_slot_stride + i * loss_stride
   int loss_split; float* loss_part; unsigned* loss_cnt;  // ranges per output (> 1 only with a single output)
   const float* grad_direct;                              // where slab-less layers left their gradient
   int groups;                                            // threads per float4 column (1, 4 or 16): split of the slab sum
@@ -1322,7 +1339,7 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
     const int per = (a.loss_n_idx + a.loss_split - 1) / a.loss_split;
     const int i1 = min((part + 1) * per, a.loss_n_idx);
     float s = 0.f;
-    for (int i = part * per + threadIdx.x; i < i1; i += 256) s += a.rowloss[(int64_t)i * a.loss_stride + slot];
+    for (int i = part * per + threadIdx.x; i < i1; i += 256) s += a.rowloss[(int64_t)i * a.loss_stride + (int64_t)slot * a.loss_slot_stride];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -1425,11 +1442,11 @@ __global__ __launch_bounds__(256) void k_adam_scalar(float* p, const float* g, f
 
 // per-output Huber mean: loss[k] = sum_b rowloss[b*N + k]   (already scaled by 1/(B*C) here)
 __global__ __launch_bounds__(256) void k_loss_reduce(const float* rowloss, float* loss, int n_idx,
-                                                     int row_stride, float inv_denom) {
+                                                     int row_stride, int64_t slot_stride, float inv_denom) {
   __shared__ float red[256];
   const int slot = blockIdx.x;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n_idx; i += 256) s += rowloss[(int64_t)i * row_stride + slot];
+  for (int i = threadIdx.x; i < n_idx; i += 256) s += rowloss[(int64_t)i * row_stride + slot * slot_stride];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {

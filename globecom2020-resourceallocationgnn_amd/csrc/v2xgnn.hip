@@ -628,8 +628,13 @@ int launch_dgrad(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const
   FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
 }
 
+// rows per slot of the slot-major MLP internals (z2, z3, dz2, dz3, dq, rowloss): the workspace capacity, so that the
+// kernel that writes them and the weight-gradient launch that reads them agree whatever the batch size
+int64_t srow_stride(const v2x_model* m) { return m->S == 1 ? 0 : m->cap_rows / m->N; }
+
 void mlp_args(v2x_model* m, MlpArgs& a, const IdxMap& x, const float* xe, const float* h, const float* agg) {
   memset(&a, 0, sizeof(a));
+  a.srow_stride = srow_stride(m);
   a.h = h; a.xe = xe; a.agg = agg;
   for (int i = 0; i < 4; ++i) { a.W[i] = m->params + m->dense[i].off; a.slot_stride[i] = m->dense[i].slot_stride; }
   a.C = m->C;
@@ -715,6 +720,8 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
   a.slab = m->slab; a.slab_stride = m->P; a.layer_off = ld.off; a.slot_stride = ld.slot_stride;
   a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.chunk = chunk;
   a.idx_base = x.idx_base; a.chunk_base = 0; a.n_chunks = nc; a.kind = kind;
+  a.dpre_slot_major = kind >= WG_KIND_DENSE1 ? 1 : 0;      // dz2, dz3, dq (MlpArgs::srow_stride)
+  a.srow_stride = (int)srow_stride(m);
   a.zeros = m->zero_buf;
   return V2X_OK;
 }
@@ -752,8 +759,8 @@ int wgrad_gnn_role(v2x_model* m, int stage, const IdxMap& x, int total_work, con
   const int F = m->F;
   WgSeg s[3];
   int n = 0;
-  if (stage > 0) { s[n++] = WgSeg{h_prev, F, F, 0}; s[n++] = WgSeg{xe, XE, XE, F}; s[n++] = WgSeg{agg_prev, F, F, F + XE}; }
-  else { s[n++] = WgSeg{xe, XE, XE, 0}; s[n++] = WgSeg{agg_prev /* neighbour-init or null */, F, F, XE}; }
+  if (stage > 0) { s[n++] = WgSeg{h_prev, F, F, 0, 0}; s[n++] = WgSeg{xe, XE, XE, F, 0}; s[n++] = WgSeg{agg_prev, F, F, F + XE, 0}; }
+  else { s[n++] = WgSeg{xe, XE, XE, 0, 0}; s[n++] = WgSeg{agg_prev /* neighbour-init or null */, F, F, XE, 0}; }
   return wgrad_role(m, m->gnn[stage], stage ? WG_KIND_GNN : WG_KIND_EMBED, x, total_work, s, n, dpre, F, a);
 }
 
@@ -815,21 +822,21 @@ int wgrad_mlp(v2x_model* m, hipStream_t st, const IdxMap& x, const float* xe, co
     WideSeg w0[3] = {WideSeg{h, F, F}, WideSeg{xe, XE, XE}, WideSeg{agg, F, F}};
     const int kp[3] = {0, F, F + XE};
     CHK(wide_wgrad(m, st, m->dense[0], x, w0, kp, 3, m->dz1, H1, "k_wgrad_dense0"));
-    WgSeg t1[1] = {WgSeg{m->z1, H1, H1, 0}};
+    WgSeg t1[1] = {WgSeg{m->z1, H1, H1, 0, 0}};
     CHK(wgrad_role(m, m->dense[1], WG_KIND_DENSE1, x, total, t1, 1, m->dz2, H2, mu.w[0]));
-    WgSeg t2[1] = {WgSeg{m->z2, H2, H2, 0}};
+    WgSeg t2[1] = {WgSeg{m->z2, H2, H2, 0, 1}};
     CHK(wgrad_role(m, m->dense[2], WG_KIND_DENSE2, x, total, t2, 1, m->dz3, H3, mu.w[1]));
-    WgSeg t3[1] = {WgSeg{m->z3, H3, H3, 0}};
+    WgSeg t3[1] = {WgSeg{m->z3, H3, H3, 0, 1}};
     CHK(wgrad_role(m, m->dense[3], WG_KIND_DENSE3, x, total, t3, 1, m->dq, m->C, mu.w[2]));
     return launch_wgrad_multi(m, st, x, mu, 3, "k_wgrad_dense");
   }
-  WgSeg s0[3] = {WgSeg{h, F, F, 0}, WgSeg{xe, XE, XE, F}, WgSeg{agg, F, F, F + XE}};
+  WgSeg s0[3] = {WgSeg{h, F, F, 0, 0}, WgSeg{xe, XE, XE, F, 0}, WgSeg{agg, F, F, F + XE, 0}};
   CHK(wgrad_role(m, m->dense[0], WG_KIND_DENSE0, x, total, s0, 3, m->dz1, H1, mu.w[0]));
-  WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0}};
+  WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0, 0}};
   CHK(wgrad_role(m, m->dense[1], WG_KIND_DENSE1, x, total, s1, 1, m->dz2, H2, mu.w[1]));
-  WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0}};
+  WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0, 1}};
   CHK(wgrad_role(m, m->dense[2], WG_KIND_DENSE2, x, total, s2, 1, m->dz3, H3, mu.w[2]));
-  WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0}};
+  WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0, 1}};
   CHK(wgrad_role(m, m->dense[3], WG_KIND_DENSE3, x, total, s3, 1, m->dq, m->C, mu.w[3]));
   return launch_wgrad_multi(m, st, x, mu, 4, "k_wgrad_dense");
 }
@@ -846,23 +853,24 @@ int wgrad_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch& d) 
   WgradMulti mu;
   memset(&mu, 0, sizeof(mu));
   int n = 0;
-  WgSeg s0[3] = {WgSeg{m->h[L], F, F, 0}, WgSeg{d.xe, XE, XE, F}, WgSeg{m->a[L], F, F, F + XE}};
+  WgSeg s0[3] = {WgSeg{m->h[L], F, F, 0, 0}, WgSeg{d.xe, XE, XE, F, 0}, WgSeg{m->a[L], F, F, F + XE, 0}};
   CHK(wgrad_role(m, m->dense[0], WG_KIND_DENSE0, x, total, s0, 3, m->dz1, H1, mu.w[n++]));
   for (int s = L; s >= 1; --s)
     CHK(wgrad_gnn_role(m, s, x, total, d.xe, m->h[s - 1], m->a[s - 1], m->dpre[s], mu.w[n++]));
   CHK(wgrad_gnn_role(m, 0, x, total, d.xe, nullptr, d.nbr, m->dpre[0], mu.w[n++]));
-  WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0}};
+  WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0, 0}};
   CHK(wgrad_role(m, m->dense[1], WG_KIND_DENSE1, x, total, s1, 1, m->dz2, H2, mu.w[n++]));
-  WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0}};
+  WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0, 1}};
   CHK(wgrad_role(m, m->dense[2], WG_KIND_DENSE2, x, total, s2, 1, m->dz3, H3, mu.w[n++]));
-  WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0}};
+  WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0, 1}};
   CHK(wgrad_role(m, m->dense[3], WG_KIND_DENSE3, x, total, s3, 1, m->dq, m->C, mu.w[n++]));
   return launch_wgrad_multi(m, st, x, mu, n, "k_wgrad_all");
 }
 
-struct LossJob { int n_out, n_idx, stride; float scale; };   // n_out == 0: no loss role
+struct LossJob { int n_out, n_idx, stride; float scale; int64_t slot_stride; };   // n_out == 0: no loss role;
+                                                                                 // rowloss(slot, i) = slot*slot_stride + i*stride
 
-int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, float* grad_dst, LossJob lj = LossJob{0, 0, 0, 0.f}) {
+int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, float* grad_dst, LossJob lj = LossJob{0, 0, 0, 0.f, 0}) {
   AdamArgs a;
   memset(&a, 0, sizeof(a));
   a.param = m->params; a.grad = grad_dst ? grad_dst : m->grads; a.mom = m->mom; a.vel = m->vel;
@@ -894,7 +902,7 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   a.n_adam_blocks = blocks;
-  a.rowloss = m->rowloss; a.loss = m->loss_dev; a.loss_n_idx = lj.n_idx; a.loss_stride = lj.stride; a.loss_scale = lj.scale;
+  a.rowloss = m->rowloss; a.loss = m->loss_dev; a.loss_n_idx = lj.n_idx; a.loss_stride = lj.stride; a.loss_scale = lj.scale; a.loss_slot_stride = lj.slot_stride;
   a.grad_direct = m->grads;
   a.loss_split = (lj.n_out == 1 && lj.n_idx > 16384) ? 64 : 1;
   a.loss_part = m->loss_part; a.loss_cnt = reinterpret_cast<unsigned*>(m->loss_part + 64);
@@ -905,8 +913,9 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
 
 LossJob loss_job(const v2x_model* m, const DevBatch& d, int n_global) {
   const float inv = 1.0f / (float)((double)n_global * m->C);
-  if (m->cfg.variable_graphs) return LossJob{1, d.R, 1, inv};
-  return LossJob{m->N, d.B, m->N, inv};
+  if (m->cfg.variable_graphs) return LossJob{1, d.R, 1, inv, 0};
+  if (m->S == 1) return LossJob{m->N, d.B, m->N, inv, 1};          // shared weights: rowloss in node-row order
+  return LossJob{m->N, d.B, 1, inv, srow_stride(m)};                // per-node weights: slot-major
 }
 
 // ------------------------------------------------------------------------------------ passes
@@ -1365,9 +1374,10 @@ int v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_global, const floa
   if (dagg) CHK(copy_cols(m, dagg, m->F, m->gha, 2 * m->F, m->F, n_rows, st));
   if (loss_out) {
     if (m->cfg.variable_graphs)
-      hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, m->rowloss, m->loss_dev, n_rows, 1, a.inv_denom);
+      hipLaunchKernelGGL(k_loss_reduce, dim3(1), dim3(256), 0, st, m->rowloss, m->loss_dev, n_rows, 1, (int64_t)0, a.inv_denom);
     else
-      hipLaunchKernelGGL(k_loss_reduce, dim3(m->N), dim3(256), 0, st, m->rowloss, m->loss_dev, n_rows / m->N, m->N, a.inv_denom);
+      hipLaunchKernelGGL(k_loss_reduce, dim3(m->N), dim3(256), 0, st, m->rowloss, m->loss_dev, n_rows / m->N,
+                         m->S == 1 ? m->N : 1, m->S == 1 ? (int64_t)1 : srow_stride(m), a.inv_denom);
     HIPCHK(m, hipMemcpyAsync(loss_out, m->loss_dev, (m->cfg.variable_graphs ? 1 : m->N) * sizeof(float),
                              hipMemcpyDeviceToDevice, st));
   }

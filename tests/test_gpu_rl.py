@@ -162,3 +162,49 @@ def test_device_replay_ring_and_gather():
     tgt = (reward.cpu().numpy()[:, None] + 0.37 * qn.cpu().numpy().reshape(50, n, 4).max(axis=2)).astype(np.float32)
     ref.reshape(50, n, 4)[np.arange(50)[:, None], np.arange(n)[None, :], action.cpu().numpy()] = tgt
     assert np.array_equal(y, ref)
+
+
+def test_device_replay_index_sharding_sums_to_the_full_batch_gradient():
+    """Data-parallel device replay: every rank draws the SAME indices and processes its contiguous share.  Emulated on
+    one GPU: the two ranks' gradients (global Huber denominator) must add up to the gradient of the whole minibatch,
+    and their Q statistics to the whole-batch statistics."""
+    agent, env, cfg = _setup(31, batch=64, n_veh=20, feat=64, device_replay=True)
+    agent.num_Episodes, agent.num_Train_Step = 1, 4
+    agent.generate_d2d_transition(150)
+    model = agent.brain.model
+    eng = model.engine
+
+    class FakeDist(object):
+        def __init__(self):
+            self.reduced = []
+
+        def all_reduce(self, t, group=None, op=None):
+            self.reduced.append(t.clone())
+
+    class FakeTrainer(object):
+        def __init__(self, rank, world):
+            self.rank, self.world, self.group, self.dist = rank, world, None, FakeDist()
+            self.grad = None
+
+        def train_step(self, batch, y, n_graphs_global, want_loss=True):
+            loss = eng.forward_backward(batch, y, n_global=n_graphs_global)      # no optimizer step: weights stay put
+            self.grad = eng.get_grad_flat().astype(np.float64)
+            return loss
+
+    state = np.random.get_state()
+    full = FakeTrainer(0, 1)
+    model.trainer = full
+    _, qm_full, qx_full, _, _ = agent.replay()
+    parts, stats = [], []
+    for r in range(2):
+        np.random.set_state(state)                                               # same draw on every rank
+        tr = FakeTrainer(r, 2)
+        model.trainer = tr
+        agent.replay()
+        parts.append(tr.grad)
+        stats.append(tr.dist.reduced[-1].cpu().numpy())                          # the rank's partial Q-statistic sums
+    model.trainer = None
+    from util import assert_grad_close
+    assert_grad_close(parts[0] + parts[1], full.grad, "sum of the two ranks' gradients")
+    tot = (stats[0] + stats[1]) / 64
+    assert np.allclose(tot[0], qm_full, rtol=1e-5) and np.allclose(tot[1], qx_full, rtol=1e-5)

@@ -1281,6 +1281,41 @@ int v2x_forward_backward(v2x_model* m, const v2x_batch* b, const float* y, int y
   return fwd_bwd(m, b, y, y_on_device, n_graphs_global, loss_out, loss_on_device, stream, false);
 }
 
+// One DQN replay step (Agent.replay, BS_brain.py:555-748) in a single call: target forward on s', online forward on s
+// (its activations are kept), y = q with the taken action's entry replaced by r + gamma * max q', then backward +
+// Adam on the online network WITHOUT a second forward of the graph layers (predict + fit would run them twice).
+int v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, const v2x_batch* s_next, const int32_t* action,
+                 const double* reward, double gamma, int32_t n_graphs_global, float* y_out, float* loss_out,
+                 int loss_on_device, void* stream) {
+  v2x_model* m = online;
+  if (!online || !target || !action || !reward) FAIL(m, V2X_EINVAL, "dqn_step: null argument");
+  if (online == target) FAIL(m, V2X_EINVAL, "dqn_step: online and target must be different models");
+  if (online->cfg.variable_graphs || target->N != online->N || target->F != online->F || target->L != online->L ||
+      target->S != online->S || target->cfg.device != online->cfg.device)
+    FAIL(m, V2X_EINVAL, "dqn_step: fixed-size graphs and two models of the same shape on the same device are required");
+  if (!s || !s_next || !s->on_device || !s_next->on_device) FAIL(m, V2X_EINVAL, "dqn_step takes device-resident batches");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(m, hipSetDevice(online->cfg.device));
+  DevBatch ds, dn;
+  CHK(resolve_batch(online, s, &ds, st));
+  if (int rc = resolve_batch(target, s_next, &dn, st)) { online->err = target->err; return rc; }
+  if (dn.R != ds.R) FAIL(m, V2X_EINVAL, "dqn_step: s and s' have different sizes");
+  if (n_graphs_global <= 0) n_graphs_global = ds.B;
+  CHK(presize(online, ds));
+  if (int rc = presize(target, dn)) { online->err = target->err; return rc; }
+  CHK(ensure(online, online->st_y, (size_t)ds.R * online->C * sizeof(float)));
+  float* y = y_out ? y_out : (float*)online->st_y.p;
+  const Range all{0, ds.B};
+  if (int rc = run_forward(target, st, dn, all, true)) { online->err = target->err; return rc; }
+  CHK(run_forward(online, st, ds, all, true));
+  hipLaunchKernelGGL(k_dqn_targets, dim3((ds.R + 255) / 256), dim3(256), 0, st, online->q, target->q, action, reward, gamma,
+                     ds.R, online->N, online->C, y);
+  CHK(run_backward(online, st, st, ds, all, y, n_graphs_global));
+  CHK(launch_reduce_adam(online, st, 1, true, nullptr, loss_job(online, ds, n_graphs_global)));
+  online->have_fwd = target->have_fwd = true;
+  return emit_loss(online, loss_out, loss_on_device, st);
+}
+
 int v2x_apply_gradients(v2x_model* m, void* stream) {
   if (!m) FAIL(m, V2X_EINVAL, "null model");
   HIPCHK(m, hipSetDevice(m->cfg.device));

@@ -200,6 +200,19 @@ class GnnEngine(object):
         """Forward + backward only: the local gradient is left in grad_tensor()."""
         return self._step(self._lib.v2x_forward_backward, batch, y, n_global, want_loss)
 
+    def dqn_step(self, target, batch, batch_next, action, reward, gamma, y_out=None, n_global=None, want_loss=True):
+        """One replay step on device-resident data (v2x_dqn_step): target forward on s', online forward on s, target
+        rule, backward + Adam on this (online) engine.  action [B, N] int32, reward [B] float64 (device tensors)."""
+        torch = _torch()
+        if not isinstance(batch, DeviceBatch) or not isinstance(batch_next, DeviceBatch):
+            raise ValueError("dqn_step takes device-resident batches")
+        sb, sn = _batch_struct(batch), _batch_struct(batch_next)
+        loss = torch.empty(self.n_outputs, dtype=torch.float32, device=batch.device) if want_loss else None
+        self._check(self._lib.v2x_dqn_step(self._h, target._h, C.byref(sb), C.byref(sn), action.data_ptr(), reward.data_ptr(),
+                                           float(gamma), int(n_global or 0), None if y_out is None else y_out.data_ptr(),
+                                           None if loss is None else loss.data_ptr(), 1, self._stream()))
+        return loss
+
     def apply_gradients(self):
         self._check(self._lib.v2x_apply_gradients(self._h, self._stream()))
 

@@ -258,13 +258,15 @@ class Agent(object):
             idx = idx[trainer.rank * per:(trainer.rank + 1) * per]
         rep = self.device_replay
         sb, sb_next, action, reward = rep.sample(idx)
-        q = model.engine.forward(sb)                                  # online  [k*n, C]
-        q_next = target.engine.forward(sb_next)                       # target  (adjacency reused, :583)
-        y = rep.dqn_targets(q, q_next, action, reward, self.gamma)
-        if trainer is not None:
-            loss = trainer.train_step(sb, y, n_graphs_global=B)
+        if trainer is None and hasattr(model.engine, 'dqn_step'):
+            # single GPU: the whole step in one call, the online graph layers run once (v2x_dqn_step)
+            y = rep.target_buffer(len(idx), self.num_CH)
+            loss = model.engine.dqn_step(target.engine, sb, sb_next, action, reward, self.gamma, y_out=y)
         else:
-            loss = model.engine.train_step(sb, y)
+            q = model.engine.forward(sb)                              # online  [k*n, C]
+            q_next = target.engine.forward(sb_next)                   # target  (adjacency reused, :583)
+            y = rep.dqn_targets(q, q_next, action, reward, self.gamma)
+            loss = trainer.train_step(sb, y, n_graphs_global=B) if trainer is not None else model.engine.train_step(sb, y)
         yv = y.view(len(idx), n, -1).double()
         stats = rep.torch.stack([yv.sum(dim=(0, 2)) / self.num_Actions, yv.max(dim=2).values.sum(dim=0)])
         if trainer is not None and trainer.world > 1:

@@ -133,6 +133,12 @@ class DeviceReplay(object):
         mk = lambda t: DeviceBatch.from_tensors(k, self.n, t, rp, col, self.n_edges)
         return mk(xe), mk(xe_next), action, reward
 
+    def target_buffer(self, k, n_channels):
+        """Reused [k * n, C] buffer for the training targets of a k-transition minibatch."""
+        if ('y', k) not in self._bufs:
+            self._bufs[('y', k)] = self.torch.empty((k * self.n, n_channels), dtype=self.torch.float32, device=self.device)
+        return self._bufs[('y', k)]
+
     def dqn_targets(self, q, q_next, action, reward, gamma):
         """The target rule (BS_brain.py:684-692) on device: y = q with y[b, k, a[b, k]] = r[b] + gamma * max q'[b, k]."""
         k, n, Cc = action.shape[0], self.n, q.shape[1]

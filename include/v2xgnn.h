@@ -12,8 +12,8 @@
  *   v2x_copy_weights              <- BS.update_target_model      BS_brain.py:237-239
  *   v2x_get_weights/set_weights   <- get_weights / set_weights / save_weights / load_weights
  *                                                                BS_brain.py:239,863,869,1254
- *   v2x_gather_rows / v2x_dqn_targets
- *                                 <- Agent.replay batching + target rule  BS_brain.py:573-692
+ *   v2x_gather_rows / v2x_dqn_targets / v2x_dqn_step
+ *                                 <- Agent.replay batching, target rule, whole step  BS_brain.py:555-748
  *   v2x_agg_* / v2x_node_update_* / v2x_mlp_* / v2x_adam_step
  *                                 <- the implicit TF op set of GNNLayer.call (:44-51),
  *                                    AggLayer.call (:69-76), Dense (:176-179), huber (:86-87),
@@ -173,6 +173,15 @@ int  v2x_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_i
 int  v2x_dqn_targets(const float* q, const float* q_next, const int32_t* action, const double* reward,
                      double gamma, int32_t n_graphs, int32_t n_nodes, int32_t n_channels, float* y_out,
                      void* stream);
+
+/* One whole replay step (BS_brain.py:664-728: predict on s, predict(target) on s', target rule, train_dnn) as a
+ * single call on device-resident batches: the graph layers of the online network run ONCE (their activations feed
+ * the backward pass), where predict + fit would run them twice.  y_out: optional [dev] [n_rows][C] buffer that
+ * receives the training targets (for the caller's Q statistics, BS_brain.py:730-746); loss_out: per-output Huber
+ * means like v2x_train_step.                                                                                   */
+int  v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, const v2x_batch* s_next,
+                  const int32_t* action, const double* reward, double gamma, int32_t n_graphs_global,
+                  float* y_out, float* loss_out, int loss_on_device, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* When enabled, every kernel launch of this model is bracketed by HIP events on its stream

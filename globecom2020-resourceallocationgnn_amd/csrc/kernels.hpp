@@ -1068,7 +1068,9 @@ __device__ __forceinline__ void wg_load(WgOperand<W>& o, const WgSrc& src, unsig
 // tiles with a barrier per tile; a 2 x 2 tile split over the waves that loads every operand twice; dword-only
 // fragment loads; single buffering at 4 waves/SIMD -- waves sharing a SIMD run in lockstep, so occupancy alone
 // does not overlap memory and MFMA phases.)
-template <int K0, int K1, int K2, int NW, int DEPTH = 2>
+// ZERO1: the K1 segment is absent (identically zero input, e.g. the embed layer's neighbour-init): nothing is loaded or
+// multiplied for its tiles, their gradient rows are written as exact zeros.
+template <int K0, int K1, int K2, int NW, int DEPTH = 2, bool ZERO1 = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, const int bx, const int slot) {
   constexpr int T0 = K0 / 16, T1 = K1 / 16, T2 = K2 / 16, KT = T0 + T1 + T2, NT = NW / 16;
   if (bx >= a.n_chunks) return;                                  // roles have work-proportional grids
@@ -1103,19 +1105,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
 
-  struct Block { WgOperand<K0> k0; WgOperand<K1> k1; WgOperand<K2> k2; WgOperand<NW> n; };
+  constexpr int K1L = ZERO1 ? 0 : K1;                            // loaded width of the K1 operand
+  struct Block { WgOperand<K0> k0; WgOperand<K1L> k1; WgOperand<K2> k2; WgOperand<NW> n; };
   auto kval = [&](const Block& b, int kt, int s) -> float {
     if (kt < T0) return b.k0.get(kt, s);
-    if (kt < T0 + T1) return b.k1.get(kt - T0, s);
+    if (kt < T0 + T1) return ZERO1 ? 0.f : b.k1.get(kt - T0, s);
     return b.k2.get(kt - T0 - T1, s);
   };
   auto mfma_block = [&](const Block& b) {
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int kt = 0; kt < KT; ++kt)
+      for (int kt = 0; kt < KT; ++kt) {
+        if (ZERO1 && kt >= T0 && kt < T0 + T1) continue;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[kt][nt] = V2X_MFMA(kval(b, kt, s), b.n.get(nt, s), acc[kt][nt]);
+      }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bsum[nt] += (b.n.get(nt, 0) + b.n.get(nt, 1)) + (b.n.get(nt, 2) + b.n.get(nt, 3));
   };
@@ -1127,7 +1132,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     for (int s = 0; s < 4; ++s) {
       const unsigned idx = idx_lane0 + (unsigned)(blk * WG_TR + s);
       wg_load<K0>(b.k0, src[0], idx * src[0].rs + src[0].off, s, j, 1.f);
-      wg_load<K1>(b.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
+      wg_load<K1L>(b.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
       wg_load<K2>(b.k2, src[2], idx * src[2].rs + src[2].off, s, j, 1.f);
       wg_load<NW>(b.n, srcn, idx * srcn.rs + srcn.off, s, j, 1.f);
     }
@@ -1203,7 +1208,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
       const float mk = ridx < i_end ? 1.f : 0.f;                 // rows past the chunk contribute 0
       const unsigned idx = (unsigned)(a.idx_base + min(ridx, a.n_idx - 1));
       wg_load<K0>(b0.k0, src[0], idx * src[0].rs + src[0].off, s, j, 1.f);
-      wg_load<K1>(b0.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
+      wg_load<K1L>(b0.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
       wg_load<K2>(b0.k2, src[2], idx * src[2].rs + src[2].off, s, j, 1.f);
       wg_load<NW>(b0.n, srcn, idx * srcn.rs + srcn.off, s, j, mk);
     }
@@ -1285,7 +1290,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
 // (runtime-indexed array): the role's descriptor is read through the constant-address-space kernarg pointer.
 constexpr int WG_MAX_ROLES = 8;
 struct WgradMulti { WgradArgs w[WG_MAX_ROLES]; };
-enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 3, WG_KIND_DENSE2 = 4, WG_KIND_DENSE3 = 5 };
+enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 3, WG_KIND_DENSE2 = 4, WG_KIND_DENSE3 = 5,
+       WG_KIND_EMBED_NONBR = 6 };
 
 // MODE 0: the GNN stages, 1: the Dense layers, 2: both families in one launch (roles ordered heaviest first)
 template <int F, int MODE>
@@ -1302,6 +1308,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
   if constexpr (MODE != 1) {
     if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
     if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_EMBED_NONBR) { wgrad_body<XE, F, 0, F, 3, true>(a, smem, blockIdx.x, blockIdx.y); return; }
   }
   if constexpr (MODE != 0) {
     if (a.kind == WG_KIND_DENSE0) wgrad_body<F, XE, F, H1>(a, smem, blockIdx.x, blockIdx.y);

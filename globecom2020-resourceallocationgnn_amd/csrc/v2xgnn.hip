@@ -709,7 +709,8 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
                const float* dpre, int d_stride, WgradArgs& a) {
   int chunk;
   // measured at batch 4096 x 20 nodes: 1024 rows per workgroup for the GNN stages, 768 for the Dense layers
-  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, kind < WG_KIND_DENSE0 ? 1024 : 768);
+  const bool gnn_kind = kind < WG_KIND_DENSE0 || kind == WG_KIND_EMBED_NONBR;
+  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, gnn_kind ? 1024 : 768);
   if (nc > m->slab_cap) FAIL(m, V2X_ESTATE, "wgrad: slabs not pre-sized (%d > %d)", nc, m->slab_cap);
   ld.n_slabs = nc;                       // remembered for the slab reduction
   memset(&a, 0, sizeof(a));
@@ -720,7 +721,7 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
   a.slab = m->slab; a.slab_stride = m->P; a.layer_off = ld.off; a.slot_stride = ld.slot_stride;
   a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.chunk = chunk;
   a.idx_base = x.idx_base; a.chunk_base = 0; a.n_chunks = nc; a.kind = kind;
-  a.dpre_slot_major = kind >= WG_KIND_DENSE1 ? 1 : 0;      // dz2, dz3, dq (MlpArgs::srow_stride)
+  a.dpre_slot_major = (kind >= WG_KIND_DENSE1 && kind <= WG_KIND_DENSE3) ? 1 : 0;      // dz2, dz3, dq (MlpArgs::srow_stride)
   a.srow_stride = (int)srow_stride(m);
   a.zeros = m->zero_buf;
   return V2X_OK;
@@ -736,7 +737,7 @@ int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti
   const size_t lds = (size_t)(maxt * 64 * 4 + 5 * 16) * 4;      // accumulator exchange + bias
   const dim3 grid(nc, x.grid_y, n_roles);
   bool dense = false, gnn = false;
-  for (int i = 0; i < n_roles; ++i) (mu.w[i].kind >= WG_KIND_DENSE0 ? dense : gnn) = true;
+  for (int i = 0; i < n_roles; ++i) ((mu.w[i].kind >= WG_KIND_DENSE0 && mu.w[i].kind <= WG_KIND_DENSE3) ? dense : gnn) = true;
 #define V2X_WG_CASE(FF)                                                              \
   if (m->F == FF) {                                                                  \
     if (dense && gnn) { auto k = k_wgrad<FF, 2>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
@@ -761,7 +762,8 @@ int wgrad_gnn_role(v2x_model* m, int stage, const IdxMap& x, int total_work, con
   int n = 0;
   if (stage > 0) { s[n++] = WgSeg{h_prev, F, F, 0, 0}; s[n++] = WgSeg{xe, XE, XE, F, 0}; s[n++] = WgSeg{agg_prev, F, F, F + XE, 0}; }
   else { s[n++] = WgSeg{xe, XE, XE, 0, 0}; s[n++] = WgSeg{agg_prev /* neighbour-init or null */, F, F, XE, 0}; }
-  return wgrad_role(m, m->gnn[stage], stage ? WG_KIND_GNN : WG_KIND_EMBED, x, total_work, s, n, dpre, F, a);
+  const int kind = stage ? WG_KIND_GNN : (agg_prev ? WG_KIND_EMBED : WG_KIND_EMBED_NONBR);
+  return wgrad_role(m, m->gnn[stage], kind, x, total_work, s, n, dpre, F, a);
 }
 
 int wide_wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const float* xe, const float* h_prev,

@@ -257,7 +257,6 @@ def test_ragged_graphs_shared_weights_vs_oracle(dense):
     """BASELINE config 5 shape: graphs of different sizes packed with graph_off, shared weights.  Forward, loss and
     every gradient against the CSR oracle (single Huber mean over all rows x channels).  dense: the reference
     topology (in-degree n-2) -> MFMA aggregation; otherwise sparse random graphs -> gather form."""
-    import ctypes as C
     from oracle.spec import GnnSpec as OSpec
     F = 64
     spec = GnnSpec(n_nodes=1, feat_dim=F, share_weights=True, variable_graphs=True)

@@ -13,7 +13,7 @@ from v2xgnn import GnnSpec, PackedBatch
 from v2xgnn import lib as vlib
 from oracle import compact as oc, literal as ol
 from oracle.spec import GnnSpec as OSpec
-from util import GOLDEN, golden_forward_cases, golden_feed, random_inputs
+from util import golden_forward_cases, golden_feed, random_inputs
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -67,11 +67,22 @@ def synth_ragged(rng, B, lo, hi, C=4):
 
 
 def algorithmic_flops(name, R, F, L, C=4, Dn=9, De=4):
-    """fp32 flops per launch of the dense kernels of the wide-feature path (SURVEY.md 8(d9) terms x rows)."""
+    """fp32 MFMA flops per launch of the dense kernels (SURVEY.md 8(d9) terms x rows); None for kernels that do no
+    matrix work (aggregations, Adam)."""
     gnn = 2 * R * (2 * F + Dn + De) * F
-    table = {"k_node_fwd": gnn, "k_wgrad_gnn": gnn, "k_node_dgrad": 2 * R * F * 2 * F,
-             "k_dense0_fwd": 2 * R * (2 * F + Dn) * 80, "k_wgrad_dense0": 2 * R * (2 * F + Dn) * 80,
-             "k_dense0_dgrad": 2 * R * 80 * 2 * F}
+    embed = 2 * R * (Dn + De) * F
+    dense0 = 2 * R * (2 * F + Dn) * 80
+    tail = 2 * R * (80 * 40 + 40 * 20 + 20 * C)
+    table = {"k_node_fwd_embed": embed, "k_node_fwd": gnn, "k_wgrad_gnn": L * gnn + embed, "k_wgrad_embed": embed,
+             "k_node_dgrad": 2 * R * F * 2 * F,
+             "k_dense0_fwd": dense0, "k_wgrad_dense0": dense0, "k_dense0_dgrad": 2 * R * 80 * 2 * F,
+             "k_mlp_fwd": (dense0 if F < 128 else 0) + tail,
+             "k_mlp_bwd": (2 * R * 80 * 2 * F if F < 128 else 0) + tail,
+             "k_wgrad_dense": (dense0 if F < 128 else 0) + tail}
+    table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"]
+    table["k_wgrad_all"] = table["k_wgrad_gnn"] + table["k_wgrad_dense"]
+    if F >= 128:
+        table["k_wgrad_gnn"] = gnn                       # wide path: one launch per stage
     return table.get(name)
 
 
@@ -281,25 +292,33 @@ def main():
         Bq, Nq = (1, n_rows_local) if ragged else (B, N)       # the byte model only needs rows = Bq*Nq and E
         step_bytes = (sum(step_bytes_per_graph(int(n), F, L, int(n) * (int(n) - 2)) for n in sizes) / B if ragged
                       else step_bytes_per_graph(N, F, L, E // B))
-        if F >= 128:
-            # wide features: the dense contractions dominate and are fp32-MFMA bound
-            dom = max((k for k in prof if algorithmic_flops(k, n_rows_local, F, L) is not None), key=lambda k: prof[k][1])
-            calls, ms = prof[dom]
-            fl = algorithmic_flops(dom, n_rows_local, F, L)
-            achieved = fl / (1e-3 * ms / calls) / 1e12
-            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": FP32_MFMA_PEAK_TF,
-                        "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": None,
-                        "algorithmic_flops_per_launch": int(fl), "avg_launch_us": round(1e3 * ms / calls, 2),
-                        "step_hbm_frac": round(step_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)}
+        # dominant kernel = most time per step among the modelled kernels; its roofline is the resource whose floor
+        # (algorithmic bytes / 8 TB/s vs algorithmic flops / 157.3 TF) is the LARGER one
+        def floors(k):
+            by = algorithmic_bytes(k, Bq, Nq, F, E, L) if F < 128 else None
+            fl = algorithmic_flops(k, n_rows_local, F, L)
+            return by, fl
+        modelled = [k for k in prof if any(v is not None for v in floors(k))]
+        dom = max(modelled, key=lambda k: prof[k][1])
+        calls, ms = prof[dom]
+        sec = 1e-3 * ms / calls
+        by, fl = floors(dom)
+        t_hbm = (by or 0) / (HBM_PEAK_GBS * 1e9)
+        t_mfma = (fl or 0) / (FP32_MFMA_PEAK_TF * 1e12)
+        common = {"kernel": dom, "avg_launch_us": round(1e6 * sec, 2),
+                  "algorithmic_bytes_per_launch": None if by is None else int(by),
+                  "algorithmic_flops_per_launch": None if fl is None else int(fl),
+                  "hbm_frac": None if by is None else round(t_hbm / sec, 4),
+                  "mfma_frac": None if fl is None else round(t_mfma / sec, 4),
+                  "step_hbm_frac": round(step_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)}
+        if t_mfma > t_hbm:
+            achieved = fl / sec / 1e12
+            roofline = dict({"bound": "mfma", "achieved": round(achieved, 1), "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": round(achieved / FP32_MFMA_PEAK_TF, 4), "traffic": hbm_traffic(dom, args)}, **common)
         else:
-            dom = max((k for k in prof if algorithmic_bytes(k, Bq, Nq, F, E, L) is not None), key=lambda k: prof[k][1])
-            calls, ms = prof[dom]
-            bytes_per_launch = algorithmic_bytes(dom, Bq, Nq, F, E, L)
-            achieved = bytes_per_launch / (1e-3 * ms / calls) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": hbm_traffic(dom, args),
-                        "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(1e3 * ms / calls, 2),
-                        "step_hbm_frac": round(step_bytes * (value / world) / 1e9 / HBM_PEAK_GBS, 4)}
+            achieved = by / sec / 1e9
+            roofline = dict({"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": hbm_traffic(dom, args)}, **common)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not ragged:

@@ -99,9 +99,17 @@ namespace {
     if (_r != V2X_OK) return _r; \
   } while (0)
 
+// Captured graphs bake in the addresses of the workspace buffers: whenever one of them is re-allocated every cached
+// graph is dropped (it would replay into freed memory and its outputs would no longer be where the caller reads them).
+void drop_graphs(v2x_model* m) {
+  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+  m->graphs.clear();
+}
+
 int ensure(v2x_model* m, DevBuf& b, size_t bytes) {
   if (bytes <= b.cap) return V2X_OK;
   if (m->capturing) FAIL(m, V2X_ESTATE, "buffer growth during graph capture");
+  drop_graphs(m);
   if (b.p) HIPCHK(m, hipFree(b.p));
   b.p = nullptr; b.cap = 0;
   HIPCHK(m, hipMalloc(&b.p, bytes));
@@ -206,6 +214,7 @@ RowMapH row_map(const v2x_model* m, int n_rows) {
 int ensure_rows(v2x_model* m, int64_t R) {
   if (R <= m->cap_rows) return V2X_OK;
   if (m->capturing) FAIL(m, V2X_ESTATE, "workspace growth during graph capture");
+  drop_graphs(m);
   auto re = [&](float*& p, int64_t w) -> int {
     if (p) HIPCHK(m, hipFree(p));
     p = nullptr;
@@ -254,6 +263,7 @@ int role_chunks(int n_idx, int n_slots, int work, int total_work, int* chunk_out
 int ensure_slabs(v2x_model* m, int nc) {
   if (nc <= m->slab_cap) return V2X_OK;
   if (m->capturing) FAIL(m, V2X_ESTATE, "slab growth during graph capture");
+  drop_graphs(m);
   if (m->slab) HIPCHK(m, hipFree(m->slab));
   m->slab = nullptr;
   HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->slab), (size_t)nc * m->P * sizeof(float)));

@@ -69,6 +69,10 @@ def _batch_struct(b):
 
 
 class GnnEngine(object):
+    """use_graph: forward / fit steps are captured once per (batch pointers, sizes) as a hipGraph and replayed.
+    Capture needs a NON-default stream: calls made while torch's current stream is the default one run eagerly
+    (`with torch.cuda.stream(torch.cuda.Stream()): ...` enables the graphs)."""
+
     def __init__(self, spec: GnnSpec, device=0, use_graph=False, lr=1e-3, beta_1=0.5, beta_2=0.999,
                  epsilon=1e-7):
         self.spec = spec

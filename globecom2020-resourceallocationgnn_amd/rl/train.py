@@ -77,9 +77,17 @@ def main(argv=None):
     cfg.Num_Episodes, cfg.Num_Train_Steps = args.episodes, args.train_steps
     env = start_env(args.links)
     t0 = time.perf_counter()
-    agent, (loss, reward_step, reward_ep, q_mean, q_max, _, _) = run_train(
-        env, cfg, save_dir=args.save_dir if rank == 0 else None, verbose=rank == 0,
-        device=local, seed=args.seed, use_graph=args.use_graph, data_parallel=world > 1 or force_dp)
+    import contextlib
+    ctx = contextlib.nullcontext()
+    if args.use_graph:
+        # the engine captures hipGraphs only on a non-default stream (capture is not allowed on the legacy stream)
+        import torch
+        torch.cuda.set_device(local)
+        ctx = torch.cuda.stream(torch.cuda.Stream(device=local))
+    with ctx:
+        agent, (loss, reward_step, reward_ep, q_mean, q_max, _, _) = run_train(
+            env, cfg, save_dir=args.save_dir if rank == 0 else None, verbose=rank == 0,
+            device=local, seed=args.seed, use_graph=args.use_graph, data_parallel=world > 1 or force_dp)
     dt = time.perf_counter() - t0
     if rank == 0:
         n_fit = args.episodes * args.train_steps

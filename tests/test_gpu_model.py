@@ -346,3 +346,33 @@ def test_ragged_large_batch_loss_is_split_reduced():
     for _ in range(2):
         loss = eng.forward_backward(pb, y)
         assert_close(loss, [ref], 1e-5, 1e-7, "split loss reduction")
+
+
+def test_graph_cache_survives_workspace_growth():
+    """use_graph: a small batch is captured, a larger batch then grows (re-allocates) the activation workspace, and
+    the small batch comes back -- the replayed graph must not reference the freed buffers."""
+    spec = GnnSpec(n_nodes=20, feat_dim=64)
+    rng = np.random.default_rng(77)
+    P = f32_params(spec, rng)
+    ref = GnnEngine(spec)                                   # eager reference
+    ref.set_weights(oc.params_to_list(P))
+    eng = GnnEngine(spec, use_graph=True)
+    eng.set_weights(oc.params_to_list(P))
+    import torch
+    stream = torch.cuda.Stream()
+    batches = {}
+    for B in (2, 300, 2, 1200, 300, 2):
+        if B not in batches:
+            x, e, adj = random_inputs(rng, B, 20)
+            y = rng.normal(2.5, 1.0, size=(B * 20, 4)).astype(np.float32)
+            pb = PackedBatch.from_dense(x, e, adj)
+            batches[B] = (pb, y, eng.to_device(pb), torch.from_numpy(y).cuda())      # device copies: STABLE pointers
+            torch.cuda.synchronize()                        # (the copies ran on the default stream)
+        pb, y, db, yd = batches[B]
+        with torch.cuda.stream(stream):                     # graphs are only captured on a non-default stream
+            q = eng.forward(db)
+            la = eng.forward_backward(db, yd)
+        stream.synchronize()
+        assert np.array_equal(q.cpu().numpy(), ref.forward(pb)), B
+        lb = ref.forward_backward(pb, y)
+        assert np.array_equal(la.cpu().numpy(), lb) and np.array_equal(eng.get_grad_flat(), ref.get_grad_flat()), B

@@ -73,7 +73,10 @@ struct v2x_model {
   std::vector<std::string> prof_names;
   std::vector<ProfRec> prof_recs;
   // hipGraph cache
-  std::map<GraphKey, hipGraphExec_t> graphs;
+  // a captured step + the per-layer slab counts its weight-gradient launches write (host state that the launches
+  // OUTSIDE the graph -- the Adam / slab-sum kernel of train_step -- depend on)
+  struct GraphEntry { hipGraphExec_t exec; std::vector<int> n_slabs; };
+  std::map<GraphKey, GraphEntry> graphs;
   bool capturing = false;
 };
 
@@ -102,7 +105,7 @@ namespace {
 // Captured graphs bake in the addresses of the workspace buffers: whenever one of them is re-allocated every cached
 // graph is dropped (it would replay into freed memory and its outputs would no longer be where the caller reads them).
 void drop_graphs(v2x_model* m) {
-  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second.exec);
   m->graphs.clear();
 }
 
@@ -1046,7 +1049,10 @@ int run_maybe_graph(v2x_model* m, hipStream_t st, const GraphKey& key, Body body
   if (!want) return body();
   auto it = m->graphs.find(key);
   if (it != m->graphs.end()) {
-    HIPCHK(m, hipGraphLaunch(it->second, st));
+    size_t i = 0;                                   // what the captured host code had left in the layer descriptors
+    for (auto* v : {&m->gnn, &m->dense})
+      for (LayerDesc& ld : *v) ld.n_slabs = it->second.n_slabs[i++];
+    HIPCHK(m, hipGraphLaunch(it->second.exec, st));
     return V2X_OK;
   }
   // make sure every lazily-sized buffer and function attribute exists before capture: run once eagerly
@@ -1063,11 +1069,12 @@ int run_maybe_graph(v2x_model* m, hipStream_t st, const GraphKey& key, Body body
   e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
   hipGraphDestroy(g);
   if (e != hipSuccess) FAIL(m, V2X_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
-  if (m->graphs.size() >= 16) {
-    for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
-    m->graphs.clear();
-  }
-  m->graphs[key] = ge;
+  if (m->graphs.size() >= 16) drop_graphs(m);
+  v2x_model::GraphEntry entry;
+  entry.exec = ge;
+  for (auto* v : {&m->gnn, &m->dense})
+    for (const LayerDesc& ld : *v) entry.n_slabs.push_back(ld.n_slabs);
+  m->graphs[key] = entry;
   HIPCHK(m, hipGraphLaunch(ge, st));
   return V2X_OK;
 }
@@ -1176,7 +1183,7 @@ void v2x_destroy(v2x_model* m) {
   if (!m) return;
   hipSetDevice(m->cfg.device);
   hipDeviceSynchronize();
-  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second);
+  for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second.exec);
   for (auto& r : m->prof_recs) { hipEventDestroy(r.ev0); hipEventDestroy(r.ev1); }
   float* ptrs[] = {m->params, m->grads, m->mom, m->vel, m->z1, m->z2, m->z3, m->q, m->dq, m->dz1, m->dz2, m->dz3,
                    m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part};

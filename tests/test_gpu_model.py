@@ -376,3 +376,32 @@ def test_graph_cache_survives_workspace_growth():
         assert np.array_equal(q.cpu().numpy(), ref.forward(pb)), B
         lb = ref.forward_backward(pb, y)
         assert np.array_equal(la.cpu().numpy(), lb) and np.array_equal(eng.get_grad_flat(), ref.get_grad_flat()), B
+
+
+def test_graph_replay_of_train_steps_at_alternating_batch_sizes():
+    """train_step keeps Adam outside the captured graph; the slab counts the Adam launch sums must be those of the
+    REPLAYED weight-gradient launch, not of whichever batch size ran last."""
+    import torch
+    spec = GnnSpec(n_nodes=20, feat_dim=64)
+    rng = np.random.default_rng(5)
+    P = f32_params(spec, rng)
+    ref = GnnEngine(spec)
+    ref.set_weights(oc.params_to_list(P))
+    eng = GnnEngine(spec, use_graph=True)
+    eng.set_weights(oc.params_to_list(P))
+    stream = torch.cuda.Stream()
+    batches = {}
+    for B in (2400, 40, 2400, 40, 2400):                     # 4 resp. 1 weight-gradient slabs per slot
+        if B not in batches:
+            x, e, adj = random_inputs(rng, B, 20)
+            y = rng.normal(2.5, 1.0, size=(B * 20, 4)).astype(np.float32)
+            pb = PackedBatch.from_dense(x, e, adj)
+            batches[B] = (pb, y, eng.to_device(pb), torch.from_numpy(y).cuda())
+            torch.cuda.synchronize()
+        pb, y, db, yd = batches[B]
+        with torch.cuda.stream(stream):
+            la = eng.train_step(db, yd)
+        stream.synchronize()
+        lb = ref.train_step(pb, y)
+        assert np.array_equal(la.cpu().numpy(), lb), B
+        assert np.array_equal(eng.get_flat(), ref.get_flat()), B

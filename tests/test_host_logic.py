@@ -202,3 +202,49 @@ def test_keras_layer_table_matches_weight_list():
     assert t[0] == ('D1_GNN', ['D1_GNN/W1:0', 'D1_GNN/W2:0', 'D1_GNN/W3:0', 'D1_GNN/bias:0'])
     assert t[4][0] == 'gnn_layer_1' and t[11][0] == 'gnn_layer_8' and t[12][0] == 'dense_1' and t[23][0] == 'dense_12'
     assert t[-1] == ('D4_Decide_Output', ['D4_Decide_Output/kernel:0', 'D4_Decide_Output/bias:0'])
+
+
+def test_fit_minibatches_epochs_and_shuffle():
+    """Model.fit semantics above the engine (bs_brain.GnnQModel.fit): minibatches of `batch_size` in order or in the
+    order of ONE np.random.shuffle per epoch (Keras shuffles with the global numpy RNG), `epochs` passes, History
+    entries = sample-weighted means of the minibatch losses.  Engine injected: the float64 oracle."""
+    from oracle_engine import OracleEngine
+    from v2xgnn.bs_brain import GnnQModel
+    from v2xgnn.packing import PackedBatch as PB
+    spec = GnnSpec(n_nodes=4, feat_dim=16)
+    rng = np.random.default_rng(8)
+    B = 40
+    x, e, adj = random_inputs(rng, B, 4)
+    feed = {}
+    for k in range(4):
+        feed['D%d_Node_Input' % (k + 1)] = x[:, k, :].astype(np.float64)
+        feed['D%d_Edge_Input' % (k + 1)] = e[:, k, :].astype(np.float64)
+        feed['D%d_Neighbor_Input' % (k + 1)] = np.zeros((B, 16))
+    feed['Adjacency_Matrix'] = np.kron(adj, np.eye(16))
+    yt = rng.normal(2.5, 1.0, size=(B, 4, 4))
+    y = {'D%d_Decide_Output' % (k + 1): yt[:, k, :] for k in range(4)}
+    for shuffle in (False, True):
+        model = GnnQModel(spec, seed=3, engine=OracleEngine(spec))
+        ref = OracleEngine(spec)
+        ref.set_weights(model.get_weights())
+        np.random.seed(21)
+        hist = model.fit(feed, y, batch_size=16, epochs=2, shuffle=shuffle)
+        np.random.seed(21)
+        want = []
+        for ep in range(2):
+            idx = np.arange(B)
+            if shuffle:
+                np.random.shuffle(idx)
+            tot = np.zeros(4)
+            for s in range(0, B, 16):
+                sel = idx[s:s + 16]
+                loss = ref.train_step(PB.from_dense(x[sel], e[sel], adj[sel]), yt[sel].reshape(-1, 4))
+                tot += np.asarray(loss) * len(sel)
+            want.append(tot / B)
+        assert hist.epoch == [0, 1] and len(hist.history['loss']) == 2
+        for ep in range(2):
+            got = [hist.history['D%d_Decide_Output_loss' % (k + 1)][ep] for k in range(4)]
+            assert np.allclose(got, want[ep], rtol=1e-6)                 # (the feed is rounded to fp32 when packed)
+            assert np.isclose(hist.history['loss'][ep], np.sum(want[ep]), rtol=1e-6)
+        for a, b in zip(model.get_weights(), ref.get_weights()):
+            assert np.allclose(a, b, rtol=1e-5, atol=1e-7)

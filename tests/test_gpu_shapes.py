@@ -1,7 +1,7 @@
 """GPU: whole-model parity (forward, per-output loss, every gradient array) against the float64 oracle over a spread of
 shapes -- link counts 1..40 (1 and 2 links: graphs without edges), all feature widths incl. the wide path, 1..4
 message-passing layers, per-node and shared weights, batches that are not multiples of any tile (1, 17, 130), the
-reference topology and random adjacencies.  `tools/shape_sweep.py` runs the full 504-shape grid.
+reference topology and random adjacencies.  `tests/sweep_shapes.py` runs the full 504-shape grid.
 
 A ReLU whose pre-activation is ~1e-6 of its layer's scale is gated differently by fp32 and fp64 arithmetic (one row's
 contribution appears / disappears from a bias gradient summed over few rows); that is conditioning, not parity, and it

@@ -50,6 +50,14 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
                 assert 'oracle/' not in src.replace('SURVEY', ''), fn
+    # repo-wide: only tests/, the smoke entry and bench.py's cpu_baseline leg may touch the oracle
+    allowed = {os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')}
+    for dirpath, dirs, files in os.walk(ROOT):
+        dirs[:] = [d for d in dirs if d not in ('.git', 'gpurun_out', '__pycache__', 'tests', 'oracle')]
+        for fn in files:
+            path = os.path.join(dirpath, fn)
+            if fn.endswith('.py') and path not in allowed:
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', open(path).read(), flags=re.M), path
 
 
 def test_spec_matches_reference_size_bookkeeping():

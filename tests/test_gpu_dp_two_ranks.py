@@ -72,3 +72,52 @@ def test_two_rank_engine_step_equals_single_process_step(use_graph):
     for r in (0, 1):
         assert np.allclose(ret[r][1], losses, rtol=2e-5, atol=1e-7)
         assert np.allclose(ret[r][0], w, rtol=2e-4, atol=2e-6)        # fp32 summation order of the two half-batch gradients
+
+
+def _dqn_worker(rank, world, port, ret):
+    import random
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from v2xgnn.rl import Agent, RL_Config
+        from v2xgnn.rl.train import start_env
+        random.seed(9)
+        np.random.seed(9)
+        cfg = RL_Config()
+        cfg.set_train_value(64, 0.5, 64, 1, 0.1)
+        env = start_env(20)
+        agent = Agent(20, env.n_RB, env.n_Neighbor, 64, env, cfg, seed=2, data_parallel=world > 1)
+        assert agent.device_replay is not None
+        loss, reward_step, _, q_mean, _, _, _ = agent.train(1, 3)
+        ret[rank] = (np.concatenate([w.ravel() for w in agent.brain.model.get_weights()]), loss, reward_step, q_mean)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_two_rank_dqn_loop_with_device_replay_on_the_engine():
+    """BASELINE config 3's scheme on the real engine: two ranks (sharing the one GPU, gloo collective) run the same
+    seeded simulator, keep their replay memories in HBM, draw the same indices and fit their halves of every minibatch.
+    Replicas must stay bit-identical and agree with the single-process loop."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_dqn_worker, args=(2, port, ret), nprocs=2, join=True)
+    single = mp.Manager().dict()
+    mp.spawn(_dqn_worker, args=(1, port, single), nprocs=1, join=True)
+    w1, loss1, rew1, qm1 = single[0]
+    assert np.array_equal(ret[0][0], ret[1][0])                     # replicas bit-identical
+    for r in (0, 1):
+        w, loss, rew, qm = ret[r]
+        assert np.array_equal(rew, rew1)                            # identical rollouts (same weights -> same actions)
+        assert np.allclose(loss, loss1, rtol=2e-4, atol=1e-6)
+        assert np.allclose(qm, qm1, rtol=1e-4, atol=1e-6)
+        assert np.allclose(w, w1, rtol=1e-3, atol=2e-5)

@@ -203,6 +203,8 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU fallback)")
+    if os.environ.get("V2X_BENCH_ONE_DEVICE") == "1":     # tests: every rank on cuda:0 (one-GPU box), gloo collective
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     force_dp = os.environ.get("V2X_FORCE_DP") == "1"      # exercise the RCCL path with a single rank (tests)
@@ -210,7 +212,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("V2X_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for the one-GPU test
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     N, F, L, B = args.nodes, args.feat, args.layers, args.batch
     spec = GnnSpec(n_nodes=1 if ragged else N, feat_dim=F, n_mp_layers=L, share_weights=args.share_weights,

@@ -121,3 +121,25 @@ def test_two_rank_dqn_loop_with_device_replay_on_the_engine():
         assert np.allclose(loss, loss1, rtol=2e-4, atol=1e-6)
         assert np.allclose(qm, qm1, rtol=1e-4, atol=1e-6)
         assert np.allclose(w, w1, rtol=1e-3, atol=2e-5)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py launched exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process:
+    barrier, max-over-ranks timing, whole-job value, rank-0 JSON line); the box has one GPU, so both ranks use cuda:0
+    and the collective is gloo (V2X_BENCH_ONE_DEVICE / V2X_BENCH_BACKEND exist for this test only)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, V2X_BENCH_ONE_DEVICE="1", V2X_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29551", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--batch", "512", "--no-cpu-baseline", "--no-roofline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # rank 0 only
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 1024 and res["config"]["parallelism"] == "dp2"
+    assert res["value"] > 0 and res["scaling"] == "weak" and res["steps"] == 5
+    assert abs(res["value"] - 1024 * 5 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-3

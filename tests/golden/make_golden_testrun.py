@@ -42,6 +42,27 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'golden_testrun_n4.npz'), **fx)
     print('wrote golden_testrun_n4.npz', {k: np.asarray(v).shape for k, v in fx.items()})
 
+    # ---- observation at 20 links: Agent.get_state is written for any num_D2D (BS_brain.py:389-407); only the
+    #      network builder and the payload loops are hard-coded to 4 links
+    random.seed(2020)
+    np.random.seed(2020)
+    env = mg.make_env(Environment)
+    env.new_random_game(20)
+    BS_brain.Memory.samples = []
+    agent = BS_brain.Agent(20, env.n_RB, env.n_Neighbor, cfg.Num_Feedback, env, cfg)
+    obs = {'v2v': [], 'v2i': [], 'edge': [], 'dest': []}
+    for step in range(3):
+        v2v, v2i, edge = zip(*[agent.get_state([k, 0]) for k in range(20)])
+        obs['v2v'].append(np.stack(v2v)); obs['v2i'].append(np.stack(v2i)); obs['edge'].append(np.stack(edge))
+        obs['dest'].append(np.array([v.destinations[0] for v in env.vehicles]))
+        a = np.random.randint(0, env.n_RB, size=(20, 1))
+        env.compute_reward_with_channel_selection(a.copy())
+        env.renew_positions()
+        env.renew_channels_fastfading()
+        env.Compute_Interference(a.copy())
+    np.savez_compressed(os.path.join(HERE, 'golden_observe_n20.npz'), **{k: np.stack(v) for k, v in obs.items()})
+    print('wrote golden_observe_n20.npz')
+
 
 if __name__ == '__main__':
     main()

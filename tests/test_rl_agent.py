@@ -140,3 +140,35 @@ def test_test_run_matches_reference_evaluation_loop():
         assert out[i].shape == g[name].shape, name
         assert np.allclose(out[i], g[name], rtol=1e-9, atol=1e-12), name
     assert len(agent.test_run(1, 2, False)) == 10
+
+
+def test_observation_at_twenty_links_matches_reference_get_state():
+    """Agent.observe() (all links at once) against the reference's per-link get_state at 20 links
+    (tests/golden/make_golden_testrun.py), incl. the adjacency rule of BS_brain.py:441-445."""
+    g = np.load(os.path.join(GOLDEN, 'golden_observe_n20.npz'))
+    random.seed(2020)
+    np.random.seed(2020)
+    cfg = RL_Config()
+    cfg.set_train_value(16, 0.5, 32, 1, 0.1)
+    env = make_env()
+    env.new_random_game(20)
+    brain = RecordingBrain(20, 3, 1, 16, env.n_Neighbor, env.n_RB)
+    agent = Agent(20, env.n_RB, env.n_Neighbor, 16, env, cfg, brain=brain)
+    for step in range(3):
+        state, adj = agent.observe()
+        assert np.array_equal([v.destinations[0] for v in env.vehicles], g['dest'][step])
+        assert np.allclose(state[:, 0:4], g['v2v'][step], rtol=1e-10, atol=1e-12)
+        assert np.allclose(state[:, 4:8], g['v2i'][step], rtol=1e-10, atol=1e-12)
+        assert np.all(state[:, 8] == env.V2V_power_dB_List[env.fixed_v2v_power_index])
+        assert np.allclose(state[:, 9:13], g['edge'][step], rtol=1e-10, atol=1e-12)
+        for k in range(20):                                  # same numbers as the per-link accessor
+            v2v, v2i, edge = agent.get_state([k, 0])
+            assert np.allclose(state[k, 0:4], v2v) and np.allclose(state[k, 9:13], edge)
+        want = np.ones((20, 20)) - np.eye(20)
+        want[g['dest'][step], np.arange(20)] = 0
+        assert np.array_equal(adj, want)
+        a = np.random.randint(0, env.n_RB, size=(20, 1))
+        env.compute_reward_with_channel_selection(a.copy())
+        env.renew_positions()
+        env.renew_channels_fastfading()
+        env.Compute_Interference(a.copy())

@@ -63,6 +63,27 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'golden_observe_n20.npz'), **{k: np.stack(v) for k, v in obs.items()})
     print('wrote golden_observe_n20.npz')
 
+    # ---- simulator at 100 links (BASELINE config 4's graph size): positions in full, channels as a strided sample
+    random.seed(2100)
+    np.random.seed(2100)
+    env = mg.make_env(Environment)
+    env.new_random_game(100)
+    big = {'pos': [], 'dest': [], 'v2v_sample': [], 'v2v_sum': [], 'v2i': [], 'v2v_rate': [], 'v2i_rate': []}
+    for step in range(3):
+        a = np.random.randint(0, env.n_RB, size=(100, 1))
+        r_v2v, r_v2i, _ = env.compute_reward_with_channel_selection(a.copy())
+        env.renew_positions()
+        env.renew_channels_fastfading()
+        env.Compute_Interference(a.copy())
+        big['pos'].append(np.array([v.position for v in env.vehicles], float))
+        big['dest'].append(np.array([v.destinations[0] for v in env.vehicles]))
+        big['v2v_sample'].append(env.V2V_channels_with_fastfading[::7, ::11, :].copy())
+        big['v2v_sum'].append(env.V2V_channels_with_fastfading.sum(axis=(0, 1)))
+        big['v2i'].append(env.V2I_channels_with_fastfading.copy())
+        big['v2v_rate'].append(r_v2v.copy()); big['v2i_rate'].append(r_v2i.copy())
+    np.savez_compressed(os.path.join(HERE, 'golden_env_n100.npz'), **{k: np.stack(v) for k, v in big.items()})
+    print('wrote golden_env_n100.npz')
+
 
 if __name__ == '__main__':
     main()

@@ -71,3 +71,26 @@ def test_turns_and_exits_match_reference():
             k += 1
         changed += sum(v.direction != str(g['place_dir'][rd, i]) for i, v in enumerate(env.vehicles))
     assert changed > 100          # the fixture really exercises turns and exits
+
+
+def test_hundred_link_simulator_matches_reference():
+    """BASELINE config 4's graph size: positions / destinations bit-exact, channels (strided sample + column sums) and
+    rates to 1e-9 against the reference simulator (tests/golden/make_golden_testrun.py)."""
+    g = np.load(os.path.join(GOLDEN, 'golden_env_n100.npz'))
+    random.seed(2100)
+    np.random.seed(2100)
+    env = make_env()
+    env.new_random_game(100)
+    for step in range(3):
+        a = np.random.randint(0, env.n_RB, size=(100, 1))
+        r_v2v, r_v2i, _ = env.compute_reward_with_channel_selection(a.copy())
+        env.renew_positions()
+        env.renew_channels_fastfading()
+        env.Compute_Interference(a.copy())
+        assert np.array_equal(np.array([v.position for v in env.vehicles], float), g['pos'][step])
+        assert np.array_equal([v.destinations[0] for v in env.vehicles], g['dest'][step])
+        assert np.allclose(env.V2V_channels_with_fastfading[::7, ::11, :], g['v2v_sample'][step], rtol=1e-11, atol=1e-9)
+        assert np.allclose(env.V2V_channels_with_fastfading.sum(axis=(0, 1)), g['v2v_sum'][step], rtol=1e-11, atol=1e-6)
+        assert np.allclose(env.V2I_channels_with_fastfading, g['v2i'][step], rtol=1e-11, atol=1e-9)
+        assert np.allclose(r_v2v, g['v2v_rate'][step], rtol=1e-9, atol=1e-12)
+        assert np.allclose(r_v2i, g['v2i_rate'][step], rtol=1e-9, atol=1e-12)

@@ -721,9 +721,11 @@ int layer_work(const LayerDesc& ld) { return (ld.kp / 16) * (ld.np / 16); }
 int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total_work, const WgSeg* segs, int n_seg,
                const float* dpre, int d_stride, WgradArgs& a) {
   int chunk;
-  // measured at batch 4096 x 20 nodes: 1024 rows per workgroup for the GNN stages, 768 for the Dense layers
   const bool gnn_kind = kind < WG_KIND_DENSE0 || kind == WG_KIND_EMBED_NONBR;
-  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, gnn_kind ? 1024 : 768);
+  // measured at batch 4096 x 20 nodes in the merged launch: the SAME 1024 rows per workgroup for every role (87 us) beats
+  // 1024 / 768 for the GNN / Dense families (102 us, the optimum when the two families were separate launches)
+  static const int rows_gnn = env_int("V2X_WG_CHUNK_GNN", 1024), rows_dense = env_int("V2X_WG_CHUNK_DENSE", 1024);
+  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, gnn_kind ? rows_gnn : rows_dense);
   if (nc > m->slab_cap) FAIL(m, V2X_ESTATE, "wgrad: slabs not pre-sized (%d > %d)", nc, m->slab_cap);
   ld.n_slabs = nc;                       // remembered for the slab reduction
   memset(&a, 0, sizeof(a));
@@ -1091,7 +1093,8 @@ GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
 
 int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   int chunk, nc = 1;
-  for (int rows : {768, 1024}) nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
+  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), 768})
+    nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
   if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 1, n_slots));     // the fewest tiles (one) split most
   return nc + 1;
 }

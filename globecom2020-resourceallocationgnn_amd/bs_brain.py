@@ -38,12 +38,14 @@ class GnnQModel(object):
     """Keras-`Model`-like object over one GnnEngine."""
 
     def __init__(self, spec: GnnSpec, device=0, seed=None, use_graph=False, validate_adjacency=True,
-                 lr=1e-3, beta_1=0.5, beta_2=0.999, epsilon=1e-7, data_parallel=False, process_group=None, engine=None):
+                 lr=1e-3, beta_1=0.5, beta_2=0.999, epsilon=1e-7, data_parallel=False, process_group=None, engine=None,
+                 model_index=0):
         """data_parallel: every fit step shards the minibatch over the ranks of `process_group` (default group) and
         all-reduces the gradient (v2xgnn.dp); all ranks must call fit with the SAME full minibatch.
         engine: an object with GnnEngine's interface (the CPU tests inject one); default: the gfx950 engine,
         which raises without a GPU."""
         self.spec = spec
+        self.model_index = int(model_index)        # how many models of this shape the session built before (layer names)
         self.engine = engine if engine is not None else GnnEngine(
             spec, device=device, use_graph=use_graph, lr=lr, beta_1=beta_1, beta_2=beta_2,
             epsilon=epsilon)                                 # Adam(lr=0.001, beta_1=0.5, beta_2=0.999) BS_brain.py:212
@@ -153,9 +155,19 @@ class GnnQModel(object):
         q = self.engine.forward(PackedBatch.from_dense(x, e, adj, nbr))
         return q.reshape(x.shape[0], self.spec.n_nodes, self.spec.n_channels)
 
+    @staticmethod
+    def consume_fit_shuffle(n_samples):
+        """Keras `Model.fit(shuffle=True)` shuffles the sample indices with the GLOBAL numpy RNG on every call, even when
+        the data is a single batch -- the same generator the epsilon-greedy policy and Memory.sample draw
+        from (BS_brain.py:261,268,330,333).  The one-batch paths (fit_arrays, the device-resident replay) skip the
+        gather but consume the identical draw, so a seeded run visits the same RNG stream on every path."""
+        if n_samples > 1:
+            np.random.shuffle(np.arange(n_samples))
+
     def fit_arrays(self, x, e, adj, y, nbr=None):
         """One Adam step on the whole batch (what the reference's fit call amounts to, BS_brain.py:218-223);
         y [B, N, C].  -> History with the same keys as fit."""
+        self.consume_fit_shuffle(np.shape(x)[0])
         loss = self._train_step(PackedBatch.from_dense(x, e, adj, nbr),
                                 np.asarray(y, np.float32).reshape(-1, self.spec.n_channels))
         loss = np.asarray(loss, np.float64)
@@ -179,26 +191,30 @@ class GnnQModel(object):
 
     def keras_layer_table(self):
         """[(layer name, [weight names])] of the layers that own weights, in the order of get_weights() -- the names
-        Keras gives the reference model's layers (BS_brain.py:121-200; auto-named layers get their class's snake-case
-        name and a running index)."""
+        Keras gives the reference model's layers (BS_brain.py:121-200).  Auto-named layers get their class's snake-case
+        name and a running index in CREATION order: the message-passing layers are created stage by stage, node by node
+        (:154-164: gnn_layer_1..N, then N+1..2N), the hidden Dense layers node by node (:176-200: dense_1/2/3 are node
+        1's 80/40/20, dense_4/5/6 node 2's, ...).  The running index is global to the Keras session, so the second
+        model BS builds (the target network, :106) continues where the first stopped: `model_index` offsets it."""
         sp = self.spec
-        slots = range(1, sp.n_nodes + 1) if not sp.share_weights else [None]
-        table, gnn_uid, dense_uid = [], 0, 0
+        slots = list(range(1, sp.n_nodes + 1)) if not sp.share_weights else [None]
+        n_slots = len(slots)
+        gnn_base = self.model_index * sp.n_mp_layers * n_slots
+        dense_base = self.model_index * 3 * n_slots
+        table = []
         for stage in range(sp.n_mp_layers + 1):
-            for k in slots:
+            for i, k in enumerate(slots):
                 if stage == 0:
                     name = 'D%d_GNN' % k if k else 'GNN'
                 else:
-                    gnn_uid += 1
-                    name = 'gnn_layer_%d' % gnn_uid
+                    name = 'gnn_layer_%d' % (gnn_base + (stage - 1) * n_slots + i + 1)
                 table.append((name, ['%s/%s:0' % (name, w) for w in ('W1', 'W2', 'W3', 'bias')]))
         for layer in range(4):
-            for k in slots:
+            for i, k in enumerate(slots):
                 if layer == 3:
                     name = 'D%d_Decide_Output' % k if k else 'Decide_Output'
                 else:
-                    dense_uid += 1
-                    name = 'dense_%d' % dense_uid
+                    name = 'dense_%d' % (dense_base + 3 * i + layer + 1)
                 table.append((name, ['%s/kernel:0' % name, '%s/bias:0' % name]))
         return table
 
@@ -253,14 +269,17 @@ class BS(object):
         self._dp, self._group, self._engine_factory = data_parallel, process_group, engine_factory
         ss = np.random.SeedSequence(seed).spawn(2)
         self._seeds = [int(s.generate_state(1)[0]) for s in ss]
+        self._n_models = 0
         self.model = self._create_model()
         self.target_model = self._create_model()
 
     def _create_model(self):
         seed = self._seeds.pop(0) if self._seeds else None
         engine = self._engine_factory(self._spec) if self._engine_factory is not None else None
+        index = self._n_models
+        self._n_models += 1
         return GnnQModel(self._spec, device=self._device, seed=seed, use_graph=self._use_graph,
-                         data_parallel=self._dp, process_group=self._group, engine=engine)
+                         data_parallel=self._dp, process_group=self._group, engine=engine, model_index=index)
 
     def train_dnn(self, data_train, labels, batch_size):
         epochs = 1

@@ -86,7 +86,16 @@ struct AggArgs {
   int gpw;                              // graphs per workgroup (power of two)
   int rows_cap, edges_cap, mask_words;  // LDS capacities
   int transpose;                        // 0: out[q] = sum_{p->q} src[p];  1: out[p] = sum_{p->q} src[q]
+  int* err;                             // host-visible flag word: bit 0 set when a tile exceeds the LDS capacities
 };
+
+// A workgroup whose graphs hold more rows / edges than the LDS tile was sized for (the batch's max_nodes / max_edges
+// understate it) must not stage them: it raises the flag and leaves its output rows untouched.
+#define V2X_TILE_GUARD(a, nrows, nedges)                                              \
+  if ((nrows) > (a).rows_cap || (nedges) > (a).edges_cap || (nrows) < 0 || (nedges) < 0) { \
+    if (threadIdx.x == 0 && (a).err) atomicOr((a).err, 1);                            \
+    return;                                                                           \
+  }
 
 template <bool TRANSPOSE>   // forward gather (false) / its transpose for the backward pass (true)
 __global__ __launch_bounds__(256) void k_agg(AggArgs a_in) {
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(256) void k_agg(AggArgs a_in) {
   const int e_begin = a.row_ptr[r_begin];
   const int nedges = a.row_ptr[r_end] - e_begin;
   const int LPR = 1 << a.lpr_shift;
+  V2X_TILE_GUARD(a, nrows, nedges)
 
   // ---- stage: the WG's graphs are contiguous rows / contiguous edges => coalesced reads
   for (int i = tid; i < (nrows << a.lpr_shift); i += 256) {
@@ -223,6 +233,10 @@ __global__ __launch_bounds__(256) void k_agg_small(AggArgs a) {
   const int nrows = r_end - r_begin;
   const int LPR = 1 << a.lpr_shift;
   const int nf4 = nrows << a.lpr_shift;
+  if (nrows > a.rows_cap || nrows < 0) {           // (edge count checked below, once it is known)
+    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
+    return;
+  }
 
   // worker = LPR lanes owning up to 4 destination rows of one graph
   const int worker = tid >> a.lpr_shift, li4 = (tid & (LPR - 1)) << 2;
@@ -258,6 +272,10 @@ __global__ __launch_bounds__(256) void k_agg_small(AggArgs a) {
     else mkv[k] = make_float4(1.f, 1.f, 1.f, 1.f);
   }
   const int nedges = e_end - e_begin;
+  if (nedges > a.edges_cap || nedges < 0) {        // workgroup-uniform: nothing has touched LDS yet
+    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
+    return;
+  }
   int cv[4];
   const int e_safe = nedges > 0 ? e_begin : 0;        // an edge-less tile reads entry 0 (col_idx holds >= 1 entry)
 #pragma unroll
@@ -1488,10 +1506,46 @@ __global__ __launch_bounds__(256) void k_dqn_targets(const float* q, const float
   if (row >= n_rows) return;
   float mx = qn[(int64_t)row * C];
   for (int c = 1; c < C; ++c) mx = fmaxf(mx, qn[(int64_t)row * C + c]);
-  // numpy semantics of `r + gamma * max(p_)` with p_ float32 and r float64: fp32 product, double sum, fp32 feed
-  const float t = (float)(reward[row / n_nodes] + (double)((float)gamma * mx));
+  // `r + GAMMA * np.amax(p_)` (BS_brain.py:690) scalar by scalar with p_ float32: under the reference's numpy-1.x
+  // stack the product is float64 (python float x np.float32), rounded to fp32 once when stored.  (numpy >= 2 / NEP 50
+  // rounds the product to fp32 first; the fixtures captured under numpy 2.2.6 differ from this by <= 1 ulp.)
+  const float t = (float)(reward[row / n_nodes] + gamma * (double)mx);
   const int a = action[row];
   for (int c = 0; c < C; ++c) y[(int64_t)row * C + c] = c == a ? t : q[(int64_t)row * C + c];
+}
+
+// Contract check of a device-resident batch (include/v2xgnn.h "Data layout"): every graph has 1..max_nodes rows and at
+// most max_edges edges, row_ptr is monotone, every source id lies inside its graph and the sources of a row are strictly
+// ascending (=> no duplicate edges: the backward pass de-duplicates through bit masks, the forward pass would not).
+// One workgroup per graph (grid-stride); flag bits: 1 sizes, 2 row_ptr, 4 source range, 8 order / duplicates.
+__global__ __launch_bounds__(256) void k_validate_batch(const int32_t* graph_off, const int32_t* row_ptr, const int32_t* col_idx,
+                                                        int n_graphs, int n_rows, int n_edges, int n_nodes, int max_nodes,
+                                                        int max_edges, int* flag) {
+  int bad = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (row_ptr[0] != 0 || row_ptr[n_rows] != n_edges) bad |= 2;
+    if (graph_off && (graph_off[0] != 0 || graph_off[n_graphs] != n_rows)) bad |= 1;
+  }
+  for (int g = blockIdx.x; g < n_graphs; g += gridDim.x) {
+    const int r0 = graph_off ? graph_off[g] : g * n_nodes;
+    const int r1 = graph_off ? graph_off[g + 1] : r0 + n_nodes;
+    const int n = r1 - r0;
+    if (n < 1 || n > max_nodes || r0 < 0 || r1 > n_rows) { bad |= 1; continue; }
+    const int e0 = row_ptr[r0], e1 = row_ptr[r1];
+    if (e1 < e0 || e1 - e0 > max_edges || e0 < 0 || e1 > n_edges) { bad |= 2; continue; }
+    for (int q = r0 + threadIdx.x; q < r1; q += 256) {
+      const int a0 = row_ptr[q], a1 = row_ptr[q + 1];
+      if (a1 < a0 || a0 < e0 || a1 > e1) { bad |= 2; continue; }
+      int prev = -1;
+      for (int e = a0; e < a1; ++e) {
+        const int c = col_idx[e];
+        if (c < 0 || c >= n) bad |= 4;
+        if (c <= prev) bad |= 8;
+        prev = c;
+      }
+    }
+  }
+  if (bad) atomicOr(flag, bad << 4);
 }
 
 }  // namespace v2x

@@ -1,0 +1,391 @@
+// Graph-major FUSED graph layers for fixed-size graphs (the headline configuration: 20 links, per-node weights).
+//
+// kernels.hpp runs a layer as two launches per direction -- aggregation (graph-major, AggLayer.call
+// BS_brain.py:69-76) and node update (slot-major, GNNLayer.call :44-51) -- because with per-node weights a workgroup
+// wants ONE slot's weight image in LDS.  Here a workgroup owns 16 whole graphs instead, so that the 16 rows of node
+// slot k (one per graph) are exactly one 16-row MFMA tile:
+//   * the tile's feature rows h_s live in LDS for the whole layer (the gather of AggLayer never leaves the CU),
+//   * slot k's weights are NOT staged in LDS: they stream from L2 straight into MFMA A fragments, from a
+//     "fragment-major" copy of the parameters (k_pack_weights) in which every load is one coalesced 1 KiB wave access
+//     (tools/l2stream.hip: 25-33 TB/s of L2 reads are available, 8 B of weights per MFMA flop need 19 TB/s at peak),
+//   * all L+1 stages and L+1 aggregations of the forward pass are ONE launch (was 6 at L = 2), the L+1 transposed
+//     aggregations and L data gradients of the backward pass ONE launch (was 5); the activations h_s / a_s and the
+//     pre-activation gradients dpre_s are still written once each, because the weight-gradient launch (slot-major,
+//     k_wgrad) and the decision MLP read them.
+// 8 waves per workgroup = 2 per SIMD: while one wave issues its weight loads and gathers from LDS, the other one's
+// MFMAs keep the matrix pipe busy (a wave issues in order: tools/l2stream.hip measured 0.55-0.7 of the MFMA peak for a
+// single wave that prefetches for itself, and clocks that do NOT drop when both pipes run).
+// Arithmetic order is that of k_agg_small / k_gemm_rows, so the results are bitwise those of the unfused path.
+#pragma once
+#include "kernels.hpp"
+
+namespace v2x {
+
+constexpr int FZ_TG = 16;        // graphs per workgroup = rows of one slot's MFMA tile
+constexpr int FZ_WAVES = 8;
+constexpr int FZ_THREADS = 64 * FZ_WAVES;
+constexpr int FZ_MAXL = 8;
+
+typedef const __attribute__((address_space(1))) f32x4* gvec_p;
+
+// sizes of the fragment-major parameter copy (floats)
+template <int F>
+struct FzPack {
+  static constexpr int FB = F / 16, KB = 2 * FB + 1;
+  static constexpr int FWD0 = FB * 256 + F;             // stage 0: [1 k-block][FB n-tiles][64 lanes][4] + bias[F]
+  static constexpr int FWD = KB * FB * 256 + F;         // stage >= 1: [KB][FB][64][4] + bias[F]
+  static constexpr int BWD = FB * 2 * FB * 256;         // stage >= 1: [FB k-blocks][2 FB n-tiles][64][4]
+  static constexpr int ROWF = 4 * (FB | 1);             // LDS row of one k-group: FB float4 + pad to an ODD float4 count
+};
+
+struct PackArgs {
+  const float* params; float* pk_fwd; float* pk_bwd;
+  int64_t layer_off[FZ_MAXL + 1]; int64_t slot_stride[FZ_MAXL + 1]; RowPad pad[FZ_MAXL + 1];
+  int S;
+};
+
+// forward fragment  (stage, slot, kb, nt, lane, s) = W[real_row(kb*16 + 4*(lane>>4) + s)][nt*16 + (lane&15)]
+// backward fragment (stage, slot, kb, nt, lane, s) = W[real_row(orow(nt) + (lane&15))][kb*16 + 4*(lane>>4) + s],
+//   orow = the h rows (nt < FB) and the agg rows (nt >= FB) of the layer's padded K axis.
+// grid = (x, S, L+1)
+template <int F>
+__global__ __launch_bounds__(256) void k_pack_weights(PackArgs a) {
+  using P = FzPack<F>;
+  constexpr int FB = P::FB;
+  typedef const __attribute__((address_space(4))) unsigned char* CBytes;
+  CBytes kp = (CBytes)__builtin_amdgcn_kernarg_segment_ptr();
+  const int stage = blockIdx.z, slot = blockIdx.y, S = a.S;
+  const int64_t loff = *(const __attribute__((address_space(4))) int64_t*)(kp + offsetof(PackArgs, layer_off) + 8 * stage);
+  const int64_t sstr = *(const __attribute__((address_space(4))) int64_t*)(kp + offsetof(PackArgs, slot_stride) + 8 * stage);
+  RowPad pad;
+  pad.pad_at = *(const __attribute__((address_space(4))) int*)(kp + offsetof(PackArgs, pad) + 12 * stage);
+  pad.n_pad = *(const __attribute__((address_space(4))) int*)(kp + offsetof(PackArgs, pad) + 12 * stage + 4);
+  pad.k_real = *(const __attribute__((address_space(4))) int*)(kp + offsetof(PackArgs, pad) + 12 * stage + 8);
+  const float* W = a.params + loff + slot * sstr;
+  const int kbs = stage ? P::KB : 1;
+  float* dst = a.pk_fwd + (stage ? (int64_t)S * P::FWD0 + ((int64_t)(stage - 1) * S + slot) * P::FWD : (int64_t)slot * P::FWD0);
+  const int n_f = kbs * FB * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_f + F; i += gridDim.x * 256) {
+    float v;
+    if (i < n_f) {
+      const int s = i & 3, lane = (i >> 2) & 63, c = i >> 8, nt = c % FB, kb = c / FB;
+      const int rr = real_row(pad, kb * 16 + 4 * (lane >> 4) + s);
+      v = rr >= 0 ? W[(int64_t)rr * F + nt * 16 + (lane & 15)] : 0.f;
+    } else {
+      v = W[(int64_t)pad.k_real * F + (i - n_f)];
+    }
+    dst[i] = v;
+  }
+  if (stage == 0) return;
+  float* dstb = a.pk_bwd + ((int64_t)(stage - 1) * S + slot) * P::BWD;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < P::BWD; i += gridDim.x * 256) {
+    const int s = i & 3, lane = (i >> 2) & 63, c = i >> 8, nt = c % (2 * FB), kb = c / (2 * FB);
+    const int orow = nt < FB ? nt * 16 : F + XE + (nt - FB) * 16;
+    const int rr = real_row(pad, orow + (lane & 15));
+    dstb[i] = W[(int64_t)rr * F + kb * 16 + 4 * (lane >> 4) + s];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS tile of the 16 graphs' feature rows, split by MFMA k-group so that every ds_read_b128 / ds_write_b128 of a
+// wave is conflict-free:  element (node p, graph j, feature f) lives at
+//     sub-array kg = (f % 16) / 4,  row p*16 + j,  float4 slot f / 16        (ROWF floats per row, an odd float4 count)
+// A 16-lane access group of a b128 LDS instruction holds 16 distinct graphs j (k-groups 0/1 or 2/3 mixed), the
+// sub-array stride and 16*ROWF are multiples of 64 banks, so the bank group is (ROWF4 * j + const) mod 16: distinct
+// for distinct j whatever the nodes p_j the lanes gather from.
+// ---------------------------------------------------------------------------------------------------------------
+struct FusedFwdArgs {
+  const float* xe; const int32_t* row_ptr; const int32_t* col_idx;
+  const float* pk;                                   // fragment-major forward weights (k_pack_weights)
+  float* h[FZ_MAXL + 1]; float* a[FZ_MAXL + 1];      // stage outputs h_s and their aggregations a_s, [R][F]
+  int n_graphs, N, L, S;                             // S = weight slots (N per-node, 1 shared)
+  int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
+  int* err;
+};
+
+__device__ __forceinline__ f32x4 ldnt4(const float* p) {      // L1-bypassing load (data another wave of this CU just wrote)
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
+
+template <int F>
+__global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a) {
+  using P = FzPack<F>;
+  constexpr int FB = P::FB, KB = P::KB, ROWF = P::ROWF;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, L = a.L;
+  const int SUB = N * FZ_TG * ROWF;                              // floats per k-group sub-array
+  float* sH = smem;                                              // [4][N*16][ROWF]
+  int* sRp = reinterpret_cast<int*>(sH + 4 * SUB);               // [16 N + 1] edge offsets relative to the tile
+  unsigned char* sCol = reinterpret_cast<unsigned char*>(sRp + FZ_TG * N + 1);   // [edges] graph-local sources
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kg = lane >> 4;
+  const int g0 = blockIdx.x * FZ_TG, ng = min(FZ_TG, a.n_graphs - g0);
+  const int r_begin = g0 * N, nrows = ng * N;
+  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
+  if (nedges > a.edges_cap || nedges < 0) {
+    if (tid == 0 && a.err) atomicOr(a.err, 1);
+    return;
+  }
+  for (int i = tid; i <= FZ_TG * N; i += FZ_THREADS) sRp[i] = i <= nrows ? a.row_ptr[r_begin + min(i, nrows)] - e_begin : nedges;
+  for (int i = tid; i < nedges; i += FZ_THREADS) sCol[i] = (unsigned char)min((unsigned)a.col_idx[e_begin + i], (unsigned)(N - 1));
+
+  typedef const __attribute__((address_space(4))) uint64_t* CQ;
+  CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
+  auto hptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedFwdArgs, h) / 8 + s]); };
+  auto aptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedFwdArgs, a) / 8 + s]); };
+
+  const bool valid = j < ng;
+  const int jc = valid ? j : ng - 1;                             // lanes of absent graphs shadow the last one, store nothing
+  float* myrow = sH + kg * SUB + j * ROWF;                       // + p*16*ROWF + kb*4
+
+  // ---- stage 0 (embed): h_0 = relu(xe . W0 + b0); the neighbour-init block is absent (always zero in the reference)
+  {
+    float* hp = hptr(0);
+    for (int k = wv; k < N; k += FZ_WAVES) {
+      const int64_t row = (int64_t)(g0 + jc) * N + k;
+      const float* wb = a.pk + (int64_t)(a.S == 1 ? 0 : k) * P::FWD0;
+      gvec_p wp = (gvec_p)wb + lane;
+      f32x4 w[FB], bias[FB];
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) w[nt] = wp[nt * 64];
+      const f32x4 xev = ld4(a.xe + row * XE + 4 * kg);
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) bias[nt] = ld4(wb + FB * 256 + nt * 16 + 4 * kg);
+      f32x4 acc[FB];
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nt = 0; nt < FB; ++nt) acc[nt] = V2X_MFMA(w[nt][s], xev[s], acc[nt]);
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) {
+        const f32x4 v = relu4(acc[nt] + bias[nt]);
+        if (valid) st4(hp + row * F + nt * 16 + 4 * kg, v);
+        st4(myrow + k * FZ_TG * ROWF + nt * 4, v);
+      }
+    }
+  }
+  __syncthreads();
+
+  // neighbour gather of slot k for this lane's graph: a[kb] = sum over in-edges, ascending sources (k_agg_small order)
+  auto gather = [&](int k, f32x4 (&ag)[FB]) {
+#pragma unroll
+    for (int kb = 0; kb < FB; ++kb) ag[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int rl = j * N + k;
+    int e = sRp[rl];
+    const int e1 = sRp[rl + 1];
+    for (; e + 4 <= e1; e += 4) {
+      const float* b0 = myrow + (int)sCol[e] * (FZ_TG * ROWF);
+      const float* b1 = myrow + (int)sCol[e + 1] * (FZ_TG * ROWF);
+      const float* b2 = myrow + (int)sCol[e + 2] * (FZ_TG * ROWF);
+      const float* b3 = myrow + (int)sCol[e + 3] * (FZ_TG * ROWF);
+      f32x4 v0[FB], v1[FB], v2[FB], v3[FB];
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) { v0[kb] = ld4(b0 + kb * 4); v1[kb] = ld4(b1 + kb * 4); v2[kb] = ld4(b2 + kb * 4); v3[kb] = ld4(b3 + kb * 4); }
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) { ag[kb] += v0[kb]; ag[kb] += v1[kb]; ag[kb] += v2[kb]; ag[kb] += v3[kb]; }
+    }
+    for (; e < e1; ++e) {
+      const float* b0 = myrow + (int)sCol[e] * (FZ_TG * ROWF);
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) ag[kb] += ld4(b0 + kb * 4);
+    }
+  };
+
+  // ---- stages 1..L: a_{s-1} = Agg(h_{s-1}) from LDS, h_s = act([h_{s-1} | xe | a_{s-1}] . W_s + b_s)
+  for (int s = 1; s <= L; ++s) {
+    float* hp = hptr(s);
+    float* ap = aptr(s - 1);
+    const float* stage_pk = a.pk + (int64_t)a.S * P::FWD0 + (int64_t)(s - 1) * a.S * P::FWD;
+    const bool relu = s < L;
+    for (int k = wv; k < N; k += FZ_WAVES) {
+      const int64_t row = (int64_t)(g0 + jc) * N + k;
+      const float* wb = stage_pk + (int64_t)(a.S == 1 ? 0 : k) * P::FWD;
+      gvec_p wp = (gvec_p)wb + lane;
+      f32x4 w[KB * FB];
+#pragma unroll
+      for (int c = 0; c < KB * FB; ++c) w[c] = wp[c * 64];       // 36 x 1 KiB from L2; lands while the gather runs
+      const f32x4 xev = ld4(a.xe + row * XE + 4 * kg);
+      f32x4 ag[FB], hb[FB];
+      gather(k, ag);
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) hb[kb] = ld4(myrow + k * FZ_TG * ROWF + kb * 4);
+      if (valid) {
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) st4(ap + row * F + kb * 16 + 4 * kg, ag[kb]);
+      }
+      f32x4 acc[FB];
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        const f32x4 bv = kb < FB ? hb[kb < FB ? kb : 0] : (kb == FB ? xev : ag[kb > FB ? kb - FB - 1 : 0]);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int nt = 0; nt < FB; ++nt) acc[nt] = V2X_MFMA(w[kb * FB + nt][s4], bv[s4], acc[nt]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) {
+        f32x4 v = acc[nt] + ld4(wb + KB * FB * 256 + nt * 16 + 4 * kg);
+        if (relu) v = relu4(v);
+        if (valid) st4(hp + row * F + nt * 16 + 4 * kg, v);
+      }
+    }
+    __syncthreads();                       // every wave is done gathering from h_{s-1}; all h_s rows have left the CU
+    for (int k = wv; k < N; k += FZ_WAVES) {                     // h_s -> LDS (own slots, same lane mapping as the stores)
+      const int64_t row = (int64_t)(g0 + jc) * N + k;
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(myrow + k * FZ_TG * ROWF + nt * 4, ldnt4(hp + row * F + nt * 16 + 4 * kg));
+    }
+    __syncthreads();
+  }
+
+  // ---- a_L = Agg(h_L) for the decision MLP
+  {
+    float* ap = aptr(L);
+    for (int k = wv; k < N; k += FZ_WAVES) {
+      const int64_t row = (int64_t)(g0 + jc) * N + k;
+      f32x4 ag[FB];
+      gather(k, ag);
+      if (valid) {
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) st4(ap + row * F + kb * 16 + 4 * kg, ag[kb]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward of the graph layers:  for s = L..0   dpre_s = (dh_s + Agg^T(dagg_s)) * act'(h_s),
+//                                for s >= 1     [dh_{s-1} | dagg_{s-1}] = dpre_s . [W1h_s | W3_s]^T
+// In: gha = [dh_L | dagg_L] (decision-MLP backward).  Out: dpre_s for the weight-gradient launch.  gha is reused as
+// the scratch of the lower stages (a row is read and rewritten by the wave that owns its slot).
+// ---------------------------------------------------------------------------------------------------------------
+struct FusedBwdArgs {
+  const int32_t* row_ptr; const int32_t* col_idx;
+  const float* pk;                                   // fragment-major backward weights
+  const float* h[FZ_MAXL + 1];                       // forward activations (ReLU' gates)
+  float* dpre[FZ_MAXL + 1];
+  float* gha;                                        // [R][2F]
+  int n_graphs, N, L, S, edges_cap;
+  int* err;
+};
+
+template <int F>
+__global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a) {
+  using P = FzPack<F>;
+  constexpr int FB = P::FB, ROWF = P::ROWF;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int N = a.N, L = a.L;
+  const int SUB = N * FZ_TG * ROWF;
+  float* sD = smem;                                              // dagg tile, same layout as the forward tile
+  int* sRp = reinterpret_cast<int*>(sD + 4 * SUB);               // [16 N + 1]
+  unsigned* sM = reinterpret_cast<unsigned*>(sRp + FZ_TG * N + 1);   // [16 N] out-neighbour bit masks (N <= 32)
+  unsigned char* sCol = reinterpret_cast<unsigned char*>(sM + FZ_TG * N);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, kg = lane >> 4;
+  const int g0 = blockIdx.x * FZ_TG, ng = min(FZ_TG, a.n_graphs - g0);
+  const int r_begin = g0 * N, nrows = ng * N;
+  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
+  if (nedges > a.edges_cap || nedges < 0) {
+    if (tid == 0 && a.err) atomicOr(a.err, 1);
+    return;
+  }
+  for (int i = tid; i <= FZ_TG * N; i += FZ_THREADS) sRp[i] = i <= nrows ? a.row_ptr[r_begin + min(i, nrows)] - e_begin : nedges;
+  for (int i = tid; i < nedges; i += FZ_THREADS) sCol[i] = (unsigned char)min((unsigned)a.col_idx[e_begin + i], (unsigned)(N - 1));
+  for (int i = tid; i < FZ_TG * N; i += FZ_THREADS) sM[i] = 0u;
+  __syncthreads();
+  // transposed adjacency: bit q of sM[j*N + p] = edge p -> q (integer atomics: order-independent)
+  for (int r = tid; r < nrows; r += FZ_THREADS) {
+    const int jj = r / N, q = r - jj * N;
+    for (int e = sRp[r]; e < sRp[r + 1]; ++e) atomicOr(&sM[jj * N + sCol[e]], 1u << q);
+  }
+
+  typedef const __attribute__((address_space(4))) uint64_t* CQ;
+  CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
+  auto hptr = [&](int s) { return reinterpret_cast<const float*>(kq[offsetof(FusedBwdArgs, h) / 8 + s]); };
+  auto dptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedBwdArgs, dpre) / 8 + s]); };
+
+  const bool valid = j < ng;
+  const int jc = valid ? j : ng - 1;
+  float* myrow = sD + kg * SUB + j * ROWF;
+
+  auto load_tile = [&]() {                                       // dagg part of gha -> LDS (own slots)
+    for (int k = wv; k < N; k += FZ_WAVES) {
+      const int64_t row = (int64_t)(g0 + jc) * N + k;
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(myrow + k * FZ_TG * ROWF + nt * 4, ldnt4(a.gha + row * (2 * F) + F + nt * 16 + 4 * kg));
+    }
+  };
+  load_tile();
+  __syncthreads();
+
+  for (int s = L; s >= 0; --s) {
+    const float* hp = hptr(s);
+    float* dp = dptr(s);
+    const float* stage_pk = a.pk + (int64_t)(s > 0 ? s - 1 : 0) * a.S * P::BWD;
+    const bool gate = s < L;
+    for (int k = wv; k < N; k += FZ_WAVES) {
+      const int64_t row = (int64_t)(g0 + jc) * N + k;
+      gvec_p wp = (gvec_p)(stage_pk + (int64_t)(a.S == 1 ? 0 : k) * P::BWD) + lane;
+      f32x4 w[FB * 2 * FB];
+      if (s > 0) {
+#pragma unroll
+        for (int c = 0; c < FB * 2 * FB; ++c) w[c] = wp[c * 64];
+      }
+      f32x4 dh[FB], hm[FB];
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) dh[nt] = ldnt4(a.gha + row * (2 * F) + nt * 16 + 4 * kg);
+      if (gate) {
+#pragma unroll
+        for (int nt = 0; nt < FB; ++nt) hm[nt] = ld4(hp + row * F + nt * 16 + 4 * kg);
+      }
+      // transposed gather, ascending destinations (k_agg_small<true> order)
+      f32x4 acc[FB];
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      unsigned bits = sM[j * N + k];
+      while (bits) {
+        const int q = __builtin_ctz(bits);
+        bits &= bits - 1;
+        const float* b0 = myrow + q * (FZ_TG * ROWF);
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) acc[kb] += ld4(b0 + kb * 4);
+      }
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) {
+        acc[kb] += dh[kb];
+        if (gate) acc[kb] = gate4(acc[kb], hm[kb]);
+        if (valid) st4(dp + row * F + kb * 16 + 4 * kg, acc[kb]);
+      }
+      if (s > 0) {
+        f32x4 o[2 * FB];
+#pragma unroll
+        for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb)
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = V2X_MFMA(w[kb * 2 * FB + nt][s4], acc[kb][s4], o[nt]);
+        if (valid) {
+#pragma unroll
+          for (int nt = 0; nt < 2 * FB; ++nt) st4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt]);
+        }
+      }
+    }
+    if (s > 0) {
+      __syncthreads();                     // all gathers from dagg_s done; the new [dh | dagg] rows have left the CU
+      load_tile();
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace v2x

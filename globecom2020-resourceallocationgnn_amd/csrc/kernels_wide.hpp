@@ -309,6 +309,7 @@ struct AggDenseArgs {
   int g_base, n_graphs, n_nodes, F;
   int n_fg;                             // 64-wide feature groups per graph (one workgroup each)
   int rows_cap, mask_words;             // rows_cap: max nodes rounded up to 16
+  int* err;                             // host-visible flag word (bit 0: a graph exceeds rows_cap)
 };
 
 // CSR-by-destination -> per-source bit masks, one workgroup per graph (integer atomics in LDS: order-independent).
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
   const int g = a.g_base + blockIdx.x;
   const int r_begin = a.graph_off ? a.graph_off[g] : g * a.n_nodes;
   const int n = (a.graph_off ? a.graph_off[g + 1] : r_begin + a.n_nodes) - r_begin;
+  if (n > a.rows_cap || n < 0) { if (tid == 0 && a.err) atomicOr(a.err, 1); return; }
   for (int i = tid; i < n * a.mask_words; i += 256) sM[i] = 0u;
   __syncthreads();
   for (int i = tid; i < n * 32; i += 256) {                                 // 32 threads per destination row
@@ -331,8 +333,11 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
     for (int u = 0; u < 4; ++u) p[u] = e0 + 32 * u < e1 ? a.col_idx[e0 + 32 * u] : -1;   // 4 loads in flight
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (p[u] >= 0) atomicOr(&sM[p[u] * a.mask_words + (q >> 5)], 1u << (q & 31));
-    for (int e = e0 + 128; e < e1; e += 32) atomicOr(&sM[a.col_idx[e] * a.mask_words + (q >> 5)], 1u << (q & 31));
+      if (p[u] >= 0 && p[u] < n) atomicOr(&sM[p[u] * a.mask_words + (q >> 5)], 1u << (q & 31));
+    for (int e = e0 + 128; e < e1; e += 32) {
+      const int pp = a.col_idx[e];
+      if (pp >= 0 && pp < n) atomicOr(&sM[pp * a.mask_words + (q >> 5)], 1u << (q & 31));
+    }
   }
   __syncthreads();
   for (int i = tid; i < n * a.mask_words; i += 256) a.adj[(int64_t)r_begin * a.mask_words + i] = sM[i];
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(256) void k_agg_dense(AggDenseArgs a) {
   const int g = a.g_base + gl, f0 = fg << 6;
   const int r_begin = a.graph_off ? a.graph_off[g] : g * a.n_nodes;
   const int n = (a.graph_off ? a.graph_off[g + 1] : r_begin + a.n_nodes) - r_begin;
+  if (n > a.rows_cap || n < 1) { if (tid == 0 && a.err) atomicOr(a.err, 1); return; }
 
   // stage the graph's [n][64] feature slice (4 loads in flight per thread) and its adjacency bit masks
   const int n_mw = n * a.mask_words;

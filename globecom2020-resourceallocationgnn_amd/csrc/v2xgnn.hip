@@ -4,6 +4,7 @@
 #include "../../include/v2xgnn.h"
 #include "kernels.hpp"
 #include "kernels_wide.hpp"
+#include "kernels_fused.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -66,6 +67,9 @@ struct v2x_model {
   // staging for host-side inputs
   DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
   DevBuf adj_mask;              // adjacency bit masks of the current batch (dense-graph aggregation)
+  float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
+  int* flag_host = nullptr;     // pinned, device-mapped word the kernels raise on a contract violation (tile guards,
+  int* flag_dev = nullptr;      // k_validate_batch); read by the host after any synchronising call
   bool have_fwd = false;
   std::string err;
   // profiling
@@ -189,7 +193,16 @@ void set_attrs_f() {
   allow_big_lds((const void*)k_wgrad<F, 2>);
 }
 
+template <int F>
+void set_attrs_fused() {
+  allow_big_lds((const void*)k_gnn_fwd_fused<F>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F>);
+}
+
 void set_attrs(int F) {
+  if (F == 16) set_attrs_fused<16>();
+  if (F == 32) set_attrs_fused<32>();
+  if (F == 64) set_attrs_fused<64>();
   allow_big_lds((const void*)k_agg<false>);
   allow_big_lds((const void*)k_agg<true>);
   allow_big_lds((const void*)k_agg_dense<false>);
@@ -275,12 +288,76 @@ int ensure_slabs(v2x_model* m, int nc) {
   return V2X_OK;
 }
 
+// ------------------------------------------------------------------------------------ device-side error flag
+struct FlagWord { int* host = nullptr; int* dev = nullptr; };
+int alloc_flag(FlagWord* f) {
+  void* h = nullptr;
+  if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return V2X_EHIP;
+  memset(h, 0, 64);
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { hipHostFree(h); return V2X_EHIP; }
+  f->host = (int*)h; f->dev = (int*)d;
+  return V2X_OK;
+}
+FlagWord* global_flag() {            // the per-kernel entry points that take no model handle
+  static FlagWord f;
+  static const bool once = [] { alloc_flag(&f); return true; }();
+  (void)once;
+  return &f;
+}
+int* flag_dev_of(v2x_model* m) { return m ? m->flag_dev : global_flag()->dev; }
+
+// to be called after the stream was synchronised: reports and clears what the kernels raised
+int check_flag(v2x_model* m) {
+  volatile int* p = m ? m->flag_host : global_flag()->host;
+  if (!p) return V2X_OK;
+  const int v = *p;
+  if (!v) return V2X_OK;
+  *p = 0;
+  if (v & 1) FAIL(m, V2X_EINVAL, "batch: a graph has more rows / edges than max_nodes / max_edges allow (LDS tile guard); results are invalid");
+  FAIL(m, V2X_EINVAL, "batch violates the layout contract:%s%s%s%s", (v >> 4) & 1 ? " graph sizes vs max_nodes / graph_off;" : "",
+       (v >> 4) & 2 ? " row_ptr not monotone / edge counts vs max_edges;" : "", (v >> 4) & 4 ? " source id outside its graph;" : "",
+       (v >> 4) & 8 ? " sources of a row not strictly ascending (duplicate edges);" : "");
+}
+
 // ------------------------------------------------------------------------------------ batches
 struct DevBatch {
   int B, R, E, max_nodes, max_edges;
   const float* xe; const float* nbr;
   const int32_t* goff; const int32_t* rp; const int32_t* ci;
 };
+
+// Host batches are checked against the layout contract before anything is copied (O(B) for the sizes that size the
+// LDS tiles, O(E) for the edge list; V2X_TRUSTED_BATCHES=1 skips the O(E) part).  Device batches: v2x_validate_batch.
+int validate_host_batch(v2x_model* m, const v2x_batch* b, int n_nodes) {
+  const int B = b->n_graphs, R = b->n_rows;
+  const int32_t *go = b->graph_off, *rp = b->row_ptr, *ci = b->col_idx;
+  if (rp[0] != 0 || rp[R] != b->n_edges) FAIL(m, V2X_EINVAL, "batch: row_ptr[0] != 0 or row_ptr[n_rows] != n_edges");
+  if (go && (go[0] != 0 || go[B] != R)) FAIL(m, V2X_EINVAL, "batch: graph_off[0] != 0 or graph_off[n_graphs] != n_rows");
+  static const bool trusted = getenv("V2X_TRUSTED_BATCHES") != nullptr;
+  for (int g = 0; g < B; ++g) {
+    const int64_t r0 = go ? go[g] : (int64_t)g * n_nodes, r1 = go ? go[g + 1] : r0 + n_nodes;
+    const int64_t n = r1 - r0;
+    if (n < 1 || n > b->max_nodes || r0 < 0 || r1 > R)
+      FAIL(m, V2X_EINVAL, "batch: graph %d has %lld rows, max_nodes is %d", g, (long long)n, b->max_nodes);
+    const int64_t e0 = rp[r0], e1 = rp[r1];
+    if (e1 < e0 || e1 - e0 > b->max_edges)
+      FAIL(m, V2X_EINVAL, "batch: graph %d has %lld edges, max_edges is %d", g, (long long)(e1 - e0), b->max_edges);
+    if (trusted) continue;
+    for (int64_t q = r0; q < r1; ++q) {
+      const int a0 = rp[q], a1 = rp[q + 1];
+      if (a1 < a0 || a0 < e0 || a1 > e1) FAIL(m, V2X_EINVAL, "batch: row_ptr not monotone at row %lld", (long long)q);
+      int prev = -1;
+      for (int e = a0; e < a1; ++e) {
+        const int c = ci[e];
+        if (c < 0 || c >= n) FAIL(m, V2X_EINVAL, "batch: source id %d of row %lld lies outside its %lld-node graph", c, (long long)q, (long long)n);
+        if (c <= prev) FAIL(m, V2X_EINVAL, "batch: sources of row %lld are not strictly ascending (duplicate edge?)", (long long)q);
+        prev = c;
+      }
+    }
+  }
+  return V2X_OK;
+}
 
 int resolve_batch(v2x_model* m, const v2x_batch* b, DevBatch* d, hipStream_t st) {
   if (!b || b->n_graphs <= 0 || b->n_rows <= 0 || !b->xe || !b->row_ptr || (b->n_edges > 0 && !b->col_idx))
@@ -295,6 +372,7 @@ int resolve_batch(v2x_model* m, const v2x_batch* b, DevBatch* d, hipStream_t st)
     d->xe = b->xe; d->nbr = b->nbr_init; d->goff = b->graph_off; d->rp = b->row_ptr; d->ci = b->col_idx;
     return V2X_OK;
   }
+  CHK(validate_host_batch(m, b, m->N));
   const size_t R = b->n_rows;
   CHK(ensure(m, m->st_xe, R * XE * sizeof(float)));
   HIPCHK(m, hipMemcpyAsync(m->st_xe.p, b->xe, R * XE * sizeof(float), hipMemcpyHostToDevice, st));
@@ -394,6 +472,7 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, 
   if (use_dense_agg(d, F)) {
     AggDenseArgs q = agg_dense_args(d, r, N, F);
     q.src = src; q.src_stride = src_stride; q.add = add; q.add_stride = add_stride; q.mask = mask; q.out = out;
+    q.err = flag_dev_of(m);
     if (m) {
       q.adj = (unsigned*)m->adj_mask.p;                 // built by run_forward for this batch
     } else {                                            // handle-less entry point: build into a scratch buffer
@@ -422,6 +501,7 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, 
   a.lpr_shift = sh;
   a.mask_words = (d.max_nodes + 31) / 32;
   a.transpose = transpose;
+  a.err = flag_dev_of(m);
   const int nworkers = 256 >> sh;
   const size_t per_graph = (size_t)d.max_nodes * F * 4 + (size_t)(d.max_nodes + 1) * 4 + (size_t)d.max_edges * 4 +
                            (transpose ? (size_t)d.max_nodes * a.mask_words * 4 : 0);
@@ -935,20 +1015,103 @@ LossJob loss_job(const v2x_model* m, const DevBatch& d, int n_global) {
   return LossJob{m->N, d.B, 1, inv, srow_stride(m)};                // per-node weights: slot-major
 }
 
+// ------------------------------------------------------------------------------------ fused graph layers
+// (kernels_fused.hpp) fixed-size graphs of <= 32 nodes, narrow features, no neighbour-init input, tile fits the LDS
+int fused_rowf(int F) { return 4 * ((F / 16) | 1); }
+size_t fused_lds(const v2x_model* m, const DevBatch& d, bool bwd) {
+  const size_t rows = (size_t)FZ_TG * m->N;
+  size_t b = 4 * rows * fused_rowf(m->F) * 4 + (rows + 1) * 4 + (size_t)FZ_TG * d.max_edges;
+  if (bwd) b += rows * 4;
+  return (b + 15) / 16 * 16;
+}
+bool fused_path(const v2x_model* m, const DevBatch& d) {
+  if (!m->pk_fwd || m->cfg.variable_graphs || d.goff || d.nbr || m->F > 64 || m->N > 32 || m->L > FZ_MAXL) return false;
+  if (d.max_nodes != m->N) return false;
+  return fused_lds(m, d, true) <= 160 * 1024;
+}
+
+int launch_pack(v2x_model* m, hipStream_t st) {
+  PackArgs p;
+  memset(&p, 0, sizeof(p));
+  p.params = m->params; p.pk_fwd = m->pk_fwd; p.pk_bwd = m->pk_bwd; p.S = m->S;
+  for (int s = 0; s <= m->L; ++s) { p.layer_off[s] = m->gnn[s].off; p.slot_stride[s] = m->gnn[s].slot_stride; p.pad[s] = m->gnn[s].pad; }
+  const dim3 grid(4, m->S, m->L + 1);
+  switch (m->F) {
+    case 16: { auto k = k_pack_weights<16>; LAUNCH(m, "k_pack_weights", k, grid, 0, st, p); break; }
+    case 32: { auto k = k_pack_weights<32>; LAUNCH(m, "k_pack_weights", k, grid, 0, st, p); break; }
+    case 64: { auto k = k_pack_weights<64>; LAUNCH(m, "k_pack_weights", k, grid, 0, st, p); break; }
+    default: FAIL(m, V2X_EINVAL, "pack: unsupported feat_dim %d", m->F);
+  }
+  return V2X_OK;
+}
+
+#define LAUNCH_T(m, kname, kern, grid, threads, lds, stream, args)                        \
+  do {                                                                                  \
+    ProfRec _r;                                                                         \
+    const bool _p = (m) && (m)->prof && !(m)->capturing;                                \
+    if (_p) {                                                                           \
+      _r.id = prof_id(m, kname);                                                          \
+      hipEventCreate(&_r.ev0); hipEventCreate(&_r.ev1);                                     \
+      hipEventRecord(_r.ev0, stream);                                                     \
+    }                                                                                   \
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, args);                   \
+    if (_p) { hipEventRecord(_r.ev1, stream); (m)->prof_recs.push_back(_r); }             \
+    hipError_t _e = hipGetLastError();                                                  \
+    if (_e != hipSuccess) FAIL(m, V2X_EHIP, "launch %s failed: %s", kname, hipGetErrorString(_e)); \
+  } while (0)
+
+int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
+  CHK(launch_pack(m, st));          // the parameters may have changed since the last call (Adam, set/copy_weights)
+  FusedFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xe = d.xe; a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_fwd;
+  for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.a[s] = m->a[s]; }
+  a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.err = m->flag_dev;
+  const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
+  const size_t lds = fused_lds(m, d, false);
+  switch (m->F) {
+    case 16: { auto k = k_gnn_fwd_fused<16>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
+    case 32: { auto k = k_gnn_fwd_fused<32>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
+    case 64: { auto k = k_gnn_fwd_fused<64>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
+  }
+  return V2X_OK;
+}
+
+int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
+  FusedBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_bwd; a.gha = m->gha;
+  for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.dpre[s] = m->dpre[s]; }
+  a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.err = m->flag_dev;
+  const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
+  const size_t lds = fused_lds(m, d, true);
+  switch (m->F) {
+    case 16: { auto k = k_gnn_bwd_fused<16>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
+    case 32: { auto k = k_gnn_bwd_fused<32>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
+    case 64: { auto k = k_gnn_bwd_fused<64>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
+  }
+  return V2X_OK;
+}
+
 // ------------------------------------------------------------------------------------ passes
 int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool with_mlp = true) {
   const int F = m->F, L = m->L;
   const IdxMap x = idx_map(m, d, r);
-  if (use_dense_agg(d, F)) {
-    AggDenseArgs q = agg_dense_args(d, r, m->N, F);
-    q.adj = (unsigned*)m->adj_mask.p;
-    CHK(build_adj_masks(m, st, q));
-  }
-  CHK(launch_node_fwd(m, st, 0, x, d.xe, nullptr, d.nbr, m->h[0]));
-  CHK(launch_agg(m, st, d, r, m->N, F, m->h[0], F, nullptr, 0, nullptr, m->a[0], 0));
-  for (int s = 1; s <= L; ++s) {
-    CHK(launch_node_fwd(m, st, s, x, d.xe, m->h[s - 1], m->a[s - 1], m->h[s]));
-    CHK(launch_agg(m, st, d, r, m->N, F, m->h[s], F, nullptr, 0, nullptr, m->a[s], 0));
+  if (fused_path(m, d) && r.g0 == 0 && r.ng == d.B) {
+    CHK(launch_fused_fwd(m, st, d));       // embed + L stages + L+1 aggregations: one launch
+  } else {
+    if (use_dense_agg(d, F)) {
+      AggDenseArgs q = agg_dense_args(d, r, m->N, F);
+      q.adj = (unsigned*)m->adj_mask.p;
+      q.err = m->flag_dev;
+      CHK(build_adj_masks(m, st, q));
+    }
+    CHK(launch_node_fwd(m, st, 0, x, d.xe, nullptr, d.nbr, m->h[0]));
+    CHK(launch_agg(m, st, d, r, m->N, F, m->h[0], F, nullptr, 0, nullptr, m->a[0], 0));
+    for (int s = 1; s <= L; ++s) {
+      CHK(launch_node_fwd(m, st, s, x, d.xe, m->h[s - 1], m->a[s - 1], m->h[s]));
+      CHK(launch_agg(m, st, d, r, m->N, F, m->h[s], F, nullptr, 0, nullptr, m->a[s], 0));
+    }
   }
   if (!with_mlp) return V2X_OK;          // training: the MLP runs fused with its backward (k_mlp_train)
   MlpArgs a;
@@ -992,13 +1155,18 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   // (overlaps the remaining agg/dgrad chain) instead of one fused launch after the chain
   static const bool per_stage = env_int("V2X_WG_PER_STAGE", 0) != 0;
   const bool split = two && per_stage && !is_wide(m);
-  for (int s = L; s >= 1; --s) {
-    // dpre_s = (dh_direct + Agg^T(dagg)) * relu'(h_s)
-    CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, s < L ? m->h[s] : nullptr, m->dpre[s], 1));
-    if (split) { CHK(fork()); CHK(wgrad_gnn(m, sw, s, x, d.xe, m->h[s - 1], m->a[s - 1], m->dpre[s])); }
-    CHK(launch_dgrad(m, st, s, x, m->dpre[s], m->gha));
+  const bool fused = fused_path(m, d) && r.g0 == 0 && r.ng == d.B && !split;
+  if (fused) {
+    CHK(launch_fused_bwd(m, st, d));       // L+1 transposed aggregations + L data gradients: one launch
+  } else {
+    for (int s = L; s >= 1; --s) {
+      // dpre_s = (dh_direct + Agg^T(dagg)) * relu'(h_s)
+      CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, s < L ? m->h[s] : nullptr, m->dpre[s], 1));
+      if (split) { CHK(fork()); CHK(wgrad_gnn(m, sw, s, x, d.xe, m->h[s - 1], m->a[s - 1], m->dpre[s])); }
+      CHK(launch_dgrad(m, st, s, x, m->dpre[s], m->gha));
+    }
+    CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, m->h[0], m->dpre[0], 1));
   }
-  CHK(launch_agg(m, st, d, r, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, m->h[0], m->dpre[0], 1));
   if (split) { CHK(fork()); CHK(wgrad_gnn(m, sw, 0, x, d.xe, nullptr, d.nbr, m->dpre[0])); }
   else if (merged) CHK(wgrad_all(m, st, x, d));             // every layer, one launch
   else CHK(wgrad_gnn_all(m, st, x, d));                     // all L+1 GNN stages, one launch
@@ -1040,6 +1208,7 @@ int emit_loss(v2x_model* m, float* loss_out, int loss_on_device, hipStream_t st)
   } else {
     HIPCHK(m, hipMemcpyAsync(loss_out, m->loss_dev, n * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(m, hipStreamSynchronize(st));
+    CHK(check_flag(m));
   }
   return V2X_OK;
 }
@@ -1172,8 +1341,21 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
       dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1) || dev_alloc(m, &m->zero_buf, 1024) ||
       dev_alloc(m, &m->loss_part, 128))
     return fail("allocation");
+  // V2X_FUSED=0 (read when the model is created) keeps the layer-by-layer kernels: A/B measurements and the test that
+  // the two paths agree bitwise
+  if (env_int("V2X_FUSED", 1) != 0 && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
+    const int FB = m->F / 16, KB = 2 * FB + 1;
+    const size_t fwd0 = (size_t)FB * 256 + m->F, fwd = (size_t)KB * FB * 256 + m->F, bwd = (size_t)FB * 2 * FB * 256;
+    if (dev_alloc(m, &m->pk_fwd, (size_t)m->S * fwd0 + (size_t)m->L * m->S * fwd) || dev_alloc(m, &m->pk_bwd, (size_t)m->L * m->S * bwd))
+      return fail("allocation");
+  }
   if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->loss_part, 0, 512) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
+  {
+    FlagWord f;
+    if (alloc_flag(&f) != V2X_OK) return fail("pinned flag word");
+    m->flag_host = f.host; m->flag_dev = f.dev;
+  }
   if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return fail("side stream");
   m->ev.resize(2 * m->L + 6);
   for (auto& e : m->ev)
@@ -1189,7 +1371,7 @@ void v2x_destroy(v2x_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second.exec);
   for (auto& r : m->prof_recs) { hipEventDestroy(r.ev0); hipEventDestroy(r.ev1); }
   float* ptrs[] = {m->params, m->grads, m->mom, m->vel, m->z1, m->z2, m->z3, m->q, m->dq, m->dz1, m->dz2, m->dz3,
-                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part};
+                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part, m->pk_fwd, m->pk_bwd};
   for (float* p : m->dpre) if (p) hipFree(p);
   for (auto& e : m->ev) if (e) hipEventDestroy(e);
   if (m->side) hipStreamDestroy(m->side);
@@ -1198,6 +1380,7 @@ void v2x_destroy(v2x_model* m) {
   for (float* p : m->a) if (p) hipFree(p);
   DevBuf* bufs[] = {&m->st_xe, &m->st_nbr, &m->st_goff, &m->st_rp, &m->st_ci, &m->st_y, &m->st_q, &m->adj_mask};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+  if (m->flag_host) hipHostFree(m->flag_host);
   delete m;
 }
 
@@ -1264,6 +1447,7 @@ int v2x_forward(v2x_model* m, const v2x_batch* b, float* q_out, int q_on_device,
   } else {
     HIPCHK(m, hipMemcpyAsync(q_out, m->q, qb, hipMemcpyDeviceToHost, st));
     HIPCHK(m, hipStreamSynchronize(st));
+    CHK(check_flag(m));
   }
   return V2X_OK;
 }
@@ -1487,6 +1671,28 @@ int v2x_dqn_targets(const float* q, const float* q_next, const int32_t* action, 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) FAIL(nullm, V2X_EHIP, "dqn_targets launch failed: %s", hipGetErrorString(e));
   return V2X_OK;
+}
+
+// ---------------------------------------------------------------------------- contract checks
+int v2x_validate_batch(v2x_model* m, const v2x_batch* b, int32_t n_nodes, void* stream) {
+  if (!b || b->n_graphs <= 0 || b->n_rows <= 0 || !b->row_ptr || (b->n_edges > 0 && !b->col_idx) || b->max_nodes <= 0 ||
+      b->max_edges < 0)
+    FAIL(m, V2X_EINVAL, "validate_batch: null pointer or non-positive size");
+  if (m) n_nodes = m->N;
+  if (!b->graph_off && (n_nodes <= 0 || (int64_t)b->n_graphs * n_nodes != b->n_rows))
+    FAIL(m, V2X_EINVAL, "validate_batch: n_rows (%d) != n_graphs*n_nodes (%d*%d)", b->n_rows, b->n_graphs, n_nodes);
+  if (!b->on_device) return validate_host_batch(m, b, n_nodes);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_validate_batch, dim3(std::min(b->n_graphs, 4096)), dim3(256), 0, st, b->graph_off, b->row_ptr, b->col_idx,
+                     b->n_graphs, b->n_rows, b->n_edges, n_nodes, b->max_nodes, b->max_edges, flag_dev_of(m));
+  HIPCHK(m, hipGetLastError());
+  HIPCHK(m, hipStreamSynchronize(st));
+  return check_flag(m);
+}
+
+int v2x_check_errors(v2x_model* m, void* stream) {
+  HIPCHK(m, hipStreamSynchronize((hipStream_t)stream));
+  return check_flag(m);
 }
 
 // ---------------------------------------------------------------------------- measurement

@@ -28,12 +28,12 @@ class DataParallelTrainer(object):
         self.force = force          # run the collective even with one rank (exercises the RCCL path)
 
     def shard(self, batch, y):
-        """Contiguous shard of whole graphs for this rank.  y is [R, C] for the full batch."""
+        """Contiguous shard of whole graphs for this rank (variable-size batches: balanced by edges + nodes,
+        PackedBatch.shard_bounds).  y is [R, C] for the full batch."""
         if self.world == 1:
             return batch, y
-        sh = batch.shard(self.rank, self.world)
-        rows = batch.n_rows // self.world
-        return sh, y[self.rank * rows:(self.rank + 1) * rows]
+        sh, (r0, r1) = batch.shard(self.rank, self.world, with_rows=True)
+        return sh, y[r0:r1]
 
     def train_step(self, local_batch, local_y, n_graphs_global, want_loss=True):
         """forward+backward on the local shard, all-reduce the gradient, Adam on every rank."""

@@ -217,6 +217,18 @@ class GnnEngine(object):
                                            None if loss is None else loss.data_ptr(), 1, self._stream()))
         return loss
 
+    def validate(self, batch):
+        """Check a batch against the layout contract of include/v2xgnn.h (sizes vs max_nodes / max_edges, sources
+        inside their graph and strictly ascending); raises ValueError.  Host batches are checked on every call
+        anyway; device batches only here."""
+        s = _batch_struct(batch)
+        self._check(self._lib.v2x_validate_batch(self._h, C.byref(s), self.spec.n_nodes, self._stream()))
+
+    def check_errors(self):
+        """Synchronise and raise if a kernel met a graph larger than the LDS tile the batch's max_nodes / max_edges
+        promised (its outputs are then invalid)."""
+        self._check(self._lib.v2x_check_errors(self._h, self._stream()))
+
     def apply_gradients(self):
         self._check(self._lib.v2x_apply_gradients(self._h, self._stream()))
 

@@ -66,7 +66,7 @@ def kron_to_adj(A, F, validate=True):
 class PackedBatch(object):
     """Compact batch: xe[R,16] f32, optional nbr[R,F] f32, CSR, sizes.  Arrays are numpy (host)."""
 
-    def __init__(self, n_graphs, n_nodes, xe, row_ptr, col_idx, max_edges, nbr=None, graph_off=None,
+    def __init__(self, n_graphs, n_nodes, xe, row_ptr, col_idx, max_edges=None, nbr=None, graph_off=None,
                  max_nodes=None):
         self.n_graphs = int(n_graphs)
         self.n_nodes = int(n_nodes)
@@ -75,14 +75,57 @@ class PackedBatch(object):
         self.col_idx = np.ascontiguousarray(col_idx, np.int32)
         self.nbr = None if nbr is None else np.ascontiguousarray(nbr, np.float32)
         self.graph_off = None if graph_off is None else np.ascontiguousarray(graph_off, np.int32)
-        self.max_edges = int(max_edges)
-        self.max_nodes = int(max_nodes if max_nodes is not None else n_nodes)
         self.n_rows = self.xe.shape[0]
         self.n_edges = int(self.row_ptr[-1])
         if self.row_ptr.shape[0] != self.n_rows + 1:
             raise ValueError("row_ptr must have n_rows+1 entries")
         if self.col_idx.shape[0] != self.n_edges:
             raise ValueError("col_idx length %d != row_ptr[-1] %d" % (self.col_idx.shape[0], self.n_edges))
+        # The kernels size their LDS tiles from max_nodes / max_edges: both are derived from the batch itself, and
+        # a caller-supplied value may only be LARGER (an understated value would overrun the tile).
+        bounds = self.graph_bounds()
+        if bounds[0] != 0 or bounds[-1] != self.n_rows or np.any(np.diff(bounds) <= 0):
+            raise ValueError("graph_off must start at 0, end at n_rows and be strictly increasing")
+        real_nodes = int(np.diff(bounds).max())
+        real_edges = int(np.diff(self.row_ptr[bounds]).max())
+        if max_nodes is not None and int(max_nodes) < real_nodes:
+            raise ValueError("max_nodes %d is smaller than the largest graph (%d nodes)" % (max_nodes, real_nodes))
+        if max_edges is not None and int(max_edges) < real_edges:
+            raise ValueError("max_edges %d is smaller than the largest graph's edge count %d" % (max_edges, real_edges))
+        self.max_nodes = int(max_nodes) if max_nodes is not None else real_nodes
+        self.max_edges = int(max_edges) if max_edges is not None else real_edges
+
+    def graph_bounds(self):
+        """First node row of every graph, plus n_rows: [B+1] int64."""
+        if self.graph_off is not None:
+            if self.graph_off.shape[0] != self.n_graphs + 1:
+                raise ValueError("graph_off must have n_graphs+1 entries")
+            return self.graph_off.astype(np.int64)
+        if self.n_rows != self.n_graphs * self.n_nodes:
+            raise ValueError("n_rows (%d) != n_graphs*n_nodes (%d*%d)" % (self.n_rows, self.n_graphs, self.n_nodes))
+        return np.arange(self.n_graphs + 1, dtype=np.int64) * self.n_nodes
+
+    def validate(self):
+        """Full check of the CSR contract (include/v2xgnn.h): row_ptr monotone, sources inside their graph and
+        strictly ascending within a row (=> no duplicate edges).  O(E) numpy; from_dense output satisfies it by
+        construction."""
+        rp = self.row_ptr.astype(np.int64)
+        if rp[0] != 0 or np.any(np.diff(rp) < 0):
+            raise ValueError("row_ptr must start at 0 and be non-decreasing")
+        if self.n_edges == 0:
+            return self
+        bounds = self.graph_bounds()
+        n_of_row = np.repeat(np.diff(bounds), np.diff(bounds))
+        deg = np.diff(rp)
+        n_of_edge = np.repeat(n_of_row, deg)
+        col = self.col_idx.astype(np.int64)
+        if np.any(col < 0) or np.any(col >= n_of_edge):
+            raise ValueError("col_idx holds a source id outside its graph")
+        first = np.zeros(self.n_edges, bool)
+        first[rp[:-1][deg > 0]] = True
+        if np.any((np.diff(col) <= 0) & ~first[1:]):
+            raise ValueError("sources of a row must be strictly ascending (duplicate edges are not allowed)")
+        return self
 
     @classmethod
     def from_dense(cls, x, e, adj, nbr=None):
@@ -94,20 +137,50 @@ class PackedBatch(object):
         nb = None if nbr is None else np.asarray(nbr).reshape(B * N, -1)
         return cls(B, N, xe, row_ptr, col_idx, max_edges, nbr=nb)
 
-    def shard(self, rank, world):
-        """Contiguous shard of whole graphs for data parallelism (fixed-size graphs)."""
-        if self.graph_off is not None:
-            raise NotImplementedError("sharding of variable-size batches")
-        if self.n_graphs % world:
-            raise ValueError("batch %d not divisible by world size %d" % (self.n_graphs, world))
-        b = self.n_graphs // world
-        g0, g1 = rank * b, (rank + 1) * b
-        r0, r1 = g0 * self.n_nodes, g1 * self.n_nodes
+    def shard_bounds(self, world, balance="edges"):
+        """Graph-index boundaries [world+1] of `world` contiguous shards of WHOLE graphs (AggLayer only contracts inside
+        a sample, BS_brain.py:73).  Fixed-size graphs: equal counts.  Variable-size graphs: balanced
+        by the cumulative per-graph cost -- "edges" (gather work + node rows; default), "nodes" or "count" -- with at
+        least one graph per shard."""
+        B = self.n_graphs
+        if world < 1 or world > B:
+            raise ValueError("cannot cut %d graphs into %d shards" % (B, world))
+        if self.graph_off is None or balance == "count":
+            if self.graph_off is None and B % world:
+                raise ValueError("batch %d not divisible by world size %d" % (B, world))
+            return (np.arange(world + 1, dtype=np.int64) * B) // world
+        bounds = self.graph_bounds()
+        nodes = np.diff(bounds)
+        cost = nodes.astype(np.float64)
+        if balance == "edges":
+            cost = cost + np.diff(self.row_ptr[bounds].astype(np.int64))
+        elif balance != "nodes":
+            raise ValueError("balance must be 'edges', 'nodes' or 'count'")
+        cum = np.concatenate([[0.0], np.cumsum(cost)])
+        targets = cum[-1] * np.arange(1, world) / world
+        hi = np.clip(np.searchsorted(cum, targets, side="left"), 1, B)          # cum[hi] >= target
+        cuts = np.where(targets - cum[hi - 1] < cum[hi] - targets, hi - 1, hi)  # the nearer graph boundary
+        out = np.concatenate([[0], cuts, [B]]).astype(np.int64)
+        for k in range(1, world):
+            out[k] = min(max(out[k], out[k - 1] + 1), B - (world - k))
+        return out
+
+    def slice_graphs(self, g0, g1):
+        """Sub-batch of the whole graphs [g0, g1) and the range of node rows it covers."""
+        bounds = self.graph_bounds()
+        r0, r1 = int(bounds[g0]), int(bounds[g1])
         e0, e1 = int(self.row_ptr[r0]), int(self.row_ptr[r1])
-        deg_g = np.add.reduceat(np.diff(self.row_ptr[r0:r1 + 1]), np.arange(0, r1 - r0, self.n_nodes))
-        return PackedBatch(b, self.n_nodes, self.xe[r0:r1], self.row_ptr[r0:r1 + 1] - e0,
-                           self.col_idx[e0:e1], int(deg_g.max()),
-                           nbr=None if self.nbr is None else self.nbr[r0:r1])
+        goff = None if self.graph_off is None else (self.graph_off[g0:g1 + 1] - r0).astype(np.int32)
+        sub = PackedBatch(g1 - g0, self.n_nodes, self.xe[r0:r1], self.row_ptr[r0:r1 + 1] - e0, self.col_idx[e0:e1],
+                          nbr=None if self.nbr is None else self.nbr[r0:r1], graph_off=goff)
+        return sub, (r0, r1)
+
+    def shard(self, rank, world, balance="edges", with_rows=False):
+        """Contiguous shard `rank` of `world` for data parallelism (see shard_bounds).  with_rows: also return the
+        (first, last+1) node rows of the shard, for slicing the targets."""
+        b = self.shard_bounds(world, balance)
+        sub, rows = self.slice_graphs(int(b[rank]), int(b[rank + 1]))
+        return (sub, rows) if with_rows else sub
 
 
 def feed_to_arrays(spec: GnnSpec, feed, validate_adjacency=True):

@@ -1,8 +1,9 @@
 """DQN agent glue around the Q-network: the counterpart of the reference `Memory` (BS_brain.py:245-270) and
 `Agent` (BS_brain.py:280-910) for any number of V2V links (the reference hard-codes D1..D4), SURVEY.md 8f-1.
 
-Same method names, argument meaning, return values and numpy-RNG consumption as the reference, so a seeded run
-with the same brain reproduces the reference's replay memory and the exact x / y payload it hands to `fit`
+Same method names, argument meaning, return values and numpy-RNG consumption as the reference (including the
+np.random.shuffle draw Keras' Model.fit makes per call, which the compact and device-resident paths reproduce), so a
+seeded run with the same brain reproduces the reference's replay memory and the exact x / y payload it hands to `fit`
 (pinned by tests/golden/golden_agent_n4.npz, captured from the reference agent on the real simulator).  What is
 different: no per-sample Python loops (state packing, batch assembly and target construction are vectorised), and
 when the brain exposes the compact entry points (`predict_arrays` / `fit_arrays`, v2xgnn.GnnQModel) the dense
@@ -229,7 +230,10 @@ class Agent(object):
         states_ = s_[:, :n * d].reshape(B, n, d)
         p = self._predict(states, adj)                                                    # online   [N, B, C]
         p_ = self._predict(states_, adj, target=True)                                     # target   (adjacency reused, :583)
-        target = r[None, :] + self.gamma * np.max(p_, axis=2)                             # [N, B]
+        # r + GAMMA * max(p_) scalar by scalar (BS_brain.py:690): under the reference's numpy-1.x stack python-float x
+        # np.float32 is a float64 product, rounded to float32 once when stored into p -- evaluated in float64 here and in
+        # k_dqn_targets alike (numpy >= 2 / NEP 50 would round the product to float32 first: <= 1 ulp apart)
+        target = r[None, :] + self.gamma * np.max(p_, axis=2).astype(np.float64)          # [N, B]
         np.put_along_axis(p, np.transpose(a)[:, :, None], target[:, :, None].astype(p.dtype), axis=2)
         y = p.astype(np.float64)
         if self._compact():
@@ -250,6 +254,7 @@ class Agent(object):
         n, B = self.num_D2D, self.batch_size
         model, target = self.brain.model, self.brain.target_model
         idx = self.memory.sample_indices(B)
+        model.consume_fit_shuffle(B)           # Model.fit's np.random.shuffle draw: same RNG stream as fit()
         trainer = model.trainer
         if trainer is not None and trainer.world > 1:
             if B % trainer.world:

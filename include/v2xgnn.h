@@ -73,7 +73,8 @@ typedef struct v2x_model v2x_model;
 typedef struct v2x_config {
   int32_t n_nodes;        /* N: nodes per graph (num_D2D, BS_brain.py:95); >=1             */
   int32_t n_channels;     /* C: num_CH (:97); this build supports C == 4                     */
-  int32_t feat_dim;       /* F: num_Feedback (:98); 16, 32 or 64 in this build               */
+  int32_t feat_dim;       /* F: num_Feedback (:98); 16, 32, 64 (register-chained path), 128 or
+                             256 (LDS-tiled wide path) in this build                         */
   int32_t n_mp_layers;    /* L: message-passing stages after the embed (reference: 2)        */
   int32_t share_weights;  /* 0 = one weight set per node slot (reference), 1 = shared        */
   int32_t variable_graphs;/* 1 = graphs of different sizes (needs share_weights)             */
@@ -167,8 +168,8 @@ int  v2x_adam_step(float* param, const float* grad, float* mom, float* vel, int6
 int  v2x_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_idx, int64_t row_bytes,
                      void* stream);
 /* y = q (online net on s), except y[b][k][action[b][k]] = reward[b] + gamma * max_c q_next[b][k][c]
- * (q_next: target net on s'); evaluated like the reference's numpy expression (fp32 product, double
- * sum, rounded to fp32 when fed).  q, q_next, y: [n_graphs*n_nodes][n_channels]; action: [n_graphs][n_nodes];
+ * (q_next: target net on s'); evaluated like the reference's numpy-1.x scalar expression (float64
+ * product and sum, rounded to fp32 once).  q, q_next, y: [n_graphs*n_nodes][n_channels]; action: [n_graphs][n_nodes];
  * reward: [n_graphs] double.                                                                    */
 int  v2x_dqn_targets(const float* q, const float* q_next, const int32_t* action, const double* reward,
                      double gamma, int32_t n_graphs, int32_t n_nodes, int32_t n_channels, float* y_out,
@@ -182,6 +183,16 @@ int  v2x_dqn_targets(const float* q, const float* q_next, const int32_t* action,
 int  v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, const v2x_batch* s_next,
                   const int32_t* action, const double* reward, double gamma, int32_t n_graphs_global,
                   float* y_out, float* loss_out, int loss_on_device, void* stream);
+
+/* ---- contract checks -------------------------------------------------------------------
+ * The kernels size their LDS tiles from max_nodes / max_edges and rely on the CSR contract above (sources inside
+ * their graph, strictly ascending => no duplicates).  HOST batches are checked on every call before anything is copied
+ * (V2X_EINVAL).  DEVICE batches are the caller's responsibility: v2x_validate_batch checks one (synchronises `stream`;
+ * `m` may be NULL, then n_nodes is used for fixed-size graphs).  Independently, a workgroup that finds a graph larger than
+ * its LDS tile stages nothing and raises a flag; the flag is reported (V2X_EINVAL, results invalid) by the next call
+ * that synchronises with the host (host-side q / loss outputs) or by v2x_check_errors.                              */
+int  v2x_validate_batch(v2x_model* m, const v2x_batch* b, int32_t n_nodes, void* stream);
+int  v2x_check_errors(v2x_model* m, void* stream);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* When enabled, every kernel launch of this model is bracketed by HIP events on its stream

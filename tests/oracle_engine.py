@@ -31,7 +31,9 @@ class OracleEngine(object):
 
     # ---- compute
     def _inputs(self, batch):
-        graph = ((np.arange(batch.n_graphs + 1) * batch.n_nodes).astype(np.int32), batch.row_ptr, batch.col_idx)
+        goff = batch.graph_off if getattr(batch, "graph_off", None) is not None else \
+            (np.arange(batch.n_graphs + 1) * batch.n_nodes).astype(np.int32)
+        graph = (goff, batch.row_ptr, batch.col_idx)
         M = oc.csr_to_matrix(*graph, dtype=self.dtype)
         return batch.xe[:, :9].astype(self.dtype), batch.xe[:, 9:13].astype(self.dtype), M
 

@@ -1,0 +1,151 @@
+"""GPU: the graph-major fused graph-layer kernels (csrc/kernels_fused.hpp) against the layer-by-layer kernels
+(V2X_FUSED=0) and the oracle; the LDS tile guards and the batch contract checks."""
+import os
+
+import numpy as np
+import pytest
+
+import v2xgnn
+from v2xgnn import GnnSpec, PackedBatch, GnnEngine
+from util import ospec, random_inputs, f32_params, assert_fwd_close, assert_grad_close, assert_close
+from oracle import compact as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(spec, weights, fused, **kw):
+    old = os.environ.get("V2X_FUSED")
+    os.environ["V2X_FUSED"] = "1" if fused else "0"          # read by v2x_create
+    try:
+        eng = GnnEngine(spec, **kw)
+    finally:
+        if old is None:
+            del os.environ["V2X_FUSED"]
+        else:
+            os.environ["V2X_FUSED"] = old
+    eng.set_weights(weights)
+    return eng
+
+
+CASES = [  # N, F, L, B, share, reference topology
+    (4, 16, 2, 64, False, True),
+    (4, 16, 2, 7, False, True),          # one partial 16-graph tile
+    (20, 64, 2, 33, False, True),        # two full tiles + one graph
+    (20, 64, 2, 16, True, True),
+    (6, 32, 3, 50, False, False),        # random topologies: ragged in-degrees, some nodes without in-edges
+    (28, 64, 1, 20, False, True),        # largest tile that fits the LDS at F = 64
+    (5, 64, 2, 1, False, True),          # batch 1 (the rollout predict)
+]
+
+
+@pytest.mark.parametrize("N,F,L,B,share,ref_topo", CASES)
+def test_fused_equals_layerwise_bitwise_and_oracle(N, F, L, B, share, ref_topo):
+    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=share)
+    rng = np.random.default_rng(100 + N + F + B)
+    P = f32_params(spec, rng)
+    weights = oc.params_to_list(P)
+    x, e, adj = random_inputs(rng, B, N, ref_topology=ref_topo, density=0.4)
+    y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+    pb = PackedBatch.from_dense(x, e, adj)
+    fused, plain = _engine(spec, weights, True), _engine(spec, weights, False)
+    qf, qp = fused.forward(pb), plain.forward(pb)
+    assert np.array_equal(qf, qp), "fused forward differs from the layer-by-layer kernels"
+    lf, lp = fused.forward_backward(pb, y), plain.forward_backward(pb, y)
+    gf, gp = fused.get_grad_flat(), plain.get_grad_flat()
+    assert np.array_equal(lf, lp)
+    assert np.array_equal(gf, gp), "fused gradient differs: max %g" % np.abs(gf - gp).max()
+    # and the oracle (float64 restatement of BS_brain.py:17-216); backward for the SAME q the kernels differentiate
+    os_ = ospec(spec)
+    M = oc.csr_to_matrix((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx, np.float64)
+    q_ref, cache = oc.forward(os_, P, x.reshape(B * N, -1).astype(np.float64), e.reshape(B * N, -1).astype(np.float64), M)
+    assert_fwd_close(qf, q_ref, "fused forward vs oracle")
+    loss_ref, dq = oc.huber_loss_and_grad(os_, qf.astype(np.float64), y.astype(np.float64))
+    g_ref = oc.backward(os_, P, cache, dq)
+    assert_close(lf, loss_ref, 2e-4, 1e-6, "loss")
+    for i, (a_, b_) in enumerate(zip(v2xgnn.flat_to_keras_list(spec, gf), oc.params_to_list(g_ref))):
+        assert_grad_close(a_, b_, "fused gradient array %d vs oracle" % i)
+    # three optimizer steps stay together
+    for _ in range(3):
+        fused.train_step(pb, y)
+        plain.train_step(pb, y)
+    assert np.array_equal(fused.get_flat(), plain.get_flat())
+    fused.close()
+    plain.close()
+
+
+def test_fused_hipgraph_replay_is_bitwise_eager():
+    import torch
+    N, F, B = 20, 64, 48
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(7)
+    weights = oc.params_to_list(f32_params(spec, rng))
+    x, e, adj = random_inputs(rng, B, N)
+    y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+    pb = PackedBatch.from_dense(x, e, adj)
+    eager = _engine(spec, weights, True)
+    graph = _engine(spec, weights, True, use_graph=True)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        db = graph.to_device(pb)
+        yd = torch.from_numpy(y).cuda()
+        for _ in range(4):
+            graph.train_step(db, yd)
+        torch.cuda.synchronize()
+    for _ in range(4):
+        eager.train_step(pb, y)
+    assert np.array_equal(eager.get_flat(), graph.get_flat())
+
+
+def test_understated_max_edges_is_reported_not_corrupting():
+    """A device batch whose max_edges understates the real edge count must not overrun the LDS tile: the kernels skip
+    the tile and the next synchronising call reports V2X_EINVAL."""
+    import torch
+    for fused in (True, False):
+        N, F, B = 20, 64, 32
+        spec = GnnSpec(n_nodes=N, feat_dim=F)
+        rng = np.random.default_rng(11)
+        eng = _engine(spec, oc.params_to_list(f32_params(spec, rng)), fused)
+        x, e, adj = random_inputs(rng, B, N)
+        pb = PackedBatch.from_dense(x, e, adj)
+        db = eng.to_device(pb)
+        db.max_edges = pb.max_edges // 2
+        eng.forward(db)
+        with pytest.raises(ValueError, match="max_nodes / max_edges"):
+            eng.check_errors()
+        eng.check_errors()                       # flag was cleared
+        with pytest.raises(ValueError, match="max_edges"):
+            eng.validate(db)
+        eng.close()
+
+
+def test_host_batches_are_validated_before_any_copy():
+    N, F, B = 6, 16, 9
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(12)
+    eng = _engine(spec, oc.params_to_list(f32_params(spec, rng)), True)
+    x, e, adj = random_inputs(rng, B, N)
+    good = PackedBatch.from_dense(x, e, adj)
+    eng.forward(good)
+
+    def broken(**kw):
+        pb = PackedBatch.from_dense(x, e, adj)
+        for k, v in kw.items():
+            setattr(pb, k, v)
+        return pb
+    with pytest.raises(ValueError, match="max_edges"):
+        eng.forward(broken(max_edges=good.max_edges - 1))
+    col = good.col_idx.copy()
+    col[1] = col[0]                               # duplicate edge
+    with pytest.raises(ValueError, match="ascending"):
+        eng.forward(broken(col_idx=col))
+    col = good.col_idx.copy()
+    col[0] = N                                    # source outside the graph
+    with pytest.raises(ValueError, match="outside"):
+        eng.forward(broken(col_idx=col))
+    # the device-side checker agrees
+    db = eng.to_device(good)
+    eng.validate(db)
+    import torch
+    db.col_idx = torch.from_numpy(col).cuda()
+    with pytest.raises(ValueError, match="source id"):
+        eng.validate(db)
+    eng.close()

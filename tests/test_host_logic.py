@@ -256,3 +256,48 @@ def test_fit_minibatches_epochs_and_shuffle():
             assert np.isclose(hist.history['loss'][ep], np.sum(want[ep]), rtol=1e-6)
         for a, b in zip(model.get_weights(), ref.get_weights()):
             assert np.allclose(a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_ragged_shards_are_whole_graphs_balanced_by_cost():
+    """PackedBatch.shard on variable-size batches: contiguous, disjoint, complete, every shard a valid
+    batch of its own, cost (edges + nodes) within one largest graph of the ideal share."""
+    import bench
+    rng = np.random.default_rng(5)
+    sizes, offs, row_ptr, col_idx, x, e, y = bench.synth_ragged(rng, 257, 8, 128)
+    pb = PackedBatch(len(sizes), 0, v2xgnn.pack_xe(x, e), row_ptr, col_idx, graph_off=offs).validate()
+    assert pb.max_nodes == sizes.max() and pb.max_edges == (sizes * (sizes - 2)).max()
+    cost = sizes + sizes * (sizes - 2)
+    for world in (2, 3, 8):
+        b = pb.shard_bounds(world)
+        assert b[0] == 0 and b[-1] == pb.n_graphs and np.all(np.diff(b) >= 1)
+        shards = [pb.shard(r, world, with_rows=True) for r in range(world)]
+        assert sum(s.n_graphs for s, _ in shards) == pb.n_graphs
+        assert [r for _, r in shards][0][0] == 0 and all(shards[i][1][1] == shards[i + 1][1][0] for i in range(world - 1))
+        for r, (s, (r0, r1)) in enumerate(shards):
+            s.validate()
+            assert np.array_equal(s.xe, pb.xe[r0:r1]) and s.graph_off[0] == 0 and s.graph_off[-1] == r1 - r0
+            share = cost[b[r]:b[r + 1]].sum()
+            assert abs(share - cost.sum() / world) <= cost.max(), (world, r)
+    # equal-count sharding is what the bench used to do: visibly worse balance on the same batch
+    by_count = pb.shard_bounds(8, balance="count")
+    worst = lambda bb: max(cost[bb[i]:bb[i + 1]].sum() for i in range(8))
+    assert worst(pb.shard_bounds(8)) <= worst(by_count)
+
+
+def test_packed_batch_rejects_understated_tile_sizes_and_broken_csr():
+    rng = np.random.default_rng(6)
+    x = rng.normal(size=(3, 5, 9)); e = rng.normal(size=(3, 5, 4))
+    adj = (rng.uniform(size=(3, 5, 5)) < 0.6).astype(float)
+    pb = PackedBatch.from_dense(x, e, adj).validate()
+    with pytest.raises(ValueError, match="max_edges"):
+        PackedBatch(3, 5, pb.xe, pb.row_ptr, pb.col_idx, max_edges=pb.max_edges - 1)
+    with pytest.raises(ValueError, match="max_nodes"):
+        PackedBatch(3, 5, pb.xe, pb.row_ptr, pb.col_idx, max_nodes=4)
+    bad = pb.col_idx.copy(); bad[0] = 5
+    with pytest.raises(ValueError, match="outside"):
+        PackedBatch(3, 5, pb.xe, pb.row_ptr, bad).validate()
+    deg = np.diff(pb.row_ptr)
+    r = int(np.argmax(deg >= 2))
+    bad = pb.col_idx.copy(); bad[pb.row_ptr[r] + 1] = bad[pb.row_ptr[r]]
+    with pytest.raises(ValueError, match="ascending"):
+        PackedBatch(3, 5, pb.xe, pb.row_ptr, bad).validate()

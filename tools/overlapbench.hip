@@ -5,7 +5,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // each wave: per iteration NL float4 loads (streaming) and NM MFMAs fed by the PREVIOUS iteration's data
-template <int NL, int NM, bool DO_LOAD, bool DO_MFMA, bool RANDOM_INIT = false>
+template <int NL, int NM, bool DO_LOAD, bool DO_MFMA, bool RANDOM_INIT = false, bool ILV = false>
 __global__ __launch_bounds__(256) void k_mix(const float4* __restrict__ in, float* __restrict__ out, size_t n4, int iters) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -21,13 +21,17 @@ __global__ __launch_bounds__(256) void k_mix(const float4* __restrict__ in, floa
 #pragma unroll
       for (int l = 0; l < NL; ++l) nxt[l] = in[(i + l * stride) & (n4 - 1)];
       i += NL * stride;
-      __builtin_amdgcn_sched_barrier(0);
+      if (!ILV) __builtin_amdgcn_sched_barrier(0);
     }
     if (DO_MFMA) {
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const float4 v = cur[m % NL];
         acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x + m, v.y, acc[m & 3], 0, 0, 0);
+      }
+      if (ILV) {      // one load per NM/NL MFMAs instead of a burst of NL loads in front of the MFMAs
+#pragma unroll
+        for (int l = 0; l < NL; ++l) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, NM / NL, 0); }
       }
       __builtin_amdgcn_sched_barrier(0);
     } else {
@@ -96,6 +100,8 @@ int main() {
       double tm = time_us([&] { hipLaunchKernelGGL((k_mix<9, 144, false, true>), dim3(wgs), dim3(256), 0, 0, (const float4*)in, out, n4, it2); });
       double tb = time_us([&] { hipLaunchKernelGGL((k_mix<9, 144, true, true>), dim3(wgs), dim3(256), 0, 0, (const float4*)in, out, n4, it2); });
       double tr = time_us([&] { hipLaunchKernelGGL((k_mix<9, 144, false, true, true>), dim3(wgs), dim3(256), 0, 0, (const float4*)in, out, n4, it2); });
+      double ti = time_us([&] { hipLaunchKernelGGL((k_mix<9, 144, true, true, false, true>), dim3(wgs), dim3(256), 0, 0, (const float4*)in, out, n4, it2); });
+      printf("   both, loads INTERLEAVED with the MFMAs (sched_group_barrier): %7.1f us\n", ti);
       printf("   mfma only, RANDOM register data: %7.1f us (%6.1f TF)\n", tr, (double)wgs * 4 * it2 * 144 * 2048 / tr / 1e6);
       const double bytes = (double)wgs * 256 * 9 * 16 * (it2 + 1), flop = (double)wgs * 4 * it2 * 144 * 2048;
       printf("node-shaped iters %2d wgs %4d: loads %7.1f us (%5.2f TB/s) | mfma %7.1f us (%6.1f TF) | both %7.1f us (%5.2f TB/s, %6.1f TF)\n",

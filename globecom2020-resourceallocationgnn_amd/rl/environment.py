@@ -124,6 +124,9 @@ class Environ(object):
         self.n_step = 0
         self.vehicles = []
         if n_Veh > 0:
+            if n_Veh % 4:
+                raise ValueError("n_Veh must be a multiple of 4 (vehicles are added four at a time, one per direction: "
+                                 "Environment.py:217-231); got %d" % n_Veh)
             self.n_Veh = n_Veh
         self.add_new_vehicles_by_number(int(self.n_Veh / 4))
         self._v2v_shadow = _gauss((self.n_Veh, self.n_Veh), self.V2V_SHADOW_STD)     # V2Vchannels.__init__ (:59)

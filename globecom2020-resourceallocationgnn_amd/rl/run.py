@@ -58,6 +58,10 @@ def main(argv=None):
     ap.add_argument("--opt", action="store_true", help="also run the brute-force optimum (C^N joint actions)")
     ap.add_argument("--seed", type=int, default=11)
     args = ap.parse_args(argv)
+    if args.links < 4 or args.links % 4:
+        # the simulator drops vehicles in groups of four, one per direction (Environment.py:217-231), and the
+        # observation divides by links - 2 (BS_brain.py:405)
+        ap.error("--links must be a multiple of 4 and at least 4 (got %d)" % args.links)
     random.seed(args.seed)
     np.random.seed(args.seed)
     cfg = RL_Config()

@@ -56,6 +56,10 @@ def main(argv=None):
     ap.add_argument("--save-dir", default=None)
     ap.add_argument("--use-graph", action="store_true")
     args = ap.parse_args(argv)
+    if args.links < 4 or args.links % 4:
+        # the simulator drops vehicles in groups of four, one per direction (Environment.py:217-231), and the
+        # observation divides by links - 2 (BS_brain.py:405)
+        ap.error("--links must be a multiple of 4 and at least 4 (got %d)" % args.links)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -201,15 +201,22 @@ def test_keras_layer_table_matches_weight_list():
     from v2xgnn.packing import keras_list_shapes
     for spec in (GnnSpec(), GnnSpec(n_nodes=20, feat_dim=64), GnnSpec(n_nodes=3, feat_dim=32, n_mp_layers=3, share_weights=True)):
         m = GnnQModel.__new__(GnnQModel)
-        m.spec = spec
+        m.spec, m.model_index = spec, 0
         table = m.keras_layer_table()
         assert sum(len(w) for _, w in table) == len(keras_list_shapes(spec))
         assert len({ln for ln, _ in table}) == len(table)
     m.spec = GnnSpec()
     t = m.keras_layer_table()
     assert t[0] == ('D1_GNN', ['D1_GNN/W1:0', 'D1_GNN/W2:0', 'D1_GNN/W3:0', 'D1_GNN/bias:0'])
-    assert t[4][0] == 'gnn_layer_1' and t[11][0] == 'gnn_layer_8' and t[12][0] == 'dense_1' and t[23][0] == 'dense_12'
+    assert t[4][0] == 'gnn_layer_1' and t[11][0] == 'gnn_layer_8'
+    # Keras numbers auto-named layers in CREATION order: node 1's Dense 80/40/20 are dense_1/2/3, node 2's dense_4/5/6
+    # (BS_brain.py:176-186); get_weights() lists them depth-sorted (all 80-wide layers first)
+    assert [t[i][0] for i in (12, 13, 14, 15)] == ['dense_1', 'dense_4', 'dense_7', 'dense_10']     # the four 80-wide layers
+    assert [t[i][0] for i in (16, 20)] == ['dense_2', 'dense_3'] and t[23][0] == 'dense_12'
     assert t[-1] == ('D4_Decide_Output', ['D4_Decide_Output/kernel:0', 'D4_Decide_Output/bias:0'])
+    m.model_index = 1                       # the target network is the second model of the session (BS_brain.py:106)
+    t = m.keras_layer_table()
+    assert t[4][0] == 'gnn_layer_9' and t[12][0] == 'dense_13' and t[0][0] == 'D1_GNN'
 
 
 def test_fit_minibatches_epochs_and_shuffle():

@@ -101,97 +101,144 @@ struct FusedFwdArgs {
   int n_graphs, N, L, S;                             // S = weight slots (N per-node, 1 shared)
   int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
   int* err;
+  long long* ts;                                     // TS builds: [8 waves][64] 100 MHz time stamps of workgroup 7
 };
 
+// phase time stamps of one workgroup (measurement builds only; v2x_debug_phase_stamps)
+template <bool TS>
+struct FzStamp {
+  long long* p; int n;
+  __device__ __forceinline__ FzStamp(long long* base, int wv, int lane) : p(nullptr), n(0) {
+    if (TS && base && blockIdx.x == 7 && lane == 0) p = base + wv * 64;
+  }
+  __device__ __forceinline__ void mark(bool drain = false) {
+    if (TS) {
+      if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      if (p && n < 64) p[n] = wall_clock64();
+      ++n;
+    }
+  }
+};
+
+// explicit GLOBAL accesses: pointers rebuilt from the kernarg segment are generic, and a FLAT store / load makes the
+// wait-count pass give up counting (vmcnt(0) in front of every dependent MFMA)
+typedef __attribute__((address_space(1))) f32x4* gvec_wp;
+__device__ __forceinline__ void stg4(float* p, f32x4 v) { *(gvec_wp)p = v; }
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *(gvec_p)p; }
+
 __device__ __forceinline__ f32x4 ldnt4(const float* p) {      // L1-bypassing load (data another wave of this CU just wrote)
-  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return __builtin_nontemporal_load((gvec_p)p);
 }
 
-template <int F>
-__global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a) {
+// Per stage a wave (1) gathers the neighbour sums of ALL its slots from LDS (all 8 waves do this at the same time: the
+// phase is LDS-bound and no MFMA waits behind it), (2) runs its slots' MFMAs back to back while the NEXT slot's weight
+// fragments stream in through a 3-chunk register ring (one 1 KiB load per 4 MFMAs: a wave issues in order, a burst of
+// loads in front of the MFMAs idles the matrix pipe -- tools/l2stream.hip), keeping the outputs in registers, and
+// (3) after a barrier writes them into the LDS tile for the next stage.  No global -> LDS reload between stages.
+//
+// NS = number of slots of THIS wave, a compile-time constant: the per-slot register arrays need constant indices, and
+// the MFMA phase must be straight-line code (a wave-uniform `if (slot exists)` between two slots makes the compiler's
+// wait-count pass merge two load histories and fall back to vmcnt(0) in front of the MFMAs, which stalls the ring).
+// The kernel instantiates the body for ceil(N/8) and ceil(N/8) - 1 slots and every wave picks one, once.  For the same
+// reason nothing is predicated per lane: lanes of graphs past the end of the batch shadow the last real graph (same
+// addresses, same values), so their stores are harmless duplicates.
+struct FzCtx {
+  float* sH; int* sRp; unsigned char* sCol;
+  int N, L, SUB, lane, wv, jc, kg, g0;
+};
+
+template <int F, int NS, bool TS>
+__device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCtx& x, const int e_begin, const int nedges,
+                                               const int nrows, const int r_begin) {
   using P = FzPack<F>;
   constexpr int FB = P::FB, KB = P::KB, ROWF = P::ROWF;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = a.N, L = a.L;
-  const int SUB = N * FZ_TG * ROWF;                              // floats per k-group sub-array
-  float* sH = smem;                                              // [4][N*16][ROWF]
-  int* sRp = reinterpret_cast<int*>(sH + 4 * SUB);               // [16 N + 1] edge offsets relative to the tile
-  unsigned char* sCol = reinterpret_cast<unsigned char*>(sRp + FZ_TG * N + 1);   // [edges] graph-local sources
+  constexpr bool RING = KB % 3 == 0 && NS > 0;                   // F = 64: 9 k-blocks = 3 chunks of 3; F = 16: 3 chunks of 1
+  constexpr int NCH = RING ? 3 : 1, CKB = KB / NCH, CHN = CKB * FB;   // chunks per slot, k-blocks / float4 per chunk
+  constexpr int NSA = NS > 0 ? NS : 1;
+  const int N = x.N, L = x.L, lane = x.lane, wv = x.wv, kg = x.kg, jc = x.jc;
+  FzStamp<TS> ts(a.ts, wv, lane);
+  ts.mark();                                                     // 0: start
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, kg = lane >> 4;
-  const int g0 = blockIdx.x * FZ_TG, ng = min(FZ_TG, a.n_graphs - g0);
-  const int r_begin = g0 * N, nrows = ng * N;
-  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
-  if (nedges > a.edges_cap || nedges < 0) {
-    if (tid == 0 && a.err) atomicOr(a.err, 1);
-    return;
+  int64_t rowi[NSA];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) rowi[i] = (int64_t)(x.g0 + jc) * N + (wv + FZ_WAVES * i);
+  // fragment-major weights of (stage s >= 1, this wave's i-th slot); the item after the last one aliases a real one
+  auto item_base = [&](int s, int i) -> const float* {
+    return a.pk + (int64_t)a.S * P::FWD0 + ((int64_t)(min(s, L) - 1) * a.S + (a.S == 1 ? 0 : wv + FZ_WAVES * i)) * P::FWD;
+  };
+  f32x4 wr[NCH][CHN];
+  auto wload = [&](int c, const float* base) {
+    gvec_p wp = (gvec_p)base + lane + c * CHN * 64;
+#pragma unroll
+    for (int u = 0; u < CHN; ++u) wr[c][u] = wp[u * 64];
+  };
+  // ---- everything that does not depend on the CSR slice is requested first
+  f32x4 xev[NSA], w0[NSA][FB], b0[NSA][FB];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const float* wb = a.pk + (int64_t)(a.S == 1 ? 0 : wv + FZ_WAVES * i) * P::FWD0;
+    xev[i] = ldg4(a.xe + rowi[i] * XE + 4 * kg);
+#pragma unroll
+    for (int nt = 0; nt < FB; ++nt) { w0[i][nt] = ((gvec_p)wb + lane)[nt * 64]; b0[i][nt] = ldg4(wb + FB * 256 + nt * 16 + 4 * kg); }
   }
-  for (int i = tid; i <= FZ_TG * N; i += FZ_THREADS) sRp[i] = i <= nrows ? a.row_ptr[r_begin + min(i, nrows)] - e_begin : nedges;
-  for (int i = tid; i < nedges; i += FZ_THREADS) sCol[i] = (unsigned char)min((unsigned)a.col_idx[e_begin + i], (unsigned)(N - 1));
+  if (RING && L >= 1) { wload(0, item_base(1, 0)); wload(1, item_base(1, 0)); }
+
+  for (int i = threadIdx.x; i <= FZ_TG * N; i += FZ_THREADS) x.sRp[i] = i <= nrows ? a.row_ptr[r_begin + min(i, nrows)] - e_begin : nedges;
+  for (int i = threadIdx.x; i < nedges; i += FZ_THREADS) x.sCol[i] = (unsigned char)min((unsigned)a.col_idx[e_begin + i], (unsigned)(N - 1));
 
   typedef const __attribute__((address_space(4))) uint64_t* CQ;
   CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
   auto hptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedFwdArgs, h) / 8 + s]); };
   auto aptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedFwdArgs, a) / 8 + s]); };
-
-  const bool valid = j < ng;
-  const int jc = valid ? j : ng - 1;                             // lanes of absent graphs shadow the last one, store nothing
-  float* myrow = sH + kg * SUB + j * ROWF;                       // + p*16*ROWF + kb*4
+  float* myrow = x.sH + kg * x.SUB + jc * ROWF;                  // + p*16*ROWF + kb*4
 
   // ---- stage 0 (embed): h_0 = relu(xe . W0 + b0); the neighbour-init block is absent (always zero in the reference)
   {
     float* hp = hptr(0);
-    for (int k = wv; k < N; k += FZ_WAVES) {
-      const int64_t row = (int64_t)(g0 + jc) * N + k;
-      const float* wb = a.pk + (int64_t)(a.S == 1 ? 0 : k) * P::FWD0;
-      gvec_p wp = (gvec_p)wb + lane;
-      f32x4 w[FB], bias[FB];
 #pragma unroll
-      for (int nt = 0; nt < FB; ++nt) w[nt] = wp[nt * 64];
-      const f32x4 xev = ld4(a.xe + row * XE + 4 * kg);
-#pragma unroll
-      for (int nt = 0; nt < FB; ++nt) bias[nt] = ld4(wb + FB * 256 + nt * 16 + 4 * kg);
+    for (int i = 0; i < NS; ++i) {
+      const int k = wv + FZ_WAVES * i;
       f32x4 acc[FB];
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int nt = 0; nt < FB; ++nt) acc[nt] = V2X_MFMA(w[nt][s], xev[s], acc[nt]);
+        for (int nt = 0; nt < FB; ++nt) acc[nt] = V2X_MFMA(w0[i][nt][s], xev[i][s], acc[nt]);
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) {
-        const f32x4 v = relu4(acc[nt] + bias[nt]);
-        if (valid) st4(hp + row * F + nt * 16 + 4 * kg, v);
+        const f32x4 v = relu4(acc[nt] + b0[i][nt]);
+        stg4(hp + rowi[i] * F + nt * 16 + 4 * kg, v);
         st4(myrow + k * FZ_TG * ROWF + nt * 4, v);
       }
     }
   }
+  ts.mark();                                                     // 1: embed done (before barrier)
   __syncthreads();
+  ts.mark();                                                     // 2: after barrier
 
   // neighbour gather of slot k for this lane's graph: a[kb] = sum over in-edges, ascending sources (k_agg_small order)
   auto gather = [&](int k, f32x4 (&ag)[FB]) {
 #pragma unroll
     for (int kb = 0; kb < FB; ++kb) ag[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int rl = j * N + k;
-    int e = sRp[rl];
-    const int e1 = sRp[rl + 1];
+    const int rl = jc * N + k;
+    int e = x.sRp[rl];
+    const int e1 = x.sRp[rl + 1];
     for (; e + 4 <= e1; e += 4) {
-      const float* b0 = myrow + (int)sCol[e] * (FZ_TG * ROWF);
-      const float* b1 = myrow + (int)sCol[e + 1] * (FZ_TG * ROWF);
-      const float* b2 = myrow + (int)sCol[e + 2] * (FZ_TG * ROWF);
-      const float* b3 = myrow + (int)sCol[e + 3] * (FZ_TG * ROWF);
+      const float* b0p = myrow + (int)x.sCol[e] * (FZ_TG * ROWF);
+      const float* b1p = myrow + (int)x.sCol[e + 1] * (FZ_TG * ROWF);
+      const float* b2p = myrow + (int)x.sCol[e + 2] * (FZ_TG * ROWF);
+      const float* b3p = myrow + (int)x.sCol[e + 3] * (FZ_TG * ROWF);
       f32x4 v0[FB], v1[FB], v2[FB], v3[FB];
 #pragma unroll
-      for (int kb = 0; kb < FB; ++kb) { v0[kb] = ld4(b0 + kb * 4); v1[kb] = ld4(b1 + kb * 4); v2[kb] = ld4(b2 + kb * 4); v3[kb] = ld4(b3 + kb * 4); }
+      for (int kb = 0; kb < FB; ++kb) { v0[kb] = ld4(b0p + kb * 4); v1[kb] = ld4(b1p + kb * 4); v2[kb] = ld4(b2p + kb * 4); v3[kb] = ld4(b3p + kb * 4); }
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) { ag[kb] += v0[kb]; ag[kb] += v1[kb]; ag[kb] += v2[kb]; ag[kb] += v3[kb]; }
     }
     for (; e < e1; ++e) {
-      const float* b0 = myrow + (int)sCol[e] * (FZ_TG * ROWF);
+      const float* b0p = myrow + (int)x.sCol[e] * (FZ_TG * ROWF);
 #pragma unroll
-      for (int kb = 0; kb < FB; ++kb) ag[kb] += ld4(b0 + kb * 4);
+      for (int kb = 0; kb < FB; ++kb) ag[kb] += ld4(b0p + kb * 4);
     }
   };
 
@@ -199,64 +246,109 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
   for (int s = 1; s <= L; ++s) {
     float* hp = hptr(s);
     float* ap = aptr(s - 1);
-    const float* stage_pk = a.pk + (int64_t)a.S * P::FWD0 + (int64_t)(s - 1) * a.S * P::FWD;
     const bool relu = s < L;
-    for (int k = wv; k < N; k += FZ_WAVES) {
-      const int64_t row = (int64_t)(g0 + jc) * N + k;
-      const float* wb = stage_pk + (int64_t)(a.S == 1 ? 0 : k) * P::FWD;
-      gvec_p wp = (gvec_p)wb + lane;
-      f32x4 w[KB * FB];
+    f32x4 ag[NSA][FB];                     // gathered a_{s-1} rows; slot i's registers become its output h_s afterwards
+    // (1) gather phase
 #pragma unroll
-      for (int c = 0; c < KB * FB; ++c) w[c] = wp[c * 64];       // 36 x 1 KiB from L2; lands while the gather runs
-      const f32x4 xev = ld4(a.xe + row * XE + 4 * kg);
-      f32x4 ag[FB], hb[FB];
-      gather(k, ag);
+    for (int i = 0; i < NS; ++i) {
+      gather(wv + FZ_WAVES * i, ag[i]);
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) stg4(ap + rowi[i] * F + kb * 16 + 4 * kg, ag[i][kb]);
+    }
+    ts.mark();                                                   // stage: gathers done
+    // (2) MFMA phase
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int k = wv + FZ_WAVES * i;
+      const float* cur = item_base(s, i);
+      const float* nxt = i + 1 < NS ? item_base(s, i + 1) : item_base(s + 1, 0);
+      f32x4 hb[FB], bias[FB], acc[FB];
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) hb[kb] = ld4(myrow + k * FZ_TG * ROWF + kb * 4);
-      if (valid) {
-#pragma unroll
-        for (int kb = 0; kb < FB; ++kb) st4(ap + row * F + kb * 16 + 4 * kg, ag[kb]);
-      }
-      f32x4 acc[FB];
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!RING) wload(0, cur);
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) {
-        const f32x4 bv = kb < FB ? hb[kb < FB ? kb : 0] : (kb == FB ? xev : ag[kb > FB ? kb - FB - 1 : 0]);
+      for (int c = 0; c < NCH; ++c) {
+        if (RING) wload((c + 2) % 3, c == 0 ? cur : nxt);        // refill the buffer consumed one chunk ago: 2 chunks ahead
+        if (c == (NCH > 1 ? 1 : 0)) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
+          for (int nt = 0; nt < FB; ++nt) bias[nt] = ldg4(cur + KB * FB * 256 + nt * 16 + 4 * kg);
+        }
 #pragma unroll
-          for (int nt = 0; nt < FB; ++nt) acc[nt] = V2X_MFMA(w[kb * FB + nt][s4], bv[s4], acc[nt]);
+        for (int q = 0; q < CKB; ++q) {
+          const int kb = c * CKB + q;
+          const f32x4 bv = kb < FB ? hb[kb < FB ? kb : 0] : (kb == FB ? xev[i] : ag[i][kb > FB ? kb - FB - 1 : 0]);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int nt = 0; nt < FB; ++nt) acc[nt] = V2X_MFMA(wr[c][q * FB + nt][s4], bv[s4], acc[nt]);
+        }
+        if (RING) {
+#pragma unroll
+          for (int u = 0; u < CHN; ++u) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) {
-        f32x4 v = acc[nt] + ld4(wb + KB * FB * 256 + nt * 16 + 4 * kg);
+        f32x4 v = acc[nt] + bias[nt];
         if (relu) v = relu4(v);
-        if (valid) st4(hp + row * F + nt * 16 + 4 * kg, v);
+        stg4(hp + rowi[i] * F + nt * 16 + 4 * kg, v);
+        ag[i][nt] = v;
       }
+      ts.mark();                                                 // slot: MFMAs + stores issued
     }
-    __syncthreads();                       // every wave is done gathering from h_{s-1}; all h_s rows have left the CU
-    for (int k = wv; k < N; k += FZ_WAVES) {                     // h_s -> LDS (own slots, same lane mapping as the stores)
-      const int64_t row = (int64_t)(g0 + jc) * N + k;
+    __syncthreads();                       // every wave is done reading the h_{s-1} tile
+    ts.mark();                                                   // stage: barrier passed
 #pragma unroll
-      for (int nt = 0; nt < FB; ++nt) st4(myrow + k * FZ_TG * ROWF + nt * 4, ldnt4(hp + row * F + nt * 16 + 4 * kg));
+    for (int i = 0; i < NS; ++i) {
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, ag[i][nt]);
     }
     __syncthreads();
+    ts.mark();                                                   // stage: tile replaced
   }
 
   // ---- a_L = Agg(h_L) for the decision MLP
   {
     float* ap = aptr(L);
-    for (int k = wv; k < N; k += FZ_WAVES) {
-      const int64_t row = (int64_t)(g0 + jc) * N + k;
-      f32x4 ag[FB];
-      gather(k, ag);
-      if (valid) {
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) st4(ap + row * F + kb * 16 + 4 * kg, ag[kb]);
-      }
+    for (int i = 0; i < NS; ++i) {
+      f32x4 ag[FB];
+      gather(wv + FZ_WAVES * i, ag);
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) stg4(ap + rowi[i] * F + kb * 16 + 4 * kg, ag[kb]);
     }
   }
+  ts.mark(true);                                                 // end
+}
+
+// SPW = ceil(N / 8) slots for the first N - 8 (SPW - 1) waves, SPW - 1 for the others
+template <int F, int SPW, bool TS = false>
+__global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a) {
+  using P = FzPack<F>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  FzCtx x;
+  x.N = a.N; x.L = a.L;
+  x.SUB = a.N * FZ_TG * P::ROWF;                                 // floats per k-group sub-array
+  x.sH = smem;                                                   // [4][N*16][ROWF]
+  x.sRp = reinterpret_cast<int*>(x.sH + 4 * x.SUB);              // [16 N + 1] edge offsets relative to the tile
+  x.sCol = reinterpret_cast<unsigned char*>(x.sRp + FZ_TG * a.N + 1);   // [edges] graph-local sources
+  x.lane = threadIdx.x & 63;
+  x.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  x.kg = x.lane >> 4;
+  x.g0 = blockIdx.x * FZ_TG;
+  const int ng = min(FZ_TG, a.n_graphs - x.g0);
+  x.jc = min(x.lane & 15, ng - 1);
+  const int r_begin = x.g0 * a.N, nrows = ng * a.N;
+  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
+  if (nedges > a.edges_cap || nedges < 0) {
+    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
+    return;
+  }
+  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_fwd_body<F, SPW, TS>(a, x, e_begin, nedges, nrows, r_begin);
+  else fused_fwd_body<F, SPW - 1, TS>(a, x, e_begin, nedges, nrows, r_begin);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -344,7 +436,7 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
       for (int nt = 0; nt < FB; ++nt) dh[nt] = ldnt4(a.gha + row * (2 * F) + nt * 16 + 4 * kg);
       if (gate) {
 #pragma unroll
-        for (int nt = 0; nt < FB; ++nt) hm[nt] = ld4(hp + row * F + nt * 16 + 4 * kg);
+        for (int nt = 0; nt < FB; ++nt) hm[nt] = ldg4(hp + row * F + nt * 16 + 4 * kg);
       }
       // transposed gather, ascending destinations (k_agg_small<true> order)
       f32x4 acc[FB];
@@ -362,7 +454,7 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
       for (int kb = 0; kb < FB; ++kb) {
         acc[kb] += dh[kb];
         if (gate) acc[kb] = gate4(acc[kb], hm[kb]);
-        if (valid) st4(dp + row * F + kb * 16 + 4 * kg, acc[kb]);
+        if (valid) stg4(dp + row * F + kb * 16 + 4 * kg, acc[kb]);
       }
       if (s > 0) {
         f32x4 o[2 * FB];
@@ -376,7 +468,7 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
             for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = V2X_MFMA(w[kb * 2 * FB + nt][s4], acc[kb][s4], o[nt]);
         if (valid) {
 #pragma unroll
-          for (int nt = 0; nt < 2 * FB; ++nt) st4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt]);
+          for (int nt = 0; nt < 2 * FB; ++nt) stg4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt]);
         }
       }
     }

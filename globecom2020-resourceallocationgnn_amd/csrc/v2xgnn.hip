@@ -67,6 +67,7 @@ struct v2x_model {
   // staging for host-side inputs
   DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
   DevBuf adj_mask;              // adjacency bit masks of the current batch (dense-graph aggregation)
+  long long* ts_buf = nullptr;                  // V2X_FUSED_TS=1: phase time stamps of the fused forward (measurement)
   float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
   int* flag_host = nullptr;     // pinned, device-mapped word the kernels raise on a contract violation (tile guards,
   int* flag_dev = nullptr;      // k_validate_batch); read by the host after any synchronising call
@@ -195,8 +196,12 @@ void set_attrs_f() {
 
 template <int F>
 void set_attrs_fused() {
-  allow_big_lds((const void*)k_gnn_fwd_fused<F>);
+  allow_big_lds((const void*)k_gnn_fwd_fused<F, 1>);
+  allow_big_lds((const void*)k_gnn_fwd_fused<F, 2>);
+  allow_big_lds((const void*)k_gnn_fwd_fused<F, 3>);
+  allow_big_lds((const void*)k_gnn_fwd_fused<F, 4>);
   allow_big_lds((const void*)k_gnn_bwd_fused<F>);
+  if (F == 64) allow_big_lds((const void*)k_gnn_fwd_fused<64, 3, true>);
 }
 
 void set_attrs(int F) {
@@ -1069,12 +1074,18 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.err = m->flag_dev;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   const size_t lds = fused_lds(m, d, false);
-  switch (m->F) {
-    case 16: { auto k = k_gnn_fwd_fused<16>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
-    case 32: { auto k = k_gnn_fwd_fused<32>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
-    case 64: { auto k = k_gnn_fwd_fused<64>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
+  const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
+#define V2X_FZ_FWD(FF, SP)                                                                                            \
+  if (m->F == FF && spw == SP) {                                                                                      \
+    if (FF == 64 && SP == 3 && m->ts_buf) { a.ts = m->ts_buf; auto k = k_gnn_fwd_fused<64, 3, true>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
+    else { auto k = k_gnn_fwd_fused<FF, SP>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); }        \
+    return V2X_OK;                                                                                                    \
   }
-  return V2X_OK;
+  V2X_FZ_FWD(16, 1) V2X_FZ_FWD(16, 2) V2X_FZ_FWD(16, 3) V2X_FZ_FWD(16, 4)
+  V2X_FZ_FWD(32, 1) V2X_FZ_FWD(32, 2) V2X_FZ_FWD(32, 3) V2X_FZ_FWD(32, 4)
+  V2X_FZ_FWD(64, 1) V2X_FZ_FWD(64, 2) V2X_FZ_FWD(64, 3) V2X_FZ_FWD(64, 4)
+#undef V2X_FZ_FWD
+  FAIL(m, V2X_EINVAL, "fused forward: unsupported shape");
 }
 
 int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
@@ -1349,6 +1360,10 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     if (dev_alloc(m, &m->pk_fwd, (size_t)m->S * fwd0 + (size_t)m->L * m->S * fwd) || dev_alloc(m, &m->pk_bwd, (size_t)m->L * m->S * bwd))
       return fail("allocation");
   }
+  if (m->pk_fwd && env_int("V2X_FUSED_TS", 0)) {
+    if (dev_alloc(m, &m->ts_buf, 8 * 64)) return fail("allocation");
+    hipMemset(m->ts_buf, 0, 8 * 64 * 8);
+  }
   if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->loss_part, 0, 512) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
   {
@@ -1381,6 +1396,7 @@ void v2x_destroy(v2x_model* m) {
   DevBuf* bufs[] = {&m->st_xe, &m->st_nbr, &m->st_goff, &m->st_rp, &m->st_ci, &m->st_y, &m->st_q, &m->adj_mask};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (m->flag_host) hipHostFree(m->flag_host);
+  if (m->ts_buf) hipFree(m->ts_buf);
   delete m;
 }
 
@@ -1696,6 +1712,14 @@ int v2x_check_errors(v2x_model* m, void* stream) {
 }
 
 // ---------------------------------------------------------------------------- measurement
+int v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n) {
+  if (!m || !out) FAIL(m, V2X_EINVAL, "null argument");
+  if (!m->ts_buf) FAIL(m, V2X_ESTATE, "phase stamps need V2X_FUSED_TS=1 when the model is created");
+  HIPCHK(m, hipDeviceSynchronize());
+  HIPCHK(m, hipMemcpy(out, m->ts_buf, (size_t)std::min(n, 8 * 64) * 8, hipMemcpyDeviceToHost));
+  return V2X_OK;
+}
+
 int v2x_profile_enable(v2x_model* m, int enable) {
   if (!m) FAIL(m, V2X_EINVAL, "null model");
   m->prof = enable != 0;

@@ -198,6 +198,9 @@ int  v2x_check_errors(v2x_model* m, void* stream);
 /* When enabled, every kernel launch of this model is bracketed by HIP events on its stream
  * (eager, no graph); v2x_profile_read returns per-kernel-name call counts and total ms.    */
 int  v2x_profile_enable(v2x_model* m, int enable);
+/* Models created with V2X_FUSED_TS=1 in the environment run a measurement build of the fused forward kernel in which
+ * workgroup 7 writes 100 MHz time stamps at its phase boundaries: out[wave * 64 + mark], n <= 512 entries.            */
+int  v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n);
 int  v2x_profile_read(v2x_model* m, char* names_out, int names_cap, double* ms_out, int64_t* calls_out,
                       int max_entries);   /* returns number of entries, names '\n'-separated */
 

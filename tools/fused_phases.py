@@ -1,0 +1,29 @@
+"""Where does the fused forward kernel spend its time?  Phase time stamps of workgroup 7 (V2X_FUSED_TS=1 build)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["V2X_FUSED_TS"] = "1"
+import bench  # noqa: E402
+import v2xgnn  # noqa: E402
+from v2xgnn import GnnSpec, PackedBatch, GnnEngine  # noqa: E402
+
+N, F, B = 20, 64, 4096
+rng = np.random.default_rng(1001)
+x, e, adj, y = bench.synth_batch(rng, B, N)
+eng = GnnEngine(GnnSpec(n_nodes=N, feat_dim=F))
+db = eng.to_device(PackedBatch.from_dense(x, e, adj))
+for _ in range(5):
+    eng.forward(db)
+buf = (C.c_int64 * 512)()
+rc = eng._lib.v2x_debug_phase_stamps(eng._h, buf, 512)
+assert rc == 0
+t = np.array(buf[:], np.int64).reshape(8, 64)
+t0 = t[:, 0].min()
+for w in range(8):
+    row = t[w][t[w] > 0]
+    print("wave %d:" % w, " ".join("%6.2f" % ((v - t0) / 100.0) for v in row))
+print("marks: 0 start | 1 embed done | 2 barrier | per stage: per slot [loads issued, gather done, weights landed, mfma+stores issued] ... | stores drained | barrier | reloaded | ... | end   (us)")

@@ -142,6 +142,22 @@ __device__ __forceinline__ f32x4 ldnt4(const float* p) {      // L1-bypassing lo
 // The kernel instantiates the body for ceil(N/8) and ceil(N/8) - 1 slots and every wave picks one, once.  For the same
 // reason nothing is predicated per lane: lanes of graphs past the end of the batch shadow the last real graph (same
 // addresses, same values), so their stores are harmless duplicates.
+// CSR slice of the tile -> LDS: edge offsets relative to the tile, sources as bytes.  U loads in flight per thread
+// (one load -> wait -> store per iteration costs a full HBM latency each: 6 us for 5760 edges).
+__device__ __forceinline__ void stage_csr(const int32_t* row_ptr, const int32_t* col_idx, int* sRp, unsigned char* sCol, int N,
+                                          int r_begin, int nrows, int e_begin, int nedges) {
+  constexpr int U = 6;
+  for (int i = threadIdx.x; i <= FZ_TG * N; i += FZ_THREADS) sRp[i] = i <= nrows ? row_ptr[r_begin + min(i, nrows)] - e_begin : nedges;
+  for (int base = threadIdx.x; base < nedges; base += FZ_THREADS * U) {
+    int v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = col_idx[e_begin + min(base + u * FZ_THREADS, nedges - 1)];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (base + u * FZ_THREADS < nedges) sCol[base + u * FZ_THREADS] = (unsigned char)min((unsigned)v[u], (unsigned)(N - 1));
+  }
+}
+
 struct FzCtx {
   float* sH; int* sRp; unsigned char* sCol;
   int N, L, SUB, lane, wv, jc, kg, g0;
@@ -183,8 +199,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   }
   if (RING && L >= 1) { wload(0, item_base(1, 0)); wload(1, item_base(1, 0)); }
 
-  for (int i = threadIdx.x; i <= FZ_TG * N; i += FZ_THREADS) x.sRp[i] = i <= nrows ? a.row_ptr[r_begin + min(i, nrows)] - e_begin : nedges;
-  for (int i = threadIdx.x; i < nedges; i += FZ_THREADS) x.sCol[i] = (unsigned char)min((unsigned)a.col_idx[e_begin + i], (unsigned)(N - 1));
+  stage_csr(a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
 
   typedef const __attribute__((address_space(4))) uint64_t* CQ;
   CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
@@ -355,7 +370,10 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
 // backward of the graph layers:  for s = L..0   dpre_s = (dh_s + Agg^T(dagg_s)) * act'(h_s),
 //                                for s >= 1     [dh_{s-1} | dagg_{s-1}] = dpre_s . [W1h_s | W3_s]^T
 // In: gha = [dh_L | dagg_L] (decision-MLP backward).  Out: dpre_s for the weight-gradient launch.  gha is reused as
-// the scratch of the lower stages (a row is read and rewritten by the wave that owns its slot).
+// the scratch of the lower stages: the dh half of a row is written and read back by the wave that owns its slot (the
+// read is issued a whole gather ahead of its use), the dagg half goes from registers into the LDS tile after the
+// barrier.  Same phase structure as the forward kernel: transposed gathers of all own slots, then the MFMAs with the
+// weight fragments streaming through a 4-chunk register ring.
 // ---------------------------------------------------------------------------------------------------------------
 struct FusedBwdArgs {
   const int32_t* row_ptr; const int32_t* col_idx;
@@ -365,119 +383,172 @@ struct FusedBwdArgs {
   float* gha;                                        // [R][2F]
   int n_graphs, N, L, S, edges_cap;
   int* err;
+  long long* ts;
 };
 
-template <int F>
-__global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a) {
+struct FzCtxB {
+  float* sD; int* sRp; unsigned* sM; unsigned char* sCol;
+  int N, L, SUB, lane, wv, jc, kg, g0;
+};
+
+template <int F, int NS, bool TS>
+__device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCtxB& x, const int e_begin, const int nedges,
+                                               const int nrows, const int r_begin) {
   using P = FzPack<F>;
   constexpr int FB = P::FB, ROWF = P::ROWF;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int N = a.N, L = a.L;
-  const int SUB = N * FZ_TG * ROWF;
-  float* sD = smem;                                              // dagg tile, same layout as the forward tile
-  int* sRp = reinterpret_cast<int*>(sD + 4 * SUB);               // [16 N + 1]
-  unsigned* sM = reinterpret_cast<unsigned*>(sRp + FZ_TG * N + 1);   // [16 N] out-neighbour bit masks (N <= 32)
-  unsigned char* sCol = reinterpret_cast<unsigned char*>(sM + FZ_TG * N);
+  constexpr bool RING = FB == 4 && NS > 0;
+  constexpr int NCH = RING ? FB : 1, CKB = FB / NCH, CHN = CKB * 2 * FB;     // chunk = CKB k-blocks x 2FB n-tiles
+  constexpr int NSA = NS > 0 ? NS : 1;
+  const int N = x.N, L = x.L, lane = x.lane, wv = x.wv, kg = x.kg, jc = x.jc;
+  FzStamp<TS> ts(a.ts ? a.ts + 512 : nullptr, wv, lane);
+  ts.mark();
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 15, kg = lane >> 4;
-  const int g0 = blockIdx.x * FZ_TG, ng = min(FZ_TG, a.n_graphs - g0);
-  const int r_begin = g0 * N, nrows = ng * N;
-  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
-  if (nedges > a.edges_cap || nedges < 0) {
-    if (tid == 0 && a.err) atomicOr(a.err, 1);
-    return;
+  int64_t rowi[NSA];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) rowi[i] = (int64_t)(x.g0 + jc) * N + (wv + FZ_WAVES * i);
+  auto item_base = [&](int s, int i) -> const float* {           // stage s >= 1 (clamped), this wave's i-th slot
+    return a.pk + ((int64_t)(max(s, 1) - 1) * a.S + (a.S == 1 ? 0 : wv + FZ_WAVES * i)) * P::BWD;
+  };
+  f32x4 wr[NCH][CHN];
+  auto wload = [&](int c, const float* base) {
+    gvec_p wp = (gvec_p)base + lane + c * CHN * 64;
+#pragma unroll
+    for (int u = 0; u < CHN; ++u) wr[c][u] = wp[u * 64];
+  };
+  float* myrow = x.sD + kg * x.SUB + jc * ROWF;
+  // requests that do not depend on the CSR slice first: the dagg_L rows of the own slots, the first weight chunks
+  f32x4 dg[NSA][FB];                     // dagg rows of the own slots on their way into the LDS tile
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int nt = 0; nt < FB; ++nt) dg[i][nt] = ldnt4(a.gha + rowi[i] * (2 * F) + F + nt * 16 + 4 * kg);
+  if (RING && L >= 1) {
+#pragma unroll
+    for (int c = 0; c + 1 < NCH; ++c) wload(c, item_base(L, 0));
   }
-  for (int i = tid; i <= FZ_TG * N; i += FZ_THREADS) sRp[i] = i <= nrows ? a.row_ptr[r_begin + min(i, nrows)] - e_begin : nedges;
-  for (int i = tid; i < nedges; i += FZ_THREADS) sCol[i] = (unsigned char)min((unsigned)a.col_idx[e_begin + i], (unsigned)(N - 1));
-  for (int i = tid; i < FZ_TG * N; i += FZ_THREADS) sM[i] = 0u;
+  stage_csr(a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
+  for (int i = threadIdx.x; i < FZ_TG * N; i += FZ_THREADS) x.sM[i] = 0u;
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+#pragma unroll
+    for (int nt = 0; nt < FB; ++nt) st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, dg[i][nt]);
   __syncthreads();
   // transposed adjacency: bit q of sM[j*N + p] = edge p -> q (integer atomics: order-independent)
-  for (int r = tid; r < nrows; r += FZ_THREADS) {
+  for (int r = threadIdx.x; r < nrows; r += FZ_THREADS) {
     const int jj = r / N, q = r - jj * N;
-    for (int e = sRp[r]; e < sRp[r + 1]; ++e) atomicOr(&sM[jj * N + sCol[e]], 1u << q);
+    for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) atomicOr(&x.sM[jj * N + x.sCol[e]], 1u << q);
   }
+  __syncthreads();
+  ts.mark();                                                     // 1: tile + masks ready
 
   typedef const __attribute__((address_space(4))) uint64_t* CQ;
   CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
   auto hptr = [&](int s) { return reinterpret_cast<const float*>(kq[offsetof(FusedBwdArgs, h) / 8 + s]); };
   auto dptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedBwdArgs, dpre) / 8 + s]); };
 
-  const bool valid = j < ng;
-  const int jc = valid ? j : ng - 1;
-  float* myrow = sD + kg * SUB + j * ROWF;
-
-  auto load_tile = [&]() {                                       // dagg part of gha -> LDS (own slots)
-    for (int k = wv; k < N; k += FZ_WAVES) {
-      const int64_t row = (int64_t)(g0 + jc) * N + k;
-#pragma unroll
-      for (int nt = 0; nt < FB; ++nt) st4(myrow + k * FZ_TG * ROWF + nt * 4, ldnt4(a.gha + row * (2 * F) + F + nt * 16 + 4 * kg));
-    }
-  };
-  load_tile();
-  __syncthreads();
-
   for (int s = L; s >= 0; --s) {
     const float* hp = hptr(s);
     float* dp = dptr(s);
-    const float* stage_pk = a.pk + (int64_t)(s > 0 ? s - 1 : 0) * a.S * P::BWD;
     const bool gate = s < L;
-    for (int k = wv; k < N; k += FZ_WAVES) {
-      const int64_t row = (int64_t)(g0 + jc) * N + k;
-      gvec_p wp = (gvec_p)(stage_pk + (int64_t)(a.S == 1 ? 0 : k) * P::BWD) + lane;
-      f32x4 w[FB * 2 * FB];
-      if (s > 0) {
+    f32x4 dpre[NSA][FB];
+    // (1) transposed gathers (ascending destinations: k_agg_small<true> order), + dh, ReLU' gate
 #pragma unroll
-        for (int c = 0; c < FB * 2 * FB; ++c) w[c] = wp[c * 64];
-      }
+    for (int i = 0; i < NS; ++i) {
       f32x4 dh[FB], hm[FB];
 #pragma unroll
-      for (int nt = 0; nt < FB; ++nt) dh[nt] = ldnt4(a.gha + row * (2 * F) + nt * 16 + 4 * kg);
-      if (gate) {
-#pragma unroll
-        for (int nt = 0; nt < FB; ++nt) hm[nt] = ldg4(hp + row * F + nt * 16 + 4 * kg);
+      for (int nt = 0; nt < FB; ++nt) {
+        dh[nt] = ldnt4(a.gha + rowi[i] * (2 * F) + nt * 16 + 4 * kg);
+        hm[nt] = ldg4(hp + rowi[i] * F + nt * 16 + 4 * kg);
       }
-      // transposed gather, ascending destinations (k_agg_small<true> order)
-      f32x4 acc[FB];
 #pragma unroll
-      for (int kb = 0; kb < FB; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      unsigned bits = sM[j * N + k];
+      for (int kb = 0; kb < FB; ++kb) dpre[i][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      unsigned bits = x.sM[jc * N + wv + FZ_WAVES * i];
       while (bits) {
         const int q = __builtin_ctz(bits);
         bits &= bits - 1;
         const float* b0 = myrow + q * (FZ_TG * ROWF);
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) acc[kb] += ld4(b0 + kb * 4);
+        for (int kb = 0; kb < FB; ++kb) dpre[i][kb] += ld4(b0 + kb * 4);
       }
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) {
-        acc[kb] += dh[kb];
-        if (gate) acc[kb] = gate4(acc[kb], hm[kb]);
-        if (valid) stg4(dp + row * F + kb * 16 + 4 * kg, acc[kb]);
+        dpre[i][kb] += dh[kb];
+        if (gate) dpre[i][kb] = gate4(dpre[i][kb], hm[kb]);
+        stg4(dp + rowi[i] * F + kb * 16 + 4 * kg, dpre[i][kb]);
       }
-      if (s > 0) {
-        f32x4 o[2 * FB];
+    }
+    ts.mark();                                                   // stage: gathers done
+    if (s == 0) break;
+    // (2) data gradients of the own slots
 #pragma unroll
-        for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NS; ++i) {
+      const float* cur = item_base(s, i);
+      const float* nxt = i + 1 < NS ? item_base(s, i + 1) : item_base(s - 1, 0);
+      f32x4 o[2 * FB];
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb)
+      for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (!RING) wload(0, cur);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (RING) wload((c + NCH - 1) % NCH, c == 0 ? cur : nxt);    // the buffer consumed one chunk ago: NCH-1 chunks ahead
+#pragma unroll
+        for (int q = 0; q < CKB; ++q) {
+          const int kb = c * CKB + q;
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = V2X_MFMA(w[kb * 2 * FB + nt][s4], acc[kb][s4], o[nt]);
-        if (valid) {
-#pragma unroll
-          for (int nt = 0; nt < 2 * FB; ++nt) stg4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt]);
+            for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = V2X_MFMA(wr[c][q * 2 * FB + nt][s4], dpre[i][kb][s4], o[nt]);
         }
+        if (RING) {
+#pragma unroll
+          for (int u = 0; u < CHN; ++u) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) {
+        stg4(a.gha + rowi[i] * (2 * F) + nt * 16 + 4 * kg, o[nt]);           // dh_{s-1}: read back by this wave next stage
+        dg[i][nt] = o[FB + nt];                                              // dagg_{s-1}: into the LDS tile after the barrier
+      }
+      ts.mark();                                                 // slot done
     }
-    if (s > 0) {
-      __syncthreads();                     // all gathers from dagg_s done; the new [dh | dagg] rows have left the CU
-      load_tile();
-      __syncthreads();
-    }
+    __syncthreads();                       // all gathers from dagg_s done; own dh rows have left the CU
+    ts.mark();
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, dg[i][nt]);
+    __syncthreads();
+    ts.mark();                                                   // stage: tile replaced
   }
+  ts.mark(true);
+}
+
+template <int F, int SPW, bool TS = false>
+__global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a) {
+  using P = FzPack<F>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  FzCtxB x;
+  x.N = a.N; x.L = a.L;
+  x.SUB = a.N * FZ_TG * P::ROWF;
+  x.sD = smem;                                                   // dagg tile, same layout as the forward tile
+  x.sRp = reinterpret_cast<int*>(x.sD + 4 * x.SUB);              // [16 N + 1]
+  x.sM = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // [16 N] out-neighbour bit masks (N <= 32)
+  x.sCol = reinterpret_cast<unsigned char*>(x.sM + FZ_TG * a.N);
+  x.lane = threadIdx.x & 63;
+  x.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  x.kg = x.lane >> 4;
+  x.g0 = blockIdx.x * FZ_TG;
+  const int ng = min(FZ_TG, a.n_graphs - x.g0);
+  x.jc = min(x.lane & 15, ng - 1);
+  const int r_begin = x.g0 * a.N, nrows = ng * a.N;
+  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
+  if (nedges > a.edges_cap || nedges < 0) {
+    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
+    return;
+  }
+  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_bwd_body<F, SPW, TS>(a, x, e_begin, nedges, nrows, r_begin);
+  else fused_bwd_body<F, SPW - 1, TS>(a, x, e_begin, nedges, nrows, r_begin);
 }
 
 }  // namespace v2x

@@ -200,8 +200,11 @@ void set_attrs_fused() {
   allow_big_lds((const void*)k_gnn_fwd_fused<F, 2>);
   allow_big_lds((const void*)k_gnn_fwd_fused<F, 3>);
   allow_big_lds((const void*)k_gnn_fwd_fused<F, 4>);
-  allow_big_lds((const void*)k_gnn_bwd_fused<F>);
-  if (F == 64) allow_big_lds((const void*)k_gnn_fwd_fused<64, 3, true>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F, 1>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F, 2>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F, 3>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F, 4>);
+  if (F == 64) { allow_big_lds((const void*)k_gnn_fwd_fused<64, 3, true>); allow_big_lds((const void*)k_gnn_bwd_fused<64, 3, true>); }
 }
 
 void set_attrs(int F) {
@@ -1096,12 +1099,18 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.err = m->flag_dev;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   const size_t lds = fused_lds(m, d, true);
-  switch (m->F) {
-    case 16: { auto k = k_gnn_bwd_fused<16>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
-    case 32: { auto k = k_gnn_bwd_fused<32>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
-    case 64: { auto k = k_gnn_bwd_fused<64>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); break; }
+  const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
+#define V2X_FZ_BWD(FF, SP)                                                                                            \
+  if (m->F == FF && spw == SP) {                                                                                      \
+    if (FF == 64 && SP == 3 && m->ts_buf) { a.ts = m->ts_buf; auto k = k_gnn_bwd_fused<64, 3, true>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
+    else { auto k = k_gnn_bwd_fused<FF, SP>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); }        \
+    return V2X_OK;                                                                                                    \
   }
-  return V2X_OK;
+  V2X_FZ_BWD(16, 1) V2X_FZ_BWD(16, 2) V2X_FZ_BWD(16, 3) V2X_FZ_BWD(16, 4)
+  V2X_FZ_BWD(32, 1) V2X_FZ_BWD(32, 2) V2X_FZ_BWD(32, 3) V2X_FZ_BWD(32, 4)
+  V2X_FZ_BWD(64, 1) V2X_FZ_BWD(64, 2) V2X_FZ_BWD(64, 3) V2X_FZ_BWD(64, 4)
+#undef V2X_FZ_BWD
+  FAIL(m, V2X_EINVAL, "fused backward: unsupported shape");
 }
 
 // ------------------------------------------------------------------------------------ passes
@@ -1361,8 +1370,8 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
       return fail("allocation");
   }
   if (m->pk_fwd && env_int("V2X_FUSED_TS", 0)) {
-    if (dev_alloc(m, &m->ts_buf, 8 * 64)) return fail("allocation");
-    hipMemset(m->ts_buf, 0, 8 * 64 * 8);
+    if (dev_alloc(m, &m->ts_buf, 2 * 8 * 64)) return fail("allocation");
+    hipMemset(m->ts_buf, 0, 2 * 8 * 64 * 8);
   }
   if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->loss_part, 0, 512) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
@@ -1716,7 +1725,7 @@ int v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n) {
   if (!m || !out) FAIL(m, V2X_EINVAL, "null argument");
   if (!m->ts_buf) FAIL(m, V2X_ESTATE, "phase stamps need V2X_FUSED_TS=1 when the model is created");
   HIPCHK(m, hipDeviceSynchronize());
-  HIPCHK(m, hipMemcpy(out, m->ts_buf, (size_t)std::min(n, 8 * 64) * 8, hipMemcpyDeviceToHost));
+  HIPCHK(m, hipMemcpy(out, m->ts_buf, (size_t)std::min(n, 2 * 8 * 64) * 8, hipMemcpyDeviceToHost));
   return V2X_OK;
 }
 

@@ -16,14 +16,18 @@ rng = np.random.default_rng(1001)
 x, e, adj, y = bench.synth_batch(rng, B, N)
 eng = GnnEngine(GnnSpec(n_nodes=N, feat_dim=F))
 db = eng.to_device(PackedBatch.from_dense(x, e, adj))
+import torch  # noqa: E402
+yd = torch.from_numpy(y).cuda()
 for _ in range(5):
-    eng.forward(db)
-buf = (C.c_int64 * 512)()
-rc = eng._lib.v2x_debug_phase_stamps(eng._h, buf, 512)
+    eng.train_step(db, yd)
+buf = (C.c_int64 * 1024)()
+rc = eng._lib.v2x_debug_phase_stamps(eng._h, buf, 1024)
 assert rc == 0
-t = np.array(buf[:], np.int64).reshape(8, 64)
-t0 = t[:, 0].min()
-for w in range(8):
-    row = t[w][t[w] > 0]
-    print("wave %d:" % w, " ".join("%6.2f" % ((v - t0) / 100.0) for v in row))
+for name, t in zip(("forward", "backward"), np.array(buf[:], np.int64).reshape(2, 8, 64)):
+    t0 = t[:, 0].min()
+    print(name)
+    for w in range(8):
+        row = t[w][t[w] > 0]
+        print("  wave %d:" % w, " ".join("%6.2f" % ((v - t0) / 100.0) for v in row))
+print("backward marks: 0 start | 1 tile + masks ready | per stage: gathers done, slot done x n, barrier, tile replaced | end")
 print("marks: 0 start | 1 embed done | 2 barrier | per stage: per slot [loads issued, gather done, weights landed, mfma+stores issued] ... | stores drained | barrier | reloaded | ... | end   (us)")

@@ -100,6 +100,7 @@ struct FusedFwdArgs {
   float* h[FZ_MAXL + 1]; float* a[FZ_MAXL + 1];      // stage outputs h_s and their aggregations a_s, [R][F]
   int n_graphs, N, L, S;                             // S = weight slots (N per-node, 1 shared)
   int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
+  int n_edges;                                       // E of the whole batch
   int* err;
   long long* ts;                                     // TS builds: [8 waves][64] 100 MHz time stamps of workgroup 7
 };
@@ -142,18 +143,43 @@ __device__ __forceinline__ f32x4 ldnt4(const float* p) {      // L1-bypassing lo
 // The kernel instantiates the body for ceil(N/8) and ceil(N/8) - 1 slots and every wave picks one, once.  For the same
 // reason nothing is predicated per lane: lanes of graphs past the end of the batch shadow the last real graph (same
 // addresses, same values), so their stores are harmless duplicates.
-// CSR slice of the tile -> LDS: edge offsets relative to the tile, sources as bytes.  U loads in flight per thread
-// (one load -> wait -> store per iteration costs a full HBM latency each: 6 us for 5760 edges).
-__device__ __forceinline__ void stage_csr(const int32_t* row_ptr, const int32_t* col_idx, int* sRp, unsigned char* sCol, int N,
-                                          int r_begin, int nrows, int e_begin, int nedges) {
-  constexpr int U = 6;
-  for (int i = threadIdx.x; i <= FZ_TG * N; i += FZ_THREADS) sRp[i] = i <= nrows ? row_ptr[r_begin + min(i, nrows)] - e_begin : nedges;
-  for (int base = threadIdx.x; base < nedges; base += FZ_THREADS * U) {
-    int v[U];
+// CSR slice of the tile -> LDS: edge offsets relative to the tile, sources as bytes.  The loads are on the critical path
+// of the launch (kernel start -> row_ptr[first row] -> col_idx slice -> LDS -> first gather), so they are issued before
+// anything else and do not wait for row_ptr: the slice is fetched from the offset it has when every graph holds max_edges
+// edges (always true for the reference topology) and only re-fetched if that guess turns out wrong.
+constexpr int FZ_CSR_U = 12;      // early source loads per thread: 512 x 12 = 6144 edges (16 graphs x 360 = 5760)
+struct FzCsrEarly { int cv[FZ_CSR_U]; int rpv[2]; int e_guess; };
+__device__ __forceinline__ void csr_issue(FzCsrEarly& c, const int32_t* row_ptr, const int32_t* col_idx, int r_begin, int nrows,
+                                          int g0, int edges_cap, int n_edges_total) {
+  c.e_guess = g0 * (edges_cap / FZ_TG);
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = col_idx[e_begin + min(base + u * FZ_THREADS, nedges - 1)];
+  for (int u = 0; u < FZ_CSR_U; ++u) c.cv[u] = col_idx[max(min(c.e_guess + (int)threadIdx.x + u * FZ_THREADS, n_edges_total - 1), 0)];
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+  for (int u = 0; u < 2; ++u) c.rpv[u] = row_ptr[r_begin + min((int)threadIdx.x + u * FZ_THREADS, nrows)];
+}
+__device__ __forceinline__ void csr_commit(const FzCsrEarly& c, const int32_t* row_ptr, const int32_t* col_idx, int* sRp,
+                                           unsigned char* sCol, int N, int r_begin, int nrows, int e_begin, int nedges) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * FZ_THREADS;
+    if (i <= FZ_TG * N) sRp[i] = i <= nrows ? c.rpv[u] - e_begin : nedges;
+  }
+  for (int i = threadIdx.x + 2 * FZ_THREADS; i <= FZ_TG * N; i += FZ_THREADS) sRp[i] = i <= nrows ? row_ptr[r_begin + i] - e_begin : nedges;
+  int done = 0;
+  if (e_begin == c.e_guess) {                                    // workgroup-uniform
+#pragma unroll
+    for (int u = 0; u < FZ_CSR_U; ++u) {
+      const int i = threadIdx.x + u * FZ_THREADS;
+      if (i < nedges) sCol[i] = (unsigned char)min((unsigned)c.cv[u], (unsigned)(N - 1));
+    }
+    done = FZ_CSR_U * FZ_THREADS;
+  }
+  for (int base = done + threadIdx.x; base < nedges; base += FZ_THREADS * 6) {
+    int v[6];
+#pragma unroll
+    for (int u = 0; u < 6; ++u) v[u] = col_idx[e_begin + min(base + u * FZ_THREADS, nedges - 1)];
+#pragma unroll
+    for (int u = 0; u < 6; ++u)
       if (base + u * FZ_THREADS < nedges) sCol[base + u * FZ_THREADS] = (unsigned char)min((unsigned)v[u], (unsigned)(N - 1));
   }
 }
@@ -164,8 +190,7 @@ struct FzCtx {
 };
 
 template <int F, int NS, bool TS>
-__device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCtx& x, const int e_begin, const int nedges,
-                                               const int nrows, const int r_begin) {
+__device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCtx& x, const int nrows, const int r_begin) {
   using P = FzPack<F>;
   constexpr int FB = P::FB, KB = P::KB, ROWF = P::ROWF;
   constexpr bool RING = KB % 3 == 0 && NS > 0;                   // F = 64: 9 k-blocks = 3 chunks of 3; F = 16: 3 chunks of 1
@@ -188,7 +213,9 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
 #pragma unroll
     for (int u = 0; u < CHN; ++u) wr[c][u] = wp[u * 64];
   };
-  // ---- everything that does not depend on the CSR slice is requested first
+  // ---- requests in the order of their urgency: CSR slice, embed operands, the first weight chunks of stage 1
+  FzCsrEarly csr;
+  csr_issue(csr, a.row_ptr, a.col_idx, r_begin, nrows, x.g0, a.edges_cap, a.n_edges);
   f32x4 xev[NSA], w0[NSA][FB], b0[NSA][FB];
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -198,8 +225,12 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     for (int nt = 0; nt < FB; ++nt) { w0[i][nt] = ((gvec_p)wb + lane)[nt * 64]; b0[i][nt] = ldg4(wb + FB * 256 + nt * 16 + 4 * kg); }
   }
   if (RING && L >= 1) { wload(0, item_base(1, 0)); wload(1, item_base(1, 0)); }
-
-  stage_csr(a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
+  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
+  if (nedges > a.edges_cap || nedges < 0) {                      // workgroup-uniform, before any barrier
+    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
+    return;
+  }
+  csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
 
   typedef const __attribute__((address_space(4))) uint64_t* CQ;
   CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
@@ -357,23 +388,17 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
   const int ng = min(FZ_TG, a.n_graphs - x.g0);
   x.jc = min(x.lane & 15, ng - 1);
   const int r_begin = x.g0 * a.N, nrows = ng * a.N;
-  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
-  if (nedges > a.edges_cap || nedges < 0) {
-    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
-    return;
-  }
-  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_fwd_body<F, SPW, TS>(a, x, e_begin, nedges, nrows, r_begin);
-  else fused_fwd_body<F, SPW - 1, TS>(a, x, e_begin, nedges, nrows, r_begin);
+  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_fwd_body<F, SPW, TS>(a, x, nrows, r_begin);
+  else fused_fwd_body<F, SPW - 1, TS>(a, x, nrows, r_begin);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // backward of the graph layers:  for s = L..0   dpre_s = (dh_s + Agg^T(dagg_s)) * act'(h_s),
 //                                for s >= 1     [dh_{s-1} | dagg_{s-1}] = dpre_s . [W1h_s | W3_s]^T
 // In: gha = [dh_L | dagg_L] (decision-MLP backward).  Out: dpre_s for the weight-gradient launch.  gha is reused as
-// the scratch of the lower stages: the dh half of a row is written and read back by the wave that owns its slot (the
-// read is issued a whole gather ahead of its use), the dagg half goes from registers into the LDS tile after the
-// barrier.  Same phase structure as the forward kernel: transposed gathers of all own slots, then the MFMAs with the
-// weight fragments streaming through a 4-chunk register ring.
+// only read: dh_{s-1} of a row is produced and consumed by the same wave (it owns the row's slot in every stage) and
+// stays in its registers, the dagg half goes from registers into the LDS tile after the barrier.  Same phase structure as the forward kernel: transposed gathers of all own slots, then the MFMAs with the
+// weight fragments streaming through a register ring of 3 one-k-block chunks (2 in flight), restarted per stage.
 // ---------------------------------------------------------------------------------------------------------------
 struct FusedBwdArgs {
   const int32_t* row_ptr; const int32_t* col_idx;
@@ -381,7 +406,7 @@ struct FusedBwdArgs {
   const float* h[FZ_MAXL + 1];                       // forward activations (ReLU' gates)
   float* dpre[FZ_MAXL + 1];
   float* gha;                                        // [R][2F]
-  int n_graphs, N, L, S, edges_cap;
+  int n_graphs, N, L, S, edges_cap, n_edges;
   int* err;
   long long* ts;
 };
@@ -392,12 +417,11 @@ struct FzCtxB {
 };
 
 template <int F, int NS, bool TS>
-__device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCtxB& x, const int e_begin, const int nedges,
-                                               const int nrows, const int r_begin) {
+__device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCtxB& x, const int nrows, const int r_begin) {
   using P = FzPack<F>;
   constexpr int FB = P::FB, ROWF = P::ROWF;
-  constexpr bool RING = FB == 4 && NS > 0;
-  constexpr int NCH = RING ? FB : 1, CKB = FB / NCH, CHN = CKB * 2 * FB;     // chunk = CKB k-blocks x 2FB n-tiles
+  constexpr bool RING = FB >= 3 && NS > 0;                       // chunk = one k-block x 2FB n-tiles (8 float4, 32 MFMAs at F = 64)
+  constexpr int NCH = RING ? FB : 1, CKB = FB / NCH, CHN = CKB * 2 * FB, NB = RING ? 3 : 1;
   constexpr int NSA = NS > 0 ? NS : 1;
   const int N = x.N, L = x.L, lane = x.lane, wv = x.wv, kg = x.kg, jc = x.jc;
   FzStamp<TS> ts(a.ts ? a.ts + 512 : nullptr, wv, lane);
@@ -406,28 +430,35 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   int64_t rowi[NSA];
 #pragma unroll
   for (int i = 0; i < NS; ++i) rowi[i] = (int64_t)(x.g0 + jc) * N + (wv + FZ_WAVES * i);
-  auto item_base = [&](int s, int i) -> const float* {           // stage s >= 1 (clamped), this wave's i-th slot
-    return a.pk + ((int64_t)(max(s, 1) - 1) * a.S + (a.S == 1 ? 0 : wv + FZ_WAVES * i)) * P::BWD;
+  auto item_base = [&](int s, int i) -> const float* {           // stage s >= 1, this wave's i-th slot
+    return a.pk + ((int64_t)(s - 1) * a.S + (a.S == 1 ? 0 : wv + FZ_WAVES * i)) * P::BWD;
   };
-  f32x4 wr[NCH][CHN];
-  auto wload = [&](int c, const float* base) {
+  f32x4 wr[NB][CHN];
+  auto wload = [&](int buf, int c, const float* base) {
     gvec_p wp = (gvec_p)base + lane + c * CHN * 64;
 #pragma unroll
-    for (int u = 0; u < CHN; ++u) wr[c][u] = wp[u * 64];
+    for (int u = 0; u < CHN; ++u) wr[buf][u] = wp[u * 64];
   };
   float* myrow = x.sD + kg * x.SUB + jc * ROWF;
-  // requests that do not depend on the CSR slice first: the dagg_L rows of the own slots, the first weight chunks
+  // ---- requests in the order of their urgency: CSR slice, the dagg_L / dh_L rows of the own slots
+  FzCsrEarly csr;
+  csr_issue(csr, a.row_ptr, a.col_idx, r_begin, nrows, x.g0, a.edges_cap, a.n_edges);
   f32x4 dg[NSA][FB];                     // dagg rows of the own slots on their way into the LDS tile
+  f32x4 dhk[NSA][FB];                    // dh rows of the own slots: produced and consumed by this wave, never leave it
 #pragma unroll
   for (int i = 0; i < NS; ++i)
 #pragma unroll
-    for (int nt = 0; nt < FB; ++nt) dg[i][nt] = ldnt4(a.gha + rowi[i] * (2 * F) + F + nt * 16 + 4 * kg);
-  if (RING && L >= 1) {
-#pragma unroll
-    for (int c = 0; c + 1 < NCH; ++c) wload(c, item_base(L, 0));
+    for (int nt = 0; nt < FB; ++nt) {
+      dg[i][nt] = ldg4(a.gha + rowi[i] * (2 * F) + F + nt * 16 + 4 * kg);
+      dhk[i][nt] = ldg4(a.gha + rowi[i] * (2 * F) + nt * 16 + 4 * kg);
+    }
+  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
+  if (nedges > a.edges_cap || nedges < 0) {
+    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
+    return;
   }
-  stage_csr(a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
   for (int i = threadIdx.x; i < FZ_TG * N; i += FZ_THREADS) x.sM[i] = 0u;
+  csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
 #pragma unroll
   for (int i = 0; i < NS; ++i)
 #pragma unroll
@@ -450,56 +481,71 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
     const float* hp = hptr(s);
     float* dp = dptr(s);
     const bool gate = s < L;
+    // the first two weight chunks of this stage land while the gathers run
+    if (RING && s > 0) { wload(0, 0, item_base(s, 0)); wload(1, 1, item_base(s, 0)); }
     f32x4 dpre[NSA][FB];
-    // (1) transposed gathers (ascending destinations: k_agg_small<true> order), + dh, ReLU' gate
+    // (1) transposed gathers (ascending destinations, two per iteration: k_agg_small<true> order), + dh, ReLU' gate; the h_s
+    //     row of slot i+1 is requested before slot i is gathered
+    f32x4 hm[2][FB];
+    auto request = [&](int i) {
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) hm[i & 1][nt] = ldg4(hp + rowi[i] * F + nt * 16 + 4 * kg);
+    };
+    if (NS > 0 && gate) request(0);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      f32x4 dh[FB], hm[FB];
+      if (i + 1 < NS && gate) request(i + 1);
+      f32x4 acc[FB];
 #pragma unroll
-      for (int nt = 0; nt < FB; ++nt) {
-        dh[nt] = ldnt4(a.gha + rowi[i] * (2 * F) + nt * 16 + 4 * kg);
-        hm[nt] = ldg4(hp + rowi[i] * F + nt * 16 + 4 * kg);
-      }
-#pragma unroll
-      for (int kb = 0; kb < FB; ++kb) dpre[i][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kb = 0; kb < FB; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       unsigned bits = x.sM[jc * N + wv + FZ_WAVES * i];
       while (bits) {
-        const int q = __builtin_ctz(bits);
+        const int q0 = __builtin_ctz(bits);
         bits &= bits - 1;
-        const float* b0 = myrow + q * (FZ_TG * ROWF);
+        const bool two = bits != 0;
+        const int q1 = two ? __builtin_ctz(bits) : q0;
+        bits &= bits - 1;                                        // (0 & anything stays 0)
+        const float m1 = two ? 1.f : 0.f;
+        const float* b0 = myrow + q0 * (FZ_TG * ROWF);
+        const float* b1 = myrow + q1 * (FZ_TG * ROWF);
+        f32x4 v0[FB], v1[FB];
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) dpre[i][kb] += ld4(b0 + kb * 4);
+        for (int kb = 0; kb < FB; ++kb) { v0[kb] = ld4(b0 + kb * 4); v1[kb] = ld4(b1 + kb * 4); }
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) { acc[kb] += v0[kb]; acc[kb] += v1[kb] * m1; }
       }
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) {
-        dpre[i][kb] += dh[kb];
-        if (gate) dpre[i][kb] = gate4(dpre[i][kb], hm[kb]);
-        stg4(dp + rowi[i] * F + kb * 16 + 4 * kg, dpre[i][kb]);
+        acc[kb] += dhk[i][kb];
+        if (gate) acc[kb] = gate4(acc[kb], hm[i & 1][kb]);
+        stg4(dp + rowi[i] * F + kb * 16 + 4 * kg, acc[kb]);
+        dpre[i][kb] = acc[kb];
       }
     }
     ts.mark();                                                   // stage: gathers done
     if (s == 0) break;
-    // (2) data gradients of the own slots
+    // (2) data gradients of the own slots: chunk sequence number n = i * NCH + c lives in ring buffer n % 3 and is
+    //     requested two chunks ahead (inside this stage only)
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      const float* cur = item_base(s, i);
-      const float* nxt = i + 1 < NS ? item_base(s, i + 1) : item_base(s - 1, 0);
       f32x4 o[2 * FB];
 #pragma unroll
       for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (!RING) wload(0, cur);
+      if (!RING) wload(0, 0, item_base(s, i));
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (RING) wload((c + NCH - 1) % NCH, c == 0 ? cur : nxt);    // the buffer consumed one chunk ago: NCH-1 chunks ahead
+        const int n = i * NCH + c, nn = n + 2;
+        const bool pf = RING && nn < NS * NCH;
+        if (pf) wload(nn % 3, nn % NCH, item_base(s, nn / NCH));
 #pragma unroll
         for (int q = 0; q < CKB; ++q) {
           const int kb = c * CKB + q;
 #pragma unroll
           for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = V2X_MFMA(wr[c][q * 2 * FB + nt][s4], dpre[i][kb][s4], o[nt]);
+            for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = V2X_MFMA(wr[RING ? n % 3 : 0][q * 2 * FB + nt][s4], dpre[i][kb][s4], o[nt]);
         }
-        if (RING) {
+        if (pf) {
 #pragma unroll
           for (int u = 0; u < CHN; ++u) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
         }
@@ -507,12 +553,12 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
       }
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) {
-        stg4(a.gha + rowi[i] * (2 * F) + nt * 16 + 4 * kg, o[nt]);           // dh_{s-1}: read back by this wave next stage
-        dg[i][nt] = o[FB + nt];                                              // dagg_{s-1}: into the LDS tile after the barrier
+        dhk[i][nt] = o[nt];                                      // dh_{s-1}
+        dg[i][nt] = o[FB + nt];                                  // dagg_{s-1}: into the LDS tile after the barrier
       }
       ts.mark();                                                 // slot done
     }
-    __syncthreads();                       // all gathers from dagg_s done; own dh rows have left the CU
+    __syncthreads();                       // all gathers from the dagg_s tile are done
     ts.mark();
 #pragma unroll
     for (int i = 0; i < NS; ++i)
@@ -542,13 +588,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
   const int ng = min(FZ_TG, a.n_graphs - x.g0);
   x.jc = min(x.lane & 15, ng - 1);
   const int r_begin = x.g0 * a.N, nrows = ng * a.N;
-  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
-  if (nedges > a.edges_cap || nedges < 0) {
-    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
-    return;
-  }
-  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_bwd_body<F, SPW, TS>(a, x, e_begin, nedges, nrows, r_begin);
-  else fused_bwd_body<F, SPW - 1, TS>(a, x, e_begin, nedges, nrows, r_begin);
+  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_bwd_body<F, SPW, TS>(a, x, nrows, r_begin);
+  else fused_bwd_body<F, SPW - 1, TS>(a, x, nrows, r_begin);
 }
 
 }  // namespace v2x

@@ -1074,7 +1074,7 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   memset(&a, 0, sizeof(a));
   a.xe = d.xe; a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_fwd;
   for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.a[s] = m->a[s]; }
-  a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.err = m->flag_dev;
+  a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   const size_t lds = fused_lds(m, d, false);
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
@@ -1096,7 +1096,7 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   memset(&a, 0, sizeof(a));
   a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_bwd; a.gha = m->gha;
   for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.dpre[s] = m->dpre[s]; }
-  a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.err = m->flag_dev;
+  a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   const size_t lds = fused_lds(m, d, true);
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;

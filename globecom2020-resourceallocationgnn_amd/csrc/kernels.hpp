@@ -1165,15 +1165,30 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   // (DEPTH 3 where the operand buffers fit the 256 architectural VGPRs next to the accumulators; DEPTH 2 otherwise)
   Block b0, b1;
 #define V2X_SB __builtin_amdgcn_sched_barrier(0)
+  // A wave issues in order: a block's loads issued as one burst in front of the MFMAs keep the matrix pipe idle while the
+  // texture unit takes them (tools/l2stream.hip, tools/overlapbench.hip).  The loads of the NEXT block are therefore
+  // spread between the MFMAs of the current one, one per PER MFMAs.
+  constexpr int NLD = 4 * ((K0 > 0 ? WgOperand<K0>::G + WgOperand<K0>::R : 0) + (K1L > 0 ? WgOperand<K1L>::G + WgOperand<K1L>::R : 0) +
+                           (K2 > 0 ? WgOperand<K2>::G + WgOperand<K2>::R : 0) + WgOperand<NW>::G + WgOperand<NW>::R);
+  constexpr int NMF = 4 * (KT - (ZERO1 ? T1 : 0)) * NT;
+  constexpr int PER = NMF / NLD > 0 ? NMF / NLD : 1;
+#define V2X_ILV                                                                                        \
+  {                                                                                                    \
+    _Pragma("unroll") for (int u_ = 0; u_ < NLD; ++u_) {                                               \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);                                             \
+    }                                                                                                  \
+  }                                                                                                    \
+  V2X_SB
   int k = 0;
   if constexpr (DEPTH == 2) {
     if (nb > 0) load_full(wv, b0);
 #pragma unroll 1
     for (; k + 2 < nb; k += 2) {
-      load_full(wv + 4 * (k + 1), b1); V2X_SB;
-      mfma_block(b0); V2X_SB;
-      load_full(wv + 4 * (k + 2), b0); V2X_SB;
-      mfma_block(b1); V2X_SB;
+      load_full(wv + 4 * (k + 1), b1);
+      mfma_block(b0); V2X_ILV;
+      load_full(wv + 4 * (k + 2), b0);
+      mfma_block(b1); V2X_ILV;
     }
     if (nb - k == 2) {                                             // peeled tail: 2 or 1 blocks left
       load_full(wv + 4 * (k + 1), b1); V2X_SB;
@@ -1193,12 +1208,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     V2X_SB;
 #pragma unroll 1
     for (; k + 4 < nb; k += 3) {             // invariant: b0 = block k, b1 = block k+1 (loaded or in flight)
-      load_full(wv + 4 * (k + 2), b2); V2X_SB;
-      mfma_block(b0); V2X_SB;
-      load_full(wv + 4 * (k + 3), b0); V2X_SB;
-      mfma_block(b1); V2X_SB;
-      load_full(wv + 4 * (k + 4), b1); V2X_SB;
-      mfma_block(b2); V2X_SB;
+      load_full(wv + 4 * (k + 2), b2);
+      mfma_block(b0); V2X_ILV;
+      load_full(wv + 4 * (k + 3), b0);
+      mfma_block(b1); V2X_ILV;
+      load_full(wv + 4 * (k + 4), b1);
+      mfma_block(b2); V2X_ILV;
     }
     const int rem = nb - k;                  // 2, 3 or 4 blocks left
     if (rem == 2) {
@@ -1218,6 +1233,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
       mfma_block(b0);
     }
   }
+#undef V2X_ILV
 #undef V2X_SB
   if (n_full * WG_TR < n_rows_here && wv == (n_full & 3)) {      // partial last block of the chunk
 #pragma unroll
@@ -1339,7 +1355,58 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
 // =====================================================================================
 // slab reduction + Keras Adam
 // =====================================================================================
+// Fragment-major copy of the GNN-layer weights for the graph-major fused kernels (kernels_fused.hpp, FzPack /
+// k_pack_weights): the Adam kernel writes every updated parameter to its place in that copy as well, so that no
+// re-packing launch is needed between two training steps.
+struct AdamPack { float* fwd; float* bwd; int F, S, L, xr; };
+
+// e = offset of a float4 of parameters in the flat buffer (GNN layers come first: stage-major, slot-minor)
+__device__ __forceinline__ void pack_scatter(const AdamPack& k, int64_t e, float4 p) {
+  const int F = k.F, FB = F >> 4, xr = k.xr;
+  const int st0 = (xr + F) * F + F, st1 = (2 * F + xr) * F + F;          // floats per slot: stage 0, stages >= 1
+  const int64_t size0 = (int64_t)k.S * st0;
+  int stage, slot, within;
+  if (e < size0) {
+    stage = 0; slot = (int)(e / st0); within = (int)(e - (int64_t)slot * st0);
+  } else {
+    const int64_t t = e - size0, per = (int64_t)k.S * st1;
+    stage = 1 + (int)(t / per);
+    if (stage > k.L) return;                                             // Dense layers: not packed
+    const int64_t r = t - (int64_t)(stage - 1) * per;
+    slot = (int)(r / st1); within = (int)(r - (int64_t)slot * st1);
+  }
+  const int k_real = stage ? 2 * F + xr : xr + F, kbs = stage ? 2 * FB + 1 : 1;
+  const int fwd_sz = kbs * FB * 256 + F;
+  float* df = k.fwd + (stage ? (int64_t)k.S * (FB * 256 + F) + ((int64_t)(stage - 1) * k.S + slot) * fwd_sz : (int64_t)slot * fwd_sz);
+  const int rr = within / F, col = within - rr * F;
+  if (rr >= k_real) {                                                    // the bias row
+    *reinterpret_cast<float4*>(df + kbs * FB * 256 + col) = p;
+    return;
+  }
+  const int pad_at = stage ? F + xr : xr;
+  const int kp = rr < pad_at ? rr : rr + (XE - xr);                      // row of the padded K axis
+  if (stage || kp < 16) {                                                // (stage 0: only the xe block is used)
+    const int kb = kp >> 4, kgp = (kp & 15) >> 2, s4 = kp & 3;
+    const float pv[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int n = col + t;
+      df[(((kb * FB + (n >> 4)) * 64) + (n & 15) + 16 * kgp) * 4 + s4] = pv[t];
+    }
+  }
+  if (stage) {
+    int ntb = -1;
+    if (kp < F) ntb = kp >> 4;
+    else if (kp >= F + XE) ntb = FB + ((kp - F - XE) >> 4);
+    if (ntb >= 0) {
+      float* db = k.bwd + ((int64_t)(stage - 1) * k.S + slot) * (FB * 2 * FB * 256);
+      *reinterpret_cast<float4*>(db + ((((col >> 4) * 2 * FB + ntb) * 64) + (kp & 15) + 16 * ((col & 15) >> 2)) * 4) = p;
+    }
+  }
+}
+
 struct AdamArgs {
+  AdamPack pack;                                         // pack.fwd == null: no fragment-major copy
   float* param; float* grad; float* mom; float* vel;
   const float* slab; int64_t slab_stride; int n_slabs;   // grad = sum of slabs (if slab != null)
   int n_layers; int64_t layer_end4[16]; int layer_slabs[16];   // slabs written per layer (float4 offsets)
@@ -1441,6 +1508,7 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
       reinterpret_cast<float4*>(a.mom)[i] = m;
       reinterpret_cast<float4*>(a.vel)[i] = v;
       reinterpret_cast<float4*>(a.param)[i] = p;
+      if (a.pack.fwd) pack_scatter(a.pack, 4 * i, p);
     }
   }
 }

@@ -68,6 +68,8 @@ struct v2x_model {
   DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
   DevBuf adj_mask;              // adjacency bit masks of the current batch (dense-graph aggregation)
   long long* ts_buf = nullptr;                  // V2X_FUSED_TS=1: phase time stamps of the fused forward (measurement)
+  bool raw_params = false;                      // v2x_param_ptr was called: re-pack before every fused forward
+  bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
   float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
   int* flag_host = nullptr;     // pinned, device-mapped word the kernels raise on a contract violation (tile guards,
   int* flag_dev = nullptr;      // k_validate_batch); read by the host after any synchronising call
@@ -997,6 +999,7 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
     const double t = (double)m->iterations;
     a.lr_t = (float)(m->cfg.lr * std::sqrt(1.0 - std::pow((double)m->cfg.beta2, t)) / (1.0 - std::pow((double)m->cfg.beta1, t)));
     a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
+    if (m->pk_fwd) { a.pack.fwd = m->pk_fwd; a.pack.bwd = m->pk_bwd; a.pack.F = m->F; a.pack.S = m->S; a.pack.L = m->L; a.pack.xr = m->Dn + m->De; }
   }
   int max_slabs_used = 0;
   for (int l = 0; l < a.n_layers; ++l) max_slabs_used = std::max(max_slabs_used, a.layer_slabs[l]);
@@ -1069,7 +1072,9 @@ int launch_pack(v2x_model* m, hipStream_t st) {
   } while (0)
 
 int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
-  CHK(launch_pack(m, st));          // the parameters may have changed since the last call (Adam, set/copy_weights)
+  // The copy follows the parameters by itself: Adam writes both (k_reduce_adam / pack_scatter), set / copy_weights
+  // re-pack eagerly.  Only a caller that took the raw parameter pointer (v2x_param_ptr) forces a re-pack per forward.
+  if (m->pk_stale) { CHK(launch_pack(m, st)); m->pk_stale = m->raw_params; }
   FusedFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.xe = d.xe; a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_fwd;
@@ -1368,6 +1373,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     const size_t fwd0 = (size_t)FB * 256 + m->F, fwd = (size_t)KB * FB * 256 + m->F, bwd = (size_t)FB * 2 * FB * 256;
     if (dev_alloc(m, &m->pk_fwd, (size_t)m->S * fwd0 + (size_t)m->L * m->S * fwd) || dev_alloc(m, &m->pk_bwd, (size_t)m->L * m->S * bwd))
       return fail("allocation");
+    m->pk_stale = true;             // first forward packs whatever the parameters are by then
   }
   if (m->pk_fwd && env_int("V2X_FUSED_TS", 0)) {
     if (dev_alloc(m, &m->ts_buf, 2 * 8 * 64)) return fail("allocation");
@@ -1410,7 +1416,10 @@ void v2x_destroy(v2x_model* m) {
 }
 
 int64_t v2x_param_count(const v2x_model* m) { return m ? m->P : 0; }
-float* v2x_param_ptr(v2x_model* m) { return m ? m->params : nullptr; }
+float* v2x_param_ptr(v2x_model* m) {
+  if (m) m->pk_stale = m->raw_params = true;   // the caller may write the parameters behind the library's back from now on
+  return m ? m->params : nullptr;
+}
 float* v2x_grad_ptr(v2x_model* m) { return m ? m->grads : nullptr; }
 
 int v2x_get_weights(v2x_model* m, float* host_out, void* stream) {
@@ -1425,6 +1434,7 @@ int v2x_set_weights(v2x_model* m, const float* host_in, void* stream) {
   if (!m || !host_in) FAIL(m, V2X_EINVAL, "set_weights: null argument");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(m, hipMemcpyAsync(m->params, host_in, (size_t)m->P * 4, hipMemcpyHostToDevice, st));
+  if (m->pk_fwd) CHK(launch_pack(m, st));
   HIPCHK(m, hipStreamSynchronize(st));
   return V2X_OK;
 }
@@ -1434,6 +1444,7 @@ int v2x_copy_weights(v2x_model* dst, const v2x_model* src, void* stream) {
   if (dst->P != src->P || dst->F != src->F || dst->N != src->N || dst->S != src->S || dst->L != src->L)
     FAIL(dst, V2X_EINVAL, "copy_weights: models have different shapes");
   HIPCHK(dst, hipMemcpyAsync(dst->params, src->params, (size_t)dst->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (dst->pk_fwd) CHK(launch_pack(dst, (hipStream_t)stream));
   return V2X_OK;
 }
 

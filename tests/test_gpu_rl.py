@@ -159,7 +159,8 @@ def test_device_replay_ring_and_gather():
     qn = torch.from_numpy(rng.normal(size=(50 * n, 4)).astype(np.float32)).cuda()
     y = rep.dqn_targets(q, qn, action, reward, 0.37).cpu().numpy()
     ref = q.cpu().numpy().copy()
-    tgt = (reward.cpu().numpy()[:, None] + 0.37 * qn.cpu().numpy().reshape(50, n, 4).max(axis=2)).astype(np.float32)
+    # r + GAMMA * max q' in float64, rounded once (the reference's numpy-1.x scalar semantics, BS_brain.py:690)
+    tgt = (reward.cpu().numpy()[:, None] + 0.37 * qn.cpu().numpy().reshape(50, n, 4).max(axis=2).astype(np.float64)).astype(np.float32)
     ref.reshape(50, n, 4)[np.arange(50)[:, None], np.arange(n)[None, :], action.cpu().numpy()] = tgt
     assert np.array_equal(y, ref)
 

@@ -176,3 +176,45 @@ def test_captured_agent_payload_contract():
         assert a[key].dtype == np.float64
         assert np.array_equal(a[key], a['replay_s/' + key[len('fit_x/'):]])
     assert 0 < gamma < 1
+
+
+@pytest.mark.parametrize("N,F,L,with_nbr", [(4, 16, 2, False), (4, 16, 2, True), (6, 32, 3, False)])
+def test_literal_formulation_fit_step_equals_the_compact_one(N, F, L, with_nbr):
+    """The reference's own formulation (per-node weights, dict inputs, dense kron(Adj, I_F) contracted with batch_dot:
+    BS_brain.py:44-76,117-208) and the compact node-row / CSR formulation are the same function: outputs, losses,
+    every gradient and the weights after two Keras-Adam steps agree to rounding.  (The literal fit step is what the
+    bench times as CPU legs C0 / C1.)"""
+    from oracle import literal as ol
+    from oracle.keras_semantics import KerasAdam
+    spec = OSpec(n_nodes=N, feat_dim=F, n_mp_layers=L)
+    rng = np.random.default_rng(N + F)
+    P = oc.init_params(spec, rng, random_bias=True)
+    B = 5
+    x, e = rng.normal(size=(B, N, 9)), rng.normal(size=(B, N, 4))
+    adj = (rng.uniform(size=(B, N, N)) < 0.6).astype(np.float64)
+    nbr = rng.normal(size=(B, N, F)) if with_nbr else None
+    feed = ol.feed_from_compact(spec, x, e, adj, nbr)
+    graph = oc.adj_to_csr(adj)
+    M = oc.csr_to_matrix(*graph, dtype=np.float64)
+    flat = lambda a: None if a is None else a.reshape(B * N, -1)
+    q, cache = oc.forward(spec, P, flat(x), flat(e), M, flat(nbr))
+    ql, lcache = ol.forward_literal_cached(spec, P, feed)
+    assert np.abs(np.stack(ql, 1).reshape(B * N, -1) - q).max() < 1e-11
+    assert all(np.abs(a - b).max() < 1e-12 for a, b in zip(ql, ol.forward_literal(spec, P, feed)))
+    y = q + rng.normal(0, 1.5, size=q.shape)
+    loss, dq = oc.huber_loss_and_grad(spec, q, y)
+    G = oc.backward(spec, P, cache, dq)
+    yl = [y.reshape(B, N, -1)[:, k] for k in range(N)]
+    Gl = ol.backward_literal(spec, P, lcache, [dq.reshape(B, N, -1)[:, k] for k in range(N)])
+    for a, b in zip(oc.param_arrays(G), oc.param_arrays(Gl)):
+        assert np.abs(a - b).max() < 1e-11
+    # two optimizer steps
+    Pc, Pl = oc.cast_params(P, np.float64), oc.cast_params(P, np.float64)
+    om = oc.OracleModel(spec, Pc, dtype=np.float64)
+    opt = KerasAdam()
+    for _ in range(2):
+        lc = om.train_step(flat(x), flat(e), graph, y, flat(nbr))
+        ll = ol.train_step_literal(spec, Pl, opt, feed, yl)
+        assert np.abs(lc - ll).max() < 1e-12
+    for a, b in zip(oc.param_arrays(om.params), oc.param_arrays(Pl)):
+        assert np.abs(a - b).max() < 1e-10

@@ -215,12 +215,14 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
             legs["%s_%s" % (name, label)] = {"graphs_per_s": round(b / sec, 1), "ms_per_step": round(1e3 * sec, 2), "steps": n,
                                              "batch": b, "threads": int(nthr),
                                              "what": what if b == (B if name == "C2" else b) else what + " (timed on a %d-graph sample)" % b}
-    main_leg = legs["C2_all_cores"]
-    return {"value": main_leg["graphs_per_s"], "unit": "graph-instances/s", "cores": int(all_thr), "kind": "port",
+    # the headline CPU number is the better of the two thread settings of C2 (on a 128-thread host the per-slot
+    # matrix products are too small for the BLAS thread pool: one thread wins); `cores` = the threads of that run
+    main_leg = max(legs["C2_all_cores"], legs["C2_one_thread"], key=lambda l: l["graphs_per_s"])
+    return {"value": main_leg["graphs_per_s"], "unit": "graph-instances/s", "cores": int(main_leg["threads"]), "kind": "port",
             "cpu_model": cpu_model(), "host_cores": len(os.sched_getaffinity(0)),
             "sample": "median of %d fit steps of B=%d (N=%d,F=%d,L=%d,%s weights) after 1 warm-up, numpy fp32 CSR oracle "
-                      "(leg C2, all cores); a CPU restatement of the reference math, not Keras/TF1"
-                      % (main_leg["steps"], B, N, F, L, "shared" if share else "per-node"),
+                      "(leg C2, %d thread(s)); a CPU restatement of the reference math, not Keras/TF1"
+                      % (main_leg["steps"], main_leg["batch"], N, F, L, "shared" if share else "per-node", main_leg["threads"]),
             "legs": legs}
 
 

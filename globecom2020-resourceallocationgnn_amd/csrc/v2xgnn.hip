@@ -39,7 +39,7 @@ struct DevBuf {
 struct ProfRec { int id; hipEvent_t ev0, ev1; };
 
 struct GraphKey {
-  int kind; const void* ptrs[8]; int sizes[6];
+  int kind; const void* ptrs[12]; int sizes[6]; double scalar;
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -1434,7 +1434,7 @@ int v2x_set_weights(v2x_model* m, const float* host_in, void* stream) {
   if (!m || !host_in) FAIL(m, V2X_EINVAL, "set_weights: null argument");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(m, hipMemcpyAsync(m->params, host_in, (size_t)m->P * 4, hipMemcpyHostToDevice, st));
-  if (m->pk_fwd) CHK(launch_pack(m, st));
+  if (m->pk_fwd) { CHK(launch_pack(m, st)); m->pk_stale = m->raw_params; }
   HIPCHK(m, hipStreamSynchronize(st));
   return V2X_OK;
 }
@@ -1444,7 +1444,7 @@ int v2x_copy_weights(v2x_model* dst, const v2x_model* src, void* stream) {
   if (dst->P != src->P || dst->F != src->F || dst->N != src->N || dst->S != src->S || dst->L != src->L)
     FAIL(dst, V2X_EINVAL, "copy_weights: models have different shapes");
   HIPCHK(dst, hipMemcpyAsync(dst->params, src->params, (size_t)dst->P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  if (dst->pk_fwd) CHK(launch_pack(dst, (hipStream_t)stream));
+  if (dst->pk_fwd) { CHK(launch_pack(dst, (hipStream_t)stream)); dst->pk_stale = dst->raw_params; }
   return V2X_OK;
 }
 
@@ -1548,11 +1548,23 @@ int v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, const
   CHK(ensure(online, online->st_y, (size_t)ds.R * online->C * sizeof(float)));
   float* y = y_out ? y_out : (float*)online->st_y.p;
   const Range all{0, ds.B};
-  if (int rc = run_forward(target, st, dn, all, true)) { online->err = target->err; return rc; }
-  CHK(run_forward(online, st, ds, all, true));
-  hipLaunchKernelGGL(k_dqn_targets, dim3((ds.R + 255) / 256), dim3(256), 0, st, online->q, target->q, action, reward, gamma,
-                     ds.R, online->N, online->C, y);
-  CHK(run_backward(online, st, st, ds, all, y, n_graphs_global));
+  // Everything up to the slab reduction is one replayable hipGraph (the Adam launch stays outside: lr_t changes per
+  // step).  The key holds every pointer the launches bake in -- both batches, action / reward / target buffers and the
+  // TARGET model's workspace, whose re-allocation must not leave a stale graph in the online model's cache.
+  GraphKey key = make_key(4, ds, y, n_graphs_global);
+  key.ptrs[6] = dn.xe; key.ptrs[7] = dn.rp; key.ptrs[8] = dn.ci; key.ptrs[9] = action; key.ptrs[10] = reward;
+  key.ptrs[11] = target->q;
+  key.scalar = gamma;
+  CHK(run_maybe_graph(online, st, key, [&]() -> int {
+    target->capturing = online->capturing;
+    int rc = run_forward(target, st, dn, all, true);
+    target->capturing = false;
+    if (rc) { online->err = target->err; return rc; }
+    CHK(run_forward(online, st, ds, all, true));
+    hipLaunchKernelGGL(k_dqn_targets, dim3((ds.R + 255) / 256), dim3(256), 0, st, online->q, target->q, action, reward, gamma,
+                       ds.R, online->N, online->C, y);
+    return run_backward(online, st, st, ds, all, y, n_graphs_global);
+  }));
   CHK(launch_reduce_adam(online, st, 1, true, nullptr, loss_job(online, ds, n_graphs_global)));
   online->have_fwd = target->have_fwd = true;
   return emit_loss(online, loss_out, loss_on_device, st);

@@ -323,6 +323,23 @@ class Agent(object):
         d2d_state, adj = self.observe()
         return self._feed(d2d_state[None], adj[None])
 
+    def _joint_actions(self):
+        """All C^N joint channel assignments, link 0 most significant (the digit extraction of BS_brain.py:1071-1078,
+        which hard-codes 4^4; here any N with C^N <= 65536)."""
+        n, C = self.num_D2D, self.num_CH
+        if C ** n > 65536:
+            raise ValueError("brute-force search over %d^%d joint actions is not feasible" % (C, n))
+        import itertools
+        return np.array(list(itertools.product(range(C), repeat=n)), int)
+
+    def _brute_force(self, joint):
+        """-> (index, reward, (V2V rates, V2I rates, interference)) of the best joint action for the CURRENT simulator
+        state; np.argmax keeps the first maximiser like the reference (:1093, :1371)."""
+        res = [self.dump_act(a.reshape(self.num_D2D, 1)) for a in joint]
+        rewards = np.array([self.v2v_weight * np.sum(r[0]) + self.v2i_weight * np.sum(r[1]) for r in res])
+        best = int(np.argmax(rewards))
+        return best, float(rewards[best]), res[best]
+
     def test_run(self, num_episodes, num_test_step, opt_flag=False):
         """Evaluation loop (BS_brain.py:986-1162): greedy policy of the trained network vs the random-action baseline
         and, with opt_flag, the brute-force optimum over all C^N joint actions (the reference hard-codes 4^4,
@@ -345,22 +362,87 @@ class Agent(object):
 
         rl, ra, opt = book(), book(), book()
         if opt_flag:
-            if C ** n > 65536:
-                raise ValueError("brute-force search over %d^%d joint actions is not feasible" % (C, n))
-            import itertools
-            joint = np.array(list(itertools.product(range(C), repeat=n)), int)          # link 0 most significant (:1071-1078)
+            joint = self._joint_actions()
         for ep in range(num_episodes):
             self.env.new_random_game(self.num_D2D)
             for st in range(num_test_step):
                 record(ra, ep, st, *self.dump_act(self.select_action_random(None)))
                 if opt_flag:
-                    res = [self.dump_act(a.reshape(n, 1)) for a in joint]
-                    rewards = np.array([w_v2v * np.sum(r[0]) + w_v2i * np.sum(r[1]) for r in res])
-                    best = int(np.argmax(rewards))
-                    if rewards[best] > 0:                                                 # at least one feasible solution
-                        record(opt, ep, st, *res[best])
+                    best, reward, res = self._brute_force(joint)
+                    if reward > 0:                                                        # at least one feasible solution
+                        record(opt, ep, st, *res)
                 d2d_state, adj = self.observe()
                 q = self._predict(d2d_state[None], adj[None])[:, 0, :]
                 action = np.argmax(q, axis=1).reshape(n, self.num_Neighbor).astype(int)
                 record(rl, ep, st, *self.act(action))
         return tuple(rl + ra + opt) if opt_flag else tuple(rl + ra)
+
+    def checkpoint_dir(self, root=None):
+        """Folder the training driver saves into and the evaluation loads from (BS_brain.py:1231-1236; the reference
+        joins with '\\' and only works on Windows)."""
+        name = 'Train-Result-RealFB-%s-Batch-%s-Gamma-%s-V2Iweight-%s' % (self.num_Feedback, self.batch_size, self.gamma, self.v2i_weight)
+        return os.path.join(root if root is not None else os.getcwd(), name)
+
+    def evaluate_training_diff_trials(self, num_episodes, num_test_step, opt_flag, fixed_epsilon, num_evaluate_trials,
+                                      model_dir=None, num_train_steps=20, load=True):
+        """Evaluation of the TRAINING PROCESS (BS_brain.py:1164-1451): for every saved checkpoint (one per 5 training
+        episodes, :1218,:1228) and every trial, an episode under a FIXED epsilon-greedy policy (:1376-1397) next to the
+        random-action baseline (:1330-1338) and -- per step of the first checkpoint -- the brute-force optimum (:1282-
+        1328); with opt_flag also the optimum of every step (:1340-1374).  Trial t re-seeds the Python / numpy RNGs with
+        t + 1 before every episode (:1262-1265).  Same return tuples as the reference: 9 arrays with opt_flag, 5 without.
+        model_dir: checkpoint folder (default: checkpoint_dir()); load=False evaluates the weights already in the brain
+        for every checkpoint (tests with a recording brain)."""
+        import random
+        n, C, nn = self.num_D2D, self.num_CH, self.num_Neighbor
+        self.num_Episodes = int(num_episodes // 5)
+        self.num_Test_Step = num_test_step
+        n_ep, n_st, n_tr = self.num_Episodes, num_test_step, num_evaluate_trials
+        w_v2v, w_v2i = self.v2v_weight, self.v2i_weight
+        folder = model_dir if model_dir is not None else self.checkpoint_dir()
+        ev_opt_return, ev_opt_reward = np.zeros(n_tr), np.zeros((n_tr, n_st))
+        ra_return, ra_reward = np.zeros((n_tr, n_ep)), np.zeros((n_tr, n_ep, n_st))
+        if opt_flag:
+            opt_return, opt_reward = np.zeros((n_tr, n_ep)), np.zeros((n_tr, n_ep, n_st))
+            opt_v2v, opt_v2i, opt_intf = np.zeros((n_tr, n_ep, n_st, n)), np.zeros((n_tr, n_ep, n_st, C)), np.zeros((n_tr, n_ep, n_st, C))
+        ret, rew = np.zeros((n_tr, n_ep)), np.zeros((n_tr, n_ep, n_st))
+        joint = self._joint_actions()
+        for trial in range(n_tr):
+            for ep in range(n_ep):
+                if load:
+                    tag = '-Episode-%d-Step-%d-Batch-%d.h5' % ((ep + 1) * 5, num_train_steps, self.batch_size)
+                    self.brain.model.load_weights(os.path.join(folder, 'Q-Network_model_weights' + tag))
+                    self.brain.target_model.load_weights(os.path.join(folder, 'Target-Network_model_weights' + tag))
+                random.seed(trial + 1)
+                np.random.seed(trial + 1)
+                self.env.new_random_game(self.num_D2D)
+                for st in range(n_st):
+                    if ep == 0:                                  # ground truth once per trial (:1282)
+                        _, reward, _ = self._brute_force(joint)
+                        if reward > 0:
+                            ev_opt_reward[trial, st] = reward
+                            ev_opt_return[trial] += reward
+                    v2v, v2i, _ = self.dump_act(self.select_action_random(None))
+                    ra_reward[trial, ep, st] = w_v2v * np.sum(v2v) + w_v2i * np.sum(v2i)
+                    ra_return[trial, ep] += ra_reward[trial, ep, st]
+                    if opt_flag:
+                        _, reward, (v2v, v2i, intf) = self._brute_force(joint)
+                        if reward > 0:
+                            opt_reward[trial, ep, st] = reward
+                            opt_return[trial, ep] += reward
+                            opt_v2v[trial, ep, st, :] = np.sum(v2v, axis=1)
+                            opt_v2i[trial, ep, st, :] = v2i
+                            opt_intf[trial, ep, st, :] = intf
+                    if np.random.random() < fixed_epsilon:
+                        action = np.zeros((n, 1), int)
+                        for k in range(n):
+                            action[k] = np.random.choice(range(0, C), nn)
+                    else:
+                        d2d_state, adj = self.observe()
+                        q = self._predict(d2d_state[None], adj[None])[:, 0, :]
+                        action = np.argmax(q, axis=1).reshape(n, nn).astype(int)
+                    v2v, v2i, _ = self.act(action)
+                    rew[trial, ep, st] = w_v2v * np.sum(v2v) + w_v2i * np.sum(v2i)
+                    ret[trial, ep] += rew[trial, ep, st]
+        if opt_flag:
+            return ret, rew, ra_return, ra_reward, opt_return, opt_reward, opt_v2v, opt_v2i, opt_intf
+        return ev_opt_return, ret, rew, ra_return, ra_reward

@@ -212,3 +212,48 @@ def test_cfg4_ragged_8_to_128_links_per_gpu_share():
     cost = [s.n_rows + s.n_edges for s, _ in shards]
     assert abs(cost[0] - cost[1]) <= 128 * 127                   # balanced by edges + nodes to within one largest graph
     _properties(spec, pb, y, pb.n_rows, lambda r: shards[r], lambda q, yy: np.array([_huber_mean(q, yy)]), "configs[4]")
+
+
+def test_dqn_step_hipgraph_replay_is_bitwise_eager():
+    """The one-call replay step captured as a hipGraph (stable gather buffers, as rl/replay.py provides them): new
+    contents in the same buffers, a target-network sync in between, three steps -- identical to eager launches."""
+    import torch
+    from util import random_inputs
+    N, F, B = 20, 64, 64
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(8)
+    w_on, w_tg = _weights(spec, rng), _weights(spec, rng)
+    data = []
+    for _ in range(3):
+        x, e, adj = random_inputs(rng, B, N)
+        x2, e2, _ = random_inputs(rng, B, N)
+        data.append((PackedBatch.from_dense(x, e, adj), PackedBatch.from_dense(x2, e2, adj),
+                     rng.integers(0, 4, size=(B, N)).astype(np.int32), rng.normal(2.4, 0.3, size=B)))
+    res = []
+    for use_graph in (False, True):
+        online, target = GnnEngine(spec, use_graph=use_graph), GnnEngine(spec, use_graph=use_graph)
+        online.set_weights(w_on)
+        target.set_weights(w_tg)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            sb, sn = online.to_device(data[0][0]), online.to_device(data[0][1])
+            a_dev = torch.zeros((B, N), dtype=torch.int32, device="cuda")
+            r_dev = torch.zeros(B, dtype=torch.float64, device="cuda")
+            y = torch.empty((B * N, 4), dtype=torch.float32, device="cuda")
+            out = []
+            for step, (pb, pb2, a, r) in enumerate(data):
+                for dst, src in ((sb, pb), (sn, pb2)):                       # same device buffers, new contents
+                    dst.xe.copy_(torch.from_numpy(src.xe))
+                    dst.col_idx.copy_(torch.from_numpy(src.col_idx))
+                a_dev.copy_(torch.from_numpy(a))
+                r_dev.copy_(torch.from_numpy(r))
+                loss = online.dqn_step(target, sb, sn, a_dev, r_dev, 0.5, y_out=y)
+                out.append((loss.cpu().numpy(), y.cpu().numpy().copy()))
+                if step == 1:
+                    target.copy_weights_from(online)
+            torch.cuda.synchronize()
+        res.append((out, online.get_flat()))
+        online.close()
+        target.close()
+    for (l0, y0), (l1, y1) in zip(res[0][0], res[1][0]):
+        assert np.array_equal(l0, l1) and np.array_equal(y0, y1)
+    assert np.array_equal(res[0][1], res[1][1])

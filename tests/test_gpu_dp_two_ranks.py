@@ -133,7 +133,7 @@ def test_bench_two_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, V2X_BENCH_ONE_DEVICE="1", V2X_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29551", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--master-port", "29551", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--min-seconds", "0",
            "--batch", "512", "--no-cpu-baseline", "--no-roofline"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]

@@ -175,3 +175,33 @@ def test_observation_at_twenty_links_matches_reference_get_state():
         env.renew_positions()
         env.renew_channels_fastfading()
         env.Compute_Interference(a.copy())
+
+
+def test_evaluate_training_diff_trials_matches_reference_loop(tmp_path):
+    """Evaluation of the training process (BS_brain.py:1164-1451) against the reference's own run
+    (tests/golden/make_golden_evaltrials.py: reference Agent + simulator, recording fake brain whose load_weights
+    records file names): same checkpoints loaded in the same order, same re-seeding per trial, same returns."""
+    g = np.load(os.path.join(GOLDEN, 'golden_evaltrials_n4.npz'))
+    names_opt = ['Return', 'Reward', 'RA_Return', 'RA_Reward', 'Opt_Return', 'Opt_Reward', 'Opt_V2V', 'Opt_V2I', 'Opt_Interference']
+    names_ra = ['Evaluated_Opt_Return', 'Return', 'Reward', 'RA_Return', 'RA_Reward']
+    for opt_flag, names, tag in ((True, names_opt, 'opt/'), (False, names_ra, 'ra/')):
+        seed = int(g['seed'])
+        random.seed(seed)
+        np.random.seed(seed)
+        cfg = RL_Config()
+        cfg.set_train_value(16, 0.5, 32, 1, 0.1)
+        env = make_env()
+        brain = RecordingBrain(env.n_Veh, 3, 1, cfg.Num_Feedback, env.n_Neighbor, env.n_RB)
+        loads = []
+        brain.model = types.SimpleNamespace(load_weights=lambda p: loads.append(os.path.basename(p)))
+        brain.target_model = types.SimpleNamespace(load_weights=lambda p: loads.append(os.path.basename(p)))
+        agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, cfg.Num_Feedback, env, cfg, brain=brain)
+        out = agent.evaluate_training_diff_trials(int(g['episodes']), int(g['steps']), opt_flag, float(g['epsilon']),
+                                                  int(g['trials']), model_dir=str(tmp_path))
+        assert len(out) == len(names)
+        for o, name in zip(out, names):
+            assert o.shape == g[tag + name].shape, name
+            assert np.allclose(o, g[tag + name], rtol=1e-9, atol=1e-12), name
+        # the reference builds 'cwd\\folder\\name' (Windows separators): compare the file names
+        assert loads == [s.split('\\')[-1] for s in g[tag + 'loads']]
+    assert os.path.basename(agent.checkpoint_dir('/x')) == 'Train-Result-RealFB-16-Batch-32-Gamma-0.5-V2Iweight-0.1'

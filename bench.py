@@ -226,6 +226,75 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
             "legs": legs}
 
 
+def rl_episode(links, feat, batch, gamma, train_steps, seed, engine_factory=None, device=0, use_graph=False):
+    """One episode of the DQN loop (RL_Train_main.py:98-118 -> Agent.train, BS_brain.py:750-910) through the package's own
+    simulator / agent counterparts: train_steps x (50 rollout transitions + 1 replay of `batch`).  -> wall-clock split."""
+    import random
+    from v2xgnn.rl import Agent, RL_Config
+    from v2xgnn.rl.train import start_env
+    random.seed(seed)
+    np.random.seed(seed)
+    cfg = RL_Config()
+    cfg.set_train_value(feat, gamma, batch, 1, 0.1)
+    env = start_env(links)
+    kw = dict(seed=seed)
+    if engine_factory is not None:
+        from v2xgnn import BS
+        kw = dict(brain=BS(links, 3, 1, feat, env.n_Neighbor, env.n_RB, seed=seed, engine_factory=engine_factory), device_replay=False)
+    else:
+        kw.update(device=device, use_graph=use_graph)
+    agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, feat, env, cfg, **kw)
+    split = {"rollout_s": 0.0, "replay_s": 0.0}
+    roll, rep = agent.generate_d2d_transition, agent.replay
+
+    def timed(fn, key):
+        def inner(*a, **k):
+            t0 = time.perf_counter()
+            out = fn(*a, **k)
+            if engine_factory is None:
+                import torch
+                torch.cuda.synchronize()
+            split[key] += time.perf_counter() - t0
+            return out
+        return inner
+    agent.generate_d2d_transition, agent.replay = timed(roll, "rollout_s"), timed(rep, "replay_s")
+    t0 = time.perf_counter()
+    loss = agent.train(1, train_steps)[0]
+    wall = time.perf_counter() - t0
+    assert np.all(np.isfinite(loss))
+    return {"wall_s": round(wall, 4), "train_steps_per_s": round(train_steps / wall, 3),
+            "rollout_s": round(split["rollout_s"], 4), "replay_s": round(split["replay_s"], 4),
+            "env_steps": int(agent.num_step), "mean_loss": round(float(loss.mean()), 6)}
+
+
+def main_rl(args):
+    """--workload cfg0: BASELINE configs[0] (default Sim_Config: 4 links, 16 features, batch 256, gamma 0.2, one episode
+    of 20 train steps), on the engine and -- as cpu_baseline, kind "port" -- on the CPU oracle behind the same agent.
+    --workload cfg2loop: configs[2] on one GPU (20 links, 64 features, replay batch 4096, HBM-resident replay)."""
+    import torch
+    links, feat, batch, gamma = (4, 16, 256, 0.2) if args.workload == "cfg0" else (20, 64, 4096, 0.5)
+    steps = 20
+    ctx = torch.cuda.stream(torch.cuda.Stream())
+    with ctx:
+        rl_episode(links, feat, batch, gamma, 2, 7, use_graph=True)           # warm-up: allocations, graph capture paths
+        gpu = rl_episode(links, feat, batch, gamma, steps, 1001, use_graph=True)
+    cpu = None
+    if args.workload == "cfg0" and not args.no_cpu_baseline:
+        from oracle.engine import OracleEngine
+        r = rl_episode(links, feat, batch, gamma, steps, 1001, engine_factory=lambda spec: OracleEngine(spec, dtype=np.float32))
+        cpu = {"value": r["train_steps_per_s"], "unit": "train-steps/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+               "cpu_model": cpu_model(), "sample": "the same episode (seed 1001) with the numpy fp32 oracle as the Q-network", "detail": r}
+    print(json.dumps({"metric": "DQN train steps/s (50 simulator transitions + 1 replay of batch %d each), %d V2V links, feat_dim %d"
+                                % (batch, links, feat),
+                      "value": gpu["train_steps_per_s"], "unit": "train-steps/s", "n_gpus": 1, "steps": steps, "warmup": 2,
+                      "ms_per_step": round(1e3 * gpu["wall_s"] / steps, 3), "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded simulator)",
+                      "config": {"workload": "BASELINE.json configs[%d]: one episode = %d train steps x (50 rollouts + 1 replay), "
+                                             "%d links, feat_dim=%d, batch %d, gamma %g"
+                                             % (0 if args.workload == "cfg0" else 2, steps, links, feat, batch, gamma),
+                                 "split": gpu}, "roofline": None, "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,12 +314,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
-    ap.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5", "cfg0", "cfg2loop"], default="cfg2",
                     help="BASELINE.json configs[1] (default, the metric's configuration), [3] (100 links x 256 features x "
                          "3 layers, 8192/8 graphs per GPU) or [4] (8-128 links per graph, shared weights, 16384/8 per GPU)")
     ap.add_argument("--ragged", type=int, nargs=2, metavar=("LO", "HI"), default=None,
                     help="variable-size graphs with LO..HI links (needs --share-weights)")
     args = ap.parse_args()
+    if args.workload in ("cfg0", "cfg2loop"):
+        return main_rl(args)
     strong = args.scaling == "strong"
     if args.workload == "cfg4":           # BASELINE configs[3]: batch 8192 on 8 GPUs = 1024 per GPU
         args.nodes, args.feat, args.layers, args.batch = 100, 256, 3, (8192 if strong else 1024)

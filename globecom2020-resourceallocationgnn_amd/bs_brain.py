@@ -92,10 +92,13 @@ class GnnQModel(object):
             cols.append(a)
         return np.stack(cols, axis=1)        # [B, N, C]
 
-    def _train_step(self, pb, y):
-        """One optimizer step on the whole minibatch `pb` -> per-output losses (of the whole minibatch)."""
+    def _train_step(self, pb, y, presharded=False, n_global=None):
+        """One optimizer step on the whole minibatch `pb` -> per-output losses (of the whole minibatch).
+        presharded: `pb` already IS this rank's share of a minibatch of n_global graphs (sharded rollouts)."""
         if self.trainer is None:
             return self.engine.train_step(pb, y)
+        if presharded:
+            return self.trainer.train_step(pb, y, n_graphs_global=n_global)
         if pb.n_graphs % self.trainer.world:
             raise ValueError("data-parallel fit: batch of %d graphs is not divisible by %d ranks"
                              % (pb.n_graphs, self.trainer.world))
@@ -164,12 +167,12 @@ class GnnQModel(object):
         if n_samples > 1:
             np.random.shuffle(np.arange(n_samples))
 
-    def fit_arrays(self, x, e, adj, y, nbr=None):
+    def fit_arrays(self, x, e, adj, y, nbr=None, presharded=False, n_global=None):
         """One Adam step on the whole batch (what the reference's fit call amounts to, BS_brain.py:218-223);
-        y [B, N, C].  -> History with the same keys as fit."""
+        y [B, N, C].  -> History with the same keys as fit.  presharded / n_global: see _train_step."""
         self.consume_fit_shuffle(np.shape(x)[0])
         loss = self._train_step(PackedBatch.from_dense(x, e, adj, nbr),
-                                np.asarray(y, np.float32).reshape(-1, self.spec.n_channels))
+                                np.asarray(y, np.float32).reshape(-1, self.spec.n_channels), presharded, n_global)
         loss = np.asarray(loss, np.float64)
         hist = History()
         hist.epoch.append(0)

@@ -1418,6 +1418,7 @@ struct AdamArgs {
   const float* rowloss; float* loss; int loss_n_idx, loss_stride; float loss_scale;
   int64_t loss_slot_stride;                              // rowloss index of (output slot, i) = slot * loss_slot_stride + i * loss_stride
   int loss_split; float* loss_part; unsigned* loss_cnt;  // ranges per output (> 1 only with a single output)
+  int64_t range_begin4, range_end4;                      // float4 range of the flat buffer this launch covers ([0, n4) = all)
   const float* grad_direct;                              // where slab-less layers left their gradient
   int groups;                                            // threads per float4 column (1, 4 or 16): split of the slab sum
 };
@@ -1463,9 +1464,9 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
   __shared__ float4 part[256];
   const int G = a.groups, cols = 256 / G;
   const int col = threadIdx.x % cols, grp = threadIdx.x / cols;
-  for (int64_t base = (int64_t)blockIdx.x * cols; base < a.n4; base += (int64_t)a.n_adam_blocks * cols) {
+  for (int64_t base = a.range_begin4 + (int64_t)blockIdx.x * cols; base < a.range_end4; base += (int64_t)a.n_adam_blocks * cols) {
     const int64_t i = base + col;
-    const bool act = i < a.n4;
+    const bool act = i < a.range_end4;
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     bool direct = false;
     if (a.slab) {

@@ -977,7 +977,12 @@ int wgrad_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch& d) 
 struct LossJob { int n_out, n_idx, stride; float scale; int64_t slot_stride; };   // n_out == 0: no loss role;
                                                                                  // rowloss(slot, i) = slot*slot_stride + i*stride
 
-int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, float* grad_dst, LossJob lj = LossJob{0, 0, 0, 0.f, 0}) {
+// bucket: -1 = the whole flat buffer, 0 = the Dense layers (its tail), 1 = the graph layers (its head)
+int64_t bucket_begin(const v2x_model* m, int bucket) { return bucket == 0 ? m->dense[0].off : 0; }
+int64_t bucket_end(const v2x_model* m, int bucket) { return bucket == 1 ? m->dense[0].off : m->P; }
+
+int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, float* grad_dst, LossJob lj = LossJob{0, 0, 0, 0.f, 0},
+                       int bucket = -1) {
   AdamArgs a;
   memset(&a, 0, sizeof(a));
   a.param = m->params; a.grad = grad_dst ? grad_dst : m->grads; a.mom = m->mom; a.vel = m->vel;
@@ -993,6 +998,7 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
     a.n_layers = nl;
   }
   a.n4 = m->P / 4;
+  a.range_begin4 = bucket_begin(m, bucket) / 4; a.range_end4 = bucket_end(m, bucket) / 4;
   a.do_adam = do_adam ? 1 : 0;
   if (do_adam) {
     m->iterations += 1;
@@ -1006,7 +1012,7 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
   a.groups = 1;
   if (a.slab && a.n4 < 256 * 1024 && max_slabs_used >= 16) a.groups = a.n4 < 64 * 1024 ? 16 : 4;
   const int cols = 256 / a.groups;
-  int blocks = (int)((a.n4 + cols - 1) / cols);
+  int blocks = (int)((a.range_end4 - a.range_begin4 + cols - 1) / cols);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   a.n_adam_blocks = blocks;
@@ -1511,6 +1517,64 @@ static int fwd_bwd(v2x_model* m, const v2x_batch* b, const float* y, int y_on_de
   }
   m->have_fwd = true;
   return emit_loss(m, loss_out, loss_on_device, st);
+}
+
+// Data-parallel step in two phases (dp.py): phase 0 = forward, decision-MLP forward + Huber + backward, the Dense layers'
+// weight gradients reduced into their bucket of the flat gradient; phase 1 = graph-layer backward, their weight gradients,
+// the per-output losses.  After phase 0 the Dense bucket is final, so the host can start its all-reduce (RCCL runs on its
+// own stream) while phase 1 computes.
+int v2x_forward_backward_phase(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device, int32_t n_global, int phase,
+                               float* loss_out, int loss_on_device, void* stream) {
+  if (!m) FAIL(m, V2X_EINVAL, "null model");
+  if (phase != 0 && phase != 1) FAIL(m, V2X_EINVAL, "forward_backward_phase: phase must be 0 or 1");
+  if (is_wide(m)) FAIL(m, V2X_EINVAL, "forward_backward_phase: narrow feature widths only (use v2x_forward_backward)");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  DevBatch d;
+  CHK(resolve_batch(m, b, &d, st));
+  if (n_global <= 0) n_global = m->cfg.variable_graphs ? d.R : d.B;
+  const float* yd;
+  CHK(resolve_y(m, y, y_on_device, d.R, st, &yd));
+  CHK(presize(m, d));
+  const Range all{0, d.B};
+  const IdxMap x = idx_map(m, d, all);
+  const int F = m->F, L = m->L;
+  if (phase == 0) {
+    CHK(run_maybe_graph(m, st, make_key(5, d, yd, n_global), [&]() -> int {
+      CHK(run_forward(m, st, d, all, !mlp_fused_training(m)));
+      MlpArgs a;
+      mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
+      a.y = yd;
+      a.inv_denom = 1.0f / loss_denominator(m, n_global);
+      if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
+      else CHK(launch_mlp(m, st, a, true));
+      CHK(wgrad_mlp(m, st, x, d.xe, m->h[L], m->a[L]));
+      return launch_reduce_adam(m, st, 1, false, nullptr, LossJob{0, 0, 0, 0.f, 0}, 0);
+    }));
+    m->have_fwd = true;
+    return V2X_OK;
+  }
+  if (!m->have_fwd) FAIL(m, V2X_ESTATE, "forward_backward_phase: phase 1 before phase 0");
+  CHK(run_maybe_graph(m, st, make_key(6, d, yd, n_global), [&]() -> int {
+    if (fused_path(m, d)) {
+      CHK(launch_fused_bwd(m, st, d));
+    } else {
+      for (int s = L; s >= 1; --s) {
+        CHK(launch_agg(m, st, d, all, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, s < L ? m->h[s] : nullptr, m->dpre[s], 1));
+        CHK(launch_dgrad(m, st, s, x, m->dpre[s], m->gha));
+      }
+      CHK(launch_agg(m, st, d, all, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, m->h[0], m->dpre[0], 1));
+    }
+    CHK(wgrad_gnn_all(m, st, x, d));
+    return launch_reduce_adam(m, st, 1, false, nullptr, loss_job(m, d, n_global), 1);
+  }));
+  return emit_loss(m, loss_out, loss_on_device, st);
+}
+
+int64_t v2x_grad_bucket(const v2x_model* m, int bucket, int64_t* offset) {
+  if (!m || bucket < 0 || bucket > 1) return 0;
+  if (offset) *offset = bucket_begin(m, bucket);
+  return bucket_end(m, bucket) - bucket_begin(m, bucket);
 }
 
 int v2x_train_step(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device, int32_t n_graphs_global,

@@ -17,7 +17,7 @@ class DataParallelTrainer(object):
     grad_tensor() -> flat torch tensor aliasing the gradient buffer, apply_gradients().
     `GnnEngine` is the GPU backend."""
 
-    def __init__(self, backend, process_group=None, force=False):
+    def __init__(self, backend, process_group=None, force=False, overlap=True):
         import torch.distributed as dist
         self.dist = dist
         self.backend = backend
@@ -25,7 +25,9 @@ class DataParallelTrainer(object):
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self._grad = None
+        self._buckets = None
         self.force = force          # run the collective even with one rank (exercises the RCCL path)
+        self.overlap = overlap      # split the step so that the Dense-layer bucket is reduced during the graph-layer backward
 
     def shard(self, batch, y):
         """Contiguous shard of whole graphs for this rank (variable-size batches: balanced by edges + nodes,
@@ -35,10 +37,36 @@ class DataParallelTrainer(object):
         sh, (r0, r1) = batch.shard(self.rank, self.world, with_rows=True)
         return sh, y[r0:r1]
 
+    def _overlapped(self, local_batch):
+        """Bucketed all-reduce overlapped with the backward pass: available when the backend splits its step
+        (GnnEngine.forward_backward_phase) and the batch is resident on the device."""
+        return (self.overlap and hasattr(self.backend, "forward_backward_phase") and hasattr(local_batch, "device")
+                and getattr(self.backend.spec, "feat_dim", 0) <= 64)
+
     def train_step(self, local_batch, local_y, n_graphs_global, want_loss=True):
-        """forward+backward on the local shard, all-reduce the gradient, Adam on every rank."""
+        """forward+backward on the local shard, all-reduce the gradient, Adam on every rank.
+
+        With a device-resident batch the step is split (SURVEY.md 8 e3 "overlappable with the tail of backward"): the
+        Dense-layer gradients are final as soon as the decision MLP has been differentiated, so their bucket (the tail
+        of the flat gradient) is all-reduced -- asynchronously, RCCL works on its own stream -- while the graph layers
+        are still in their backward pass; the graph-layer bucket follows, and ONE Adam launch runs after both."""
+        reduce_now = self.world > 1 or self.force
+        if reduce_now and self._overlapped(local_batch):
+            if self._grad is None:
+                self._grad = self.backend.grad_tensor()
+                self._buckets = [self._grad[o:o + n] for o, n in self.backend.grad_buckets()]
+            self.backend.forward_backward_phase(local_batch, local_y, 0, n_global=n_graphs_global)
+            w0 = self.dist.all_reduce(self._buckets[0], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            loss = self.backend.forward_backward_phase(local_batch, local_y, 1, n_global=n_graphs_global, want_loss=want_loss)
+            w1 = self.dist.all_reduce(self._buckets[1], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w0.wait()
+            w1.wait()
+            if want_loss and loss is not None:
+                self.dist.all_reduce(loss, op=self.dist.ReduceOp.SUM, group=self.group)
+            self.backend.apply_gradients()
+            return loss
         loss = self.backend.forward_backward(local_batch, local_y, n_global=n_graphs_global, want_loss=want_loss)
-        if self.world > 1 or self.force:
+        if reduce_now:
             if self._grad is None:
                 self._grad = self.backend.grad_tensor()
             self.dist.all_reduce(self._grad, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -54,3 +82,15 @@ class DataParallelTrainer(object):
                     self.dist.all_reduce(loss, op=self.dist.ReduceOp.SUM, group=self.group)
         self.backend.apply_gradients()
         return loss
+
+    def all_reduce_numpy(self, arr):
+        """Sum of a small float64 numpy array over the ranks (statistics, not the hot path).  RCCL has no CPU tensors:
+        the array travels through the device the gradient lives on; gloo takes the CPU tensor as is."""
+        if self.world == 1:
+            return np.asarray(arr, np.float64)
+        import torch
+        if self._grad is None:
+            self._grad = self.backend.grad_tensor()
+        t = torch.as_tensor(np.asarray(arr, np.float64), device=self._grad.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()

@@ -204,6 +204,21 @@ class GnnEngine(object):
         """Forward + backward only: the local gradient is left in grad_tensor()."""
         return self._step(self._lib.v2x_forward_backward, batch, y, n_global, want_loss)
 
+    def forward_backward_phase(self, batch, y, phase, n_global=None, want_loss=True):
+        """forward_backward in two calls (v2x_forward_backward_phase): after phase 0 the Dense-layer gradient bucket is
+        final, after phase 1 the graph-layer bucket and the losses.  Device batches only."""
+        fn = lambda h, s, yp, yd, ng, lo, ld, st: self._lib.v2x_forward_backward_phase(h, s, yp, yd, ng, int(phase), lo, ld, st)
+        return self._step(fn, batch, y, n_global, want_loss and phase == 1)
+
+    def grad_buckets(self):
+        """[(offset, count)] of the all-reduce buckets inside grad_tensor(), in the order they become final."""
+        out = []
+        for b in (0, 1):
+            off = C.c_int64()
+            n = int(self._lib.v2x_grad_bucket(self._h, b, C.byref(off)))
+            out.append((int(off.value), n))
+        return out
+
     def dqn_step(self, target, batch, batch_next, action, reward, gamma, y_out=None, n_global=None, want_loss=True):
         """One replay step on device-resident data (v2x_dqn_step): target forward on s', online forward on s, target
         rule, backward + Adam on this (online) engine.  action [B, N] int32, reward [B] float64 (device tensors)."""

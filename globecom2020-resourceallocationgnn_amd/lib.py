@@ -49,6 +49,8 @@ SYMBOLS = [
     ("v2x_train_step", C.c_int, [_P, C.POINTER(Batch), _P, C.c_int, _I, _P, C.c_int, _P]),
     ("v2x_forward_backward", C.c_int, [_P, C.POINTER(Batch), _P, C.c_int, _I, _P, C.c_int, _P]),
     ("v2x_apply_gradients", C.c_int, [_P, _P]),
+    ("v2x_forward_backward_phase", C.c_int, [_P, C.POINTER(Batch), _P, C.c_int, _I, C.c_int, _P, C.c_int, _P]),
+    ("v2x_grad_bucket", _L, [_P, C.c_int, C.POINTER(_L)]),
     ("v2x_agg_fwd", C.c_int, [C.POINTER(Batch), _I, _I, _P, _P, _P]),
     ("v2x_agg_bwd", C.c_int, [C.POINTER(Batch), _I, _I, _P, _P, _P]),
     ("v2x_node_update_fwd", C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P]),

@@ -47,9 +47,18 @@ class Memory(object):
 
 class Agent(object):
     def __init__(self, num_d2d, num_ch, num_neighbor, num_d2d_feedback, environment, curr_rl_config, brain=None,
-                 device_replay='auto', **brain_kwargs):
+                 device_replay='auto', rollouts='replicated', **brain_kwargs):
         """device_replay: keep the replay memory in HBM (rl/replay.py) and run replay() without the minibatch
-        visiting the host; 'auto' = whenever the brain runs on the gfx950 engine."""
+        visiting the host; 'auto' = whenever the brain runs on the gfx950 engine.
+
+        rollouts (data-parallel runs only; north_star: "RL rollouts from Environment.py are the natural shard"):
+          'replicated'  every rank steps the SAME seeded simulator and draws the same minibatch, of which it fits its
+                        contiguous share: bit-identical to the single-process run, but G GPUs do G identical rollouts;
+          'sharded'     every rank owns a differently seeded simulator and its own replay memory, contributes
+                        ceil(50 / G) of the transitions of a train step and samples its B / G graphs of the minibatch
+                        from its OWN memory (stratified sampling: the minibatch is the union of the ranks' draws); the
+                        Huber mean is over all B graphs and the gradients are all-reduced, so the replicas stay
+                        bit-identical while the simulator work per rank drops by G."""
         self.epsilon = MAX_EPSILON
         self.num_step = 0
         self.num_CH = num_ch
@@ -72,6 +81,10 @@ class Agent(object):
         self.v2v_weight = curr_rl_config.v2v_weight
         self.v2i_weight = curr_rl_config.v2i_weight
         self.num_Episodes, self.num_Train_Step, self.num_transition = 1, 1, 50
+        if rollouts not in ('replicated', 'sharded'):
+            raise ValueError("rollouts must be 'replicated' or 'sharded'")
+        self.rollouts = rollouts
+        self._sync_mark = 0
         engine = getattr(getattr(self.brain, 'model', None), 'engine', None)
         on_gpu = hasattr(engine, '_h') and self.num_Neighbor == 1
         self.device_replay = None
@@ -80,6 +93,14 @@ class Agent(object):
                 raise ValueError("device_replay needs a brain on the gfx950 engine")
             from .replay import DeviceReplay
             self.device_replay = DeviceReplay(MEMORY_CAPACITY, self.num_D2D, device=engine.device)
+
+    def _trainer(self):
+        return getattr(getattr(self.brain, 'model', None), 'trainer', None)
+
+    def _shard_world(self):
+        """number of ranks the rollouts are sharded over (1 unless rollouts='sharded' under data parallelism)"""
+        tr = self._trainer()
+        return tr.world if (self.rollouts == 'sharded' and tr is not None) else 1
 
     # ------------------------------------------------------------------ observation
     def get_state(self, idx):
@@ -220,7 +241,10 @@ class Agent(object):
         if self.device_replay is not None:
             return self._replay_on_device()
         n, d = self.num_D2D, self.brain.num_One_D2D_Input
-        batch = self.memory.sample(self.batch_size)
+        world = self._shard_world()
+        if self.batch_size % world:
+            raise ValueError("batch %d not divisible by %d ranks" % (self.batch_size, world))
+        batch = self.memory.sample(self.batch_size // world)         # sharded rollouts: this rank's share, from its own memory
         B = len(batch)
         s = np.stack([b[0][0] for b in batch])
         s_ = np.stack([b[3][0] for b in batch])
@@ -238,12 +262,15 @@ class Agent(object):
         y = p.astype(np.float64)
         if self._compact():
             dn = self.brain.num_One_Node_Input
-            result = self.brain.model.fit_arrays(states[:, :, :dn], states[:, :, dn:], adj, np.transpose(y, (1, 0, 2)))
+            kw = dict(presharded=True, n_global=self.batch_size) if world > 1 else {}
+            result = self.brain.model.fit_arrays(states[:, :, :dn], states[:, :, dn:], adj, np.transpose(y, (1, 0, 2)), **kw)
         else:
             y_train = {'D%d_Decide_Output' % (k + 1): y[k] for k in range(n)}
             result = self.brain.train_dnn(self._feed(states, adj), y_train, self.batch_size)
-        q_mean = np.sum(np.sum(y, axis=2) / self.num_Actions, axis=1) / B
-        q_max_mean = np.sum(np.max(y, axis=2), axis=1) / B
+        q_mean = np.sum(np.sum(y, axis=2) / self.num_Actions, axis=1) / self.batch_size
+        q_max_mean = np.sum(np.max(y, axis=2), axis=1) / self.batch_size
+        if world > 1:
+            q_mean, q_max_mean = self._trainer().all_reduce_numpy(np.stack([q_mean, q_max_mean]))
         # the reference reads "original" Q statistics from p AFTER it was overwritten in place (:684-690, :743-746)
         return result, q_mean, q_max_mean, q_mean.copy(), q_max_mean.copy()
 
@@ -253,14 +280,18 @@ class Agent(object):
         from ..bs_brain import History
         n, B = self.num_D2D, self.batch_size
         model, target = self.brain.model, self.brain.target_model
-        idx = self.memory.sample_indices(B)
-        model.consume_fit_shuffle(B)           # Model.fit's np.random.shuffle draw: same RNG stream as fit()
         trainer = model.trainer
-        if trainer is not None and trainer.world > 1:
-            if B % trainer.world:
-                raise ValueError("batch %d not divisible by %d ranks" % (B, trainer.world))
-            per = B // trainer.world
-            idx = idx[trainer.rank * per:(trainer.rank + 1) * per]
+        if trainer is not None and trainer.world > 1 and B % trainer.world:
+            raise ValueError("batch %d not divisible by %d ranks" % (B, trainer.world))
+        if self._shard_world() > 1:                                # own memory, own draws: B / G graphs of the minibatch
+            idx = self.memory.sample_indices(B // trainer.world)
+            model.consume_fit_shuffle(len(idx))
+        else:
+            idx = self.memory.sample_indices(B)
+            model.consume_fit_shuffle(B)       # Model.fit's np.random.shuffle draw: same RNG stream as fit()
+            if trainer is not None and trainer.world > 1:
+                per = B // trainer.world
+                idx = idx[trainer.rank * per:(trainer.rank + 1) * per]
         rep = self.device_replay
         sb, sb_next, action, reward = rep.sample(idx)
         if trainer is None and hasattr(model.engine, 'dqn_step'):
@@ -290,7 +321,9 @@ class Agent(object):
         target sync whenever num_step is a multiple of 500, weights saved every `save_interval` episodes."""
         self.num_Episodes, self.num_Train_Step = num_episodes, num_train_steps
         n = self.num_D2D
-        self.num_transition = 50
+        world = self._shard_world()
+        self.num_transition = -(-50 // world)          # sharded rollouts: this rank's share of the 50 transitions per step
+        self._sync_mark = 0
         loss = np.ones((n, num_episodes, num_train_steps))
         q_mean, q_max = np.zeros_like(loss), np.zeros_like(loss)
         self.num_step = 0
@@ -304,7 +337,11 @@ class Agent(object):
                 for k in range(n):
                     loss[k, ep, it] = result.history['D%d_Decide_Output_loss' % (k + 1)][0]
                 q_mean[:, ep, it], q_max[:, ep, it] = qm, qx
-                if self.num_step % UPDATE_TARGET_FREQUENCY == 0:
+                # target sync whenever the job has collected another 500 transitions (BS_brain.py:846-847 tests
+                # num_step % 500 once per train step; num_step advances by 50 per step there, so this is the same rule)
+                mark = (self.num_step * world) // UPDATE_TARGET_FREQUENCY
+                if mark > self._sync_mark:
+                    self._sync_mark = mark
                     self.brain.update_target_model()
             reward_episode[ep] = np.sum(reward_step[ep])
             if verbose:

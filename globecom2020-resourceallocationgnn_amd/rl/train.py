@@ -6,10 +6,11 @@ data-parallel over the GPUs of one node (BASELINE.json configs[0] and configs[2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         -m v2xgnn.rl.train --links 20 --feedback 64 --batch 4096 --episodes 1 --train-steps 20
 
-Data-parallel scheme: every rank runs the SAME seeded simulator and replay sampling (a few hundred microseconds of
+Data-parallel scheme (--rollouts replicated, the default): every rank runs the SAME seeded simulator and replay sampling (a few hundred microseconds of
 numpy per step), so all ranks hold the identical minibatch without any broadcast; each fit step takes the rank's
 contiguous shard of it and all-reduces the gradient (v2xgnn.dp).  Weights therefore stay bit-identical on all ranks
-and the epsilon-greedy rollouts stay in lock-step.
+and the epsilon-greedy rollouts stay in lock-step.  --rollouts sharded gives every rank its own simulator and replay
+memory and 50/G of the transitions of a train step (Agent docstring): the simulator work per rank drops by G.
 """
 import argparse
 import json
@@ -55,6 +56,9 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1001)           # RL_Train_main.py:44
     ap.add_argument("--save-dir", default=None)
     ap.add_argument("--use-graph", action="store_true")
+    ap.add_argument("--rollouts", choices=["replicated", "sharded"], default="replicated",
+                    help="data-parallel runs: every rank steps the same simulator (bit-identical to one process) or every "
+                         "rank its own, contributing 50/G transitions per train step (Agent docstring)")
     args = ap.parse_args(argv)
     if args.links < 4 or args.links % 4:
         # the simulator drops vehicles in groups of four, one per direction (Environment.py:217-231), and the
@@ -74,8 +78,9 @@ def main(argv=None):
         os.environ.setdefault("MASTER_PORT", "29544")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    random.seed(args.seed)
-    np.random.seed(args.seed)
+    sharded = args.rollouts == "sharded" and world > 1
+    random.seed(args.seed + (7919 * rank if sharded else 0))      # sharded rollouts: one simulator / exploration stream per rank
+    np.random.seed(args.seed + (7919 * rank if sharded else 0))
     cfg = RL_Config()
     cfg.set_train_value(args.feedback, args.gamma, args.batch, 1, 0.1)       # RL_Train_main.py:33-35,60
     cfg.Num_Episodes, cfg.Num_Train_Steps = args.episodes, args.train_steps
@@ -91,7 +96,8 @@ def main(argv=None):
     with ctx:
         agent, (loss, reward_step, reward_ep, q_mean, q_max, _, _) = run_train(
             env, cfg, save_dir=args.save_dir if rank == 0 else None, verbose=rank == 0,
-            device=local, seed=args.seed, use_graph=args.use_graph, data_parallel=world > 1 or force_dp)
+            device=local, seed=args.seed, use_graph=args.use_graph, data_parallel=world > 1 or force_dp,
+            rollouts=args.rollouts)
     dt = time.perf_counter() - t0
     if rank == 0:
         n_fit = args.episodes * args.train_steps

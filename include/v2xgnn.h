@@ -131,6 +131,14 @@ int  v2x_train_step(v2x_model* m, const v2x_batch* b, const float* y, int y_on_d
 int  v2x_forward_backward(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device,
                           int32_t n_graphs_global, float* loss_out, int loss_on_device, void* stream);
 int  v2x_apply_gradients(v2x_model* m, void* stream);
+/* the same forward+backward in two calls, for overlapping the gradient all-reduce with the backward pass (feat_dim <= 64):
+ *   phase 0: forward, decision MLP + Huber + its backward, the Dense layers' weight gradients -> bucket 0 is final
+ *   phase 1: graph-layer backward and weight gradients -> bucket 1 is final; loss_out as above
+ * v2x_grad_bucket gives a bucket's length and its offset (floats) inside v2x_grad_ptr(): bucket 0 = the Dense layers
+ * (tail of the flat layout), bucket 1 = the graph layers (head).                                                        */
+int  v2x_forward_backward_phase(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device,
+                                int32_t n_graphs_global, int phase, float* loss_out, int loss_on_device, void* stream);
+int64_t v2x_grad_bucket(const v2x_model* m, int bucket, int64_t* offset);
 
 /* ---- per-kernel entry points (parity tests; all pointers [dev]) ------------------------ */
 /* AggLayer.call forward: out[q] = sum_{p in N(q)} h[p]            (BS_brain.py:69-76)      */

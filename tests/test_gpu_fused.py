@@ -149,3 +149,36 @@ def test_host_batches_are_validated_before_any_copy():
     with pytest.raises(ValueError, match="source id"):
         eng.validate(db)
     eng.close()
+
+
+@pytest.mark.parametrize("N,F,B,use_graph", [(20, 64, 48, False), (20, 64, 48, True), (4, 16, 64, False)])
+def test_two_phase_step_equals_single_call(N, F, B, use_graph):
+    """v2x_forward_backward_phase (data-parallel overlap: Dense bucket final after phase 0, graph-layer bucket after
+    phase 1) leaves the same gradient and losses as v2x_forward_backward."""
+    import torch
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(17)
+    weights = oc.params_to_list(f32_params(spec, rng))
+    x, e, adj = random_inputs(rng, B, N)
+    y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+    pb = PackedBatch.from_dense(x, e, adj)
+    one, two = _engine(spec, weights, True, use_graph=use_graph), _engine(spec, weights, True, use_graph=use_graph)
+    (o0, n0), (o1, n1) = two.grad_buckets()
+    assert o1 == 0 and o0 == n1 and n0 + n1 == two.n_params          # graph layers first, Dense layers behind them
+    with torch.cuda.stream(torch.cuda.Stream()):
+        db1, db2 = one.to_device(pb), two.to_device(pb)
+        yd = torch.from_numpy(y).cuda()
+        for _ in range(3):                                            # replays of the captured phases included
+            l1 = one.forward_backward(db1, yd)
+            two.grad_tensor().zero_()
+            assert two.forward_backward_phase(db2, yd, 0) is None
+            g_mid = two.get_grad_flat()
+            l2 = two.forward_backward_phase(db2, yd, 1)
+            torch.cuda.synchronize()
+            g1, g2 = one.get_grad_flat(), two.get_grad_flat()
+            assert np.array_equal(g_mid[o0:], g2[o0:]) and not g_mid[:o0].any()     # Dense bucket final after phase 0
+            assert np.array_equal(l1.cpu().numpy(), l2.cpu().numpy())
+            assert np.allclose(g1, g2, rtol=1e-5, atol=1e-9)
+            one.apply_gradients()
+            two.apply_gradients()
+    assert np.allclose(one.get_flat(), two.get_flat(), rtol=1e-6, atol=1e-8)

@@ -226,17 +226,17 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
             "legs": legs}
 
 
-def rl_episode(links, feat, batch, gamma, train_steps, seed, engine_factory=None, device=0, use_graph=False):
+def rl_episode(links, feat, batch, gamma, train_steps, seed, engine_factory=None, device=0, use_graph=False, envs=0):
     """One episode of the DQN loop (RL_Train_main.py:98-118 -> Agent.train, BS_brain.py:750-910) through the package's own
     simulator / agent counterparts: train_steps x (50 rollout transitions + 1 replay of `batch`).  -> wall-clock split."""
     import random
     from v2xgnn.rl import Agent, RL_Config
-    from v2xgnn.rl.train import start_env
+    from v2xgnn.rl.train import start_env, start_env_batched
     random.seed(seed)
     np.random.seed(seed)
     cfg = RL_Config()
     cfg.set_train_value(feat, gamma, batch, 1, 0.1)
-    env = start_env(links)
+    env = start_env_batched(links, envs, seed) if envs > 0 else start_env(links)       # E simulators stepped as arrays
     kw = dict(seed=seed)
     if engine_factory is not None:
         from v2xgnn import BS
@@ -276,12 +276,13 @@ def main_rl(args):
     steps = 20
     ctx = torch.cuda.stream(torch.cuda.Stream())
     with ctx:
-        rl_episode(links, feat, batch, gamma, 2, 7, use_graph=True)           # warm-up: allocations, graph capture paths
-        gpu = rl_episode(links, feat, batch, gamma, steps, 1001, use_graph=True)
+        rl_episode(links, feat, batch, gamma, 2, 7, use_graph=True, envs=args.envs)   # warm-up: allocations, graph capture
+        gpu = rl_episode(links, feat, batch, gamma, steps, 1001, use_graph=True, envs=args.envs)
     cpu = None
     if args.workload == "cfg0" and not args.no_cpu_baseline:
         from oracle.engine import OracleEngine
-        r = rl_episode(links, feat, batch, gamma, steps, 1001, engine_factory=lambda spec: OracleEngine(spec, dtype=np.float32))
+        r = rl_episode(links, feat, batch, gamma, steps, 1001, engine_factory=lambda spec: OracleEngine(spec, dtype=np.float32),
+                       envs=args.envs)
         cpu = {"value": r["train_steps_per_s"], "unit": "train-steps/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
                "cpu_model": cpu_model(), "sample": "the same episode (seed 1001) with the numpy fp32 oracle as the Q-network", "detail": r}
     print(json.dumps({"metric": "DQN train steps/s (50 simulator transitions + 1 replay of batch %d each), %d V2V links, feat_dim %d"
@@ -292,6 +293,7 @@ def main_rl(args):
                       "config": {"workload": "BASELINE.json configs[%d]: one episode = %d train steps x (50 rollouts + 1 replay), "
                                              "%d links, feat_dim=%d, batch %d, gamma %g"
                                              % (0 if args.workload == "cfg0" else 2, steps, links, feat, batch, gamma),
+                                 "simulators": ("%d stepped as arrays (rl/batched_env.py)" % args.envs) if args.envs > 0 else "1 (rl/environment.py)",
                                  "split": gpu}, "roofline": None, "cpu_baseline": cpu}))
 
 
@@ -304,6 +306,7 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --batch graphs per GPU (global batch grows with --gpus); strong: --batch graphs in total, "
                          "cut into contiguous shards of whole graphs (SURVEY.md 8 d1: global batch fixed)")
+    ap.add_argument("--envs", type=int, default=0, help="cfg0 / cfg2loop: number of simulators stepped as arrays (0 = the single one)")
     ap.add_argument("--min-seconds", type=float, default=0.25,
                     help="the timed region is extended to at least this long (more steps than --steps if needed)")
     ap.add_argument("--nodes", type=int, default=20)

@@ -3,3 +3,4 @@ so that the reference's training / test loops run on the engine where the refere
 from .environment import Environ, Vehicle                      # noqa: F401
 from .sim_config import RL_Config                              # noqa: F401
 from .agent import Agent, Memory                               # noqa: F401
+from .batched_env import BatchedEnviron                        # noqa: F401

@@ -122,9 +122,21 @@ class Agent(object):
             adj[self.env.vehicles[q].destinations[0], q] = 0
         return adj
 
+    def _batched(self):
+        """the simulator is a BatchedEnviron (rl/batched_env.py): E environments stepped as arrays"""
+        return hasattr(self.env, 'E')
+
+    def _one_env(self):
+        if self.env.E != 1:
+            raise ValueError("this entry point steps ONE environment; the simulator holds %d" % self.env.E)
+
     def observe(self):
         """-> D2D_State [N, Dn+De] = [V2V gain x C | V2I gain x C | power | edge gain x C] (BS_brain.py:458-467)
         and the adjacency."""
+        if self._batched():
+            self._one_env()
+            state, adj = self.env.observe(self.num_CH)
+            return state[0], adj[0]
         n, C, nn = self.num_D2D, self.num_CH, self.num_Neighbor
         power = self.env.V2V_power_dB_List[self.env.fixed_v2v_power_index]
         state = np.zeros((n, self.brain.num_One_D2D_Input))
@@ -200,6 +212,10 @@ class Agent(object):
     def act(self, actions):
         """BS_brain.py:366-376"""
         self.num_step += 1
+        if self._batched():
+            self._one_env()
+            v2v, v2i, intf = self.env.act(np.asarray(actions)[None])
+            return v2v[0], v2i[0], intf[0]
         rates = self.env.compute_reward_with_channel_selection(actions)
         self.env.renew_positions()
         self.env.renew_channels_fastfading()
@@ -207,6 +223,10 @@ class Agent(object):
         return rates
 
     def dump_act(self, actions):
+        if self._batched():
+            self._one_env()
+            v2v, v2i, intf = self.env.compute_reward_with_channel_selection(np.asarray(actions)[None])
+            return v2v[0], v2i[0], intf[0]
         return self.env.compute_reward_with_channel_selection(actions)
 
     def train_observe(self, sample):
@@ -215,6 +235,8 @@ class Agent(object):
     def generate_d2d_transition(self, num_transitions):
         """num_transitions environment steps under the epsilon-greedy policy into the replay memory
         (BS_brain.py:409-553).  A sample is [States(1, N*13+N*N), Actions(1, N), reward, States_]."""
+        if self._batched():
+            return self._generate_batched(num_transitions)
         rewards = np.zeros(num_transitions)
         for self.train_step in range(num_transitions):
             d2d_state, adj = self.observe()
@@ -233,6 +255,48 @@ class Agent(object):
             else:
                 self.train_observe([states, action.reshape(1, -1), reward, states_])
         return rewards
+
+    def _generate_batched(self, num_transitions):
+        """generate_d2d_transition on a BatchedEnviron: every iteration observes all E environments, picks the E joint
+        actions (epsilon-greedy per environment: one uniform draw each, in order; the greedy environments share ONE
+        forward pass), steps the E simulators as arrays and stores E transitions.  ceil(num / E) iterations; with E = 1
+        the numpy-RNG consumption and the stored transitions are those of the single-simulator loop."""
+        E, n, nn, C = self.env.E, self.num_D2D, self.num_Neighbor, self.num_CH
+        dn = self.brain.num_One_Node_Input
+        n_iter = -(-num_transitions // E)
+        rewards = np.zeros(n_iter * E)
+        for it in range(n_iter):
+            states, adj = self.env.observe(C)
+            steps = self.num_Episodes * 0.8 * self.num_Train_Step * self.num_transition
+            per_step = (MAX_EPSILON - MIN_EPSILON) / steps
+            actions = np.zeros((E, n, nn), int)
+            greedy = []
+            for e in range(E):
+                step_no = self.num_step + e
+                self.epsilon = MAX_EPSILON - per_step * step_no if step_no < steps else MIN_EPSILON
+                if np.random.random() < self.epsilon:
+                    for k in range(n):
+                        actions[e, k, :] = np.random.choice(range(0, C), nn)
+                else:
+                    greedy.append(e)
+            if greedy:
+                q = self._predict(states[greedy], adj[greedy])                            # [N, len(greedy), C]
+                actions[greedy] = np.transpose(np.argmax(q, axis=2))[:, :, None]
+            v2v, v2i, _ = self.env.act(actions)
+            self.num_step += E
+            reward = self.v2v_weight * v2v.sum(axis=(1, 2)) + self.v2i_weight * v2i.sum(axis=1)
+            rewards[it * E:(it + 1) * E] = reward
+            nxt, _ = self.env.observe(C)
+            for e in range(E):
+                if self.device_replay is not None:
+                    self.device_replay.add(states[e, :, :dn], states[e, :, dn:], adj[e], actions[e].reshape(-1), reward[e],
+                                           nxt[e, :, :dn], nxt[e, :, dn:])
+                    self.train_observe(None)
+                else:
+                    self.train_observe([np.concatenate((states[e].reshape(1, -1), adj[e].reshape(1, -1)), axis=-1),
+                                        actions[e].reshape(1, -1), reward[e],
+                                        np.concatenate((nxt[e].reshape(1, -1), adj[e].reshape(1, -1)), axis=-1)])
+        return rewards[:num_transitions] if n_iter * E == num_transitions else rewards
 
     # ------------------------------------------------------------------ learning
     def replay(self):
@@ -323,6 +387,8 @@ class Agent(object):
         n = self.num_D2D
         world = self._shard_world()
         self.num_transition = -(-50 // world)          # sharded rollouts: this rank's share of the 50 transitions per step
+        if self._batched():                            # batched simulator: whole iterations of E transitions
+            self.num_transition = -(-self.num_transition // self.env.E) * self.env.E
         self._sync_mark = 0
         loss = np.ones((n, num_episodes, num_train_steps))
         q_mean, q_max = np.zeros_like(loss), np.zeros_like(loss)

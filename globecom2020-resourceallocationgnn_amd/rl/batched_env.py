@@ -1,0 +1,275 @@
+"""E independent V2X simulators stepped as arrays ("vectorised/batched Environ").
+
+`BatchedEnviron` holds the state of E environments of N vehicles as stacked numpy arrays and advances all of them with
+one set of array operations per simulator step: mobility (Environment.py:236-345), large-scale fading with correlated
+shadowing (:378-393), Rayleigh fast fading (:395-406), the rate / interference computation (:408-493) and the agent's
+observation (BS_brain.py:389-467).  Every environment owns an `MTStream` -- an MT19937 stream with the stdlib's draw
+algorithms -- and consumes it in the reference's order, so environment e of a batch IS the single simulator seeded with
+`seeds[e]`: same vehicles, bit-identical positions and directions, channels / rates to rounding
+(tests/test_rl_batched_env.py checks both against `Environ` and against trajectories captured from the reference).
+With `streams=None, n_envs=1` the one environment runs on the process-wide stdlib generator (borrowed per call), i.e.
+it is a drop-in for `Environ` in seeded runs.
+
+Only the 1-receiver configuration of the reference (n_Neighbor = 1) is batched.
+"""
+import numpy as np
+
+from .environment import Environ
+from .mtstream import MTStream, gauss_uniforms, box_muller
+
+_DIRS = 'udlr'        # direction codes 0..3
+
+
+class BatchedEnviron(object):
+    def __init__(self, down_lane, up_lane, left_lane, right_lane, width, height, n_envs=1, seeds=None):
+        """seeds: one seed per environment (each environment then reproduces `random.seed(seed); Environ(...)`);
+        None with n_envs == 1: the process-wide stdlib generator is used (borrowed and returned around every call)."""
+        self._proto = Environ.__new__(Environ)                 # constants + path-loss models of the single simulator
+        p = self._proto
+        p.timestep = 0.01
+        p.down_lanes, p.up_lanes, p.left_lanes, p.right_lanes = list(down_lane), list(up_lane), list(left_lane), list(right_lane)
+        p.width, p.height = width, height
+        p.V2V_power_dB = p.V2I_power_dB = 23
+        p.V2V_power_dB_List = [23, 10, 5]
+        p.fixed_v2v_power_index = 1
+        p.sig2_dB = -114
+        p.bsAntGain, p.bsNoiseFigure, p.vehAntGain, p.vehNoiseFigure = 8, 5, 3, 9
+        p.sig2 = 10 ** (p.sig2_dB / 10)
+        for k in ('timestep', 'width', 'height', 'V2V_power_dB', 'V2I_power_dB', 'V2V_power_dB_List', 'fixed_v2v_power_index',
+                  'sig2', 'bsAntGain', 'bsNoiseFigure', 'vehAntGain', 'vehNoiseFigure'):
+            setattr(self, k, getattr(p, k))
+        self.n_RB, self.n_Veh, self.n_Neighbor = 4, 4, 1
+        self.E = int(n_envs)
+        if seeds is None and self.E != 1:
+            raise ValueError("n_envs > 1 needs one seed per environment")
+        self._shared = seeds is None
+        self.streams = None if self._shared else [MTStream(int(s)) for s in seeds]
+        if not self._shared and len(self.streams) != self.E:
+            raise ValueError("need %d seeds" % self.E)
+        # lane tables of the mobility rule, in the reference's checking order (Environment.py:247-324):
+        # direction -> (moving axis, sign, [(lanes, new direction, side-step sign, gap sign)])
+        L, R, U, D = p.left_lanes, p.right_lanes, p.up_lanes, p.down_lanes
+        self._moves = {0: (1, +1, [(L, 2, -1, -1), (R, 3, +1, +1)]), 1: (1, -1, [(L, 2, -1, -1), (R, 3, +1, +1)]),
+                       3: (0, +1, [(U, 0, +1, -1), (D, 1, -1, -1)]), 2: (0, -1, [(U, 0, +1, -1), (D, 1, -1, -1)])}
+        self._lanes_of = {0: np.array(L + R, float), 1: np.array(L + R, float), 3: np.array(U + D, float), 2: np.array(U + D, float)}
+        with self._rng() as rs:                                # Environ.__init__ draws the initial shadowing (:208-209)
+            for s in rs:
+                s.gauss_array((self.n_Veh, self.n_Veh), Environ.V2V_SHADOW_STD)
+                s.gauss_array((self.n_Veh,), Environ.V2I_SHADOW_STD)
+
+    # ------------------------------------------------------------------ random streams
+    class _Borrow(object):
+        def __init__(self, env):
+            self.env = env
+
+        def __enter__(self):
+            if self.env._shared:
+                self.s = [MTStream.borrow_stdlib()]
+                return self.s
+            return self.env.streams
+
+        def __exit__(self, *exc):
+            if self.env._shared:
+                self.s[0].return_stdlib()
+
+    def _rng(self):
+        return BatchedEnviron._Borrow(self)
+
+    # ------------------------------------------------------------------ construction
+    def new_random_game(self, n_Veh=0):
+        """Environment.py:495-506 for every environment."""
+        if n_Veh > 0:
+            if n_Veh % 4:
+                raise ValueError("n_Veh must be a multiple of 4; got %d" % n_Veh)
+            self.n_Veh = n_Veh
+        E, N, p = self.E, self.n_Veh, self._proto
+        self.pos = np.zeros((E, N, 2))
+        self.dirs = np.zeros((E, N), np.int8)
+        self.vel = np.zeros((E, N))
+        self.dest = np.zeros((E, N), np.int64)
+        self._v2v_shadow = np.zeros((E, N, N))
+        self._v2i_shadow = np.zeros((E, N))
+        with self._rng() as rs:
+            for e, s in enumerate(rs):
+                k = 0
+                for _ in range(N // 4):                        # add_new_vehicles_by_number (:217-234)
+                    ind = s.randrange(0, len(p.down_lanes))
+                    for code, lane_x, lane_y in ((1, p.down_lanes[ind], None), (0, p.up_lanes[ind], None),
+                                                 (2, None, p.left_lanes[ind]), (3, None, p.right_lanes[ind])):
+                        if lane_y is None:
+                            self.pos[e, k] = (lane_x, s.randint(0, p.height))
+                        else:
+                            self.pos[e, k] = (s.randint(0, p.width), lane_y)
+                        self.dirs[e, k] = code
+                        self.vel[e, k] = s.randint(10, 15)
+                        k += 1
+                s.gauss_array((N, N), 3)                        # V2V_Shadowing / V2I_Shadowing: drawn, never used (:232-233)
+                s.gauss_array((N,), 8)
+                self._v2v_shadow[e] = s.gauss_array((N, N), Environ.V2V_SHADOW_STD)
+                self._v2i_shadow[e] = s.gauss_array((N,), Environ.V2I_SHADOW_STD)
+        self.renew_channels_fastfading()
+        with self._rng() as rs:                                # renew_neighbor (:360-376)
+            for e, s in enumerate(rs):
+                z = np.array([[complex(x, y) for x, y in self.pos[e]]])
+                dist = abs(z.T - z)
+                for i in range(N):
+                    order = np.argsort(dist[:, i])
+                    self.dest[e, i] = s.sample(list(order[1:(len(order) - 2)]), 1)[0]
+        self.activate_links = np.ones((E, N, 1), dtype=bool)
+
+    # ------------------------------------------------------------------ mobility
+    def renew_positions(self):
+        """One 10 ms step of every vehicle of every environment.  Vehicles that reach no crossing lane (almost all)
+        move as arrays; the few that do are walked in the reference's order because each reached lane costs its
+        environment one uniform draw (turn with probability 0.4)."""
+        p = self._proto
+        dd = self.vel * p.timestep
+        axis = np.where(self.dirs < 2, 1, 0)
+        sign = np.where((self.dirs == 0) | (self.dirs == 3), 1.0, -1.0)
+        a = np.take_along_axis(self.pos, axis[..., None], axis=2)[..., 0]
+        new_a = np.where(sign > 0, a + dd, a - dd)
+        lo, hi = np.minimum(a, new_a), np.maximum(a, new_a)
+        flagged = np.zeros(self.dirs.shape, bool)
+        for d, lanes in self._lanes_of.items():
+            m = self.dirs == d
+            if m.any():
+                flagged[m] = ((lanes[None, :] >= lo[m][:, None]) & (lanes[None, :] <= hi[m][:, None])).any(axis=1)
+        straight = ~flagged
+        e_idx, v_idx = np.nonzero(straight)
+        self.pos[e_idx, v_idx, axis[straight]] = new_a[straight]
+        if flagged.any():
+            with self._rng() as rs:
+                for e, v in zip(*np.nonzero(flagged)):          # row-major: vehicle order inside every environment
+                    s = rs[e]
+                    ax, sg, options = self._moves[int(self.dirs[e, v])]
+                    av, ov, dv = self.pos[e, v, ax], self.pos[e, v, 1 - ax], dd[e, v]
+                    turned = False
+                    for lanes, new_dir, side_sign, gap_sign in options:
+                        for lane in lanes:
+                            reached = (av <= lane and av + dv >= lane) if sg > 0 else (av >= lane and av - dv <= lane)
+                            if reached and s.uniform(0, 1) < 0.4:
+                                gap = sg * (lane - av)
+                                new_o = ov + side_sign * (dv + gap_sign * gap)
+                                self.pos[e, v] = (new_o, lane) if ax == 1 else (lane, new_o)
+                                self.dirs[e, v] = new_dir
+                                turned = True
+                                break
+                        if turned:
+                            break
+                    if not turned:
+                        self.pos[e, v, ax] = av + dv if sg > 0 else av - dv
+        x, y = self.pos[..., 0], self.pos[..., 1]
+        out = (x < 0) | (y < 0) | (x > p.width) | (y > p.height)
+        if out.any():                                          # re-entry on the outermost lane (:326-345)
+            d = self.dirs
+            for code, new_dir, fix_axis, lane in ((0, 3, 1, p.right_lanes[-1]), (1, 2, 1, p.left_lanes[0]),
+                                                  (2, 0, 0, p.up_lanes[0]), (3, 1, 0, p.down_lanes[-1])):
+                m = out & (d == code)
+                if m.any():
+                    ee, vv = np.nonzero(m)
+                    self.pos[ee, vv, fix_axis] = lane
+                    self.dirs[ee, vv] = new_dir
+                    out = out & ~m
+
+    # ------------------------------------------------------------------ channels
+    def renew_channels_fastfading(self):
+        """renew_channel + fast fading (:378-406) for all environments; per environment ONE block of uniforms feeds the
+        n + n^2 shadowing draws and the 2 n rb + 2 n^2 rb Rayleigh draws, in the reference's order."""
+        E, n, rb, p = self.E, self.n_Veh, self.n_RB, self._proto
+        n_sh, n_ff = n + n * n, 2 * n * rb + 2 * n * n * rb
+        with self._rng() as rs:
+            g = box_muller(gauss_uniforms(rs, n_sh + n_ff))[:, :n_sh + n_ff]
+            if (n_sh + n_ff) & 1:                              # keep the odd value cached like random.gauss would
+                raise NotImplementedError("odd number of draws per step")
+        dd = 0.002 * self.vel
+        self._v2i_shadow = (np.exp(-1 * (dd / Environ.V2I_DECORR)) * self._v2i_shadow
+                            + np.sqrt(1 - np.exp(-2 * (dd / Environ.V2I_DECORR))) * (g[:, :n] * Environ.V2I_SHADOW_STD))
+        ddm = dd[:, :, None] + dd[:, None, :]
+        self._v2v_shadow = (np.exp(-1 * (ddm / Environ.V2V_DECORR)) * self._v2v_shadow
+                            + np.sqrt(1 - np.exp(-2 * (ddm / Environ.V2V_DECORR))) * (g[:, n:n_sh].reshape(E, n, n) * Environ.V2V_SHADOW_STD))
+        self.V2V_channels_abs = p._v2v_pathloss(self.pos) + self._v2v_shadow + 50 * np.identity(n)
+        self.V2I_channels_abs = p._v2i_pathloss(self.pos) + self._v2i_shadow
+        f = g[:, n_sh:]
+        a, b = n * rb, n * n * rb
+        re, im = f[:, :a].reshape(E, n, rb), f[:, a:2 * a].reshape(E, n, rb)
+        v2i_ff = 20 * np.log10(np.abs(1 / np.sqrt(2) * (re + 1j * im)))
+        re, im = f[:, 2 * a:2 * a + b].reshape(E, n, n, rb), f[:, 2 * a + b:].reshape(E, n, n, rb)
+        v2v_ff = 20 * np.log10(np.abs(1 / np.sqrt(2) * (re + 1j * im)))
+        self.V2V_channels_with_fastfading = self.V2V_channels_abs[..., None] - v2v_ff
+        self.V2I_channels_with_fastfading = self.V2I_channels_abs[..., None] - v2i_ff
+
+    # ------------------------------------------------------------------ reward
+    def compute_reward_with_channel_selection(self, actions):
+        """actions [E, N] or [E, N, 1] -> V2V rates [E, N, 1], V2I rates [E, min(rb, N)], interference at the base
+        station [E, rb] (Environment.py:408-458, every link active, one receiver per link)."""
+        E, n, rb = self.E, self.n_Veh, self.n_RB
+        ch = np.asarray(actions).reshape(E, n).astype(np.int64)
+        ei = np.arange(E)[:, None]
+        ki = np.arange(n)[None, :]
+        rx = self.dest
+        p_v2v = self.V2V_power_dB_List[self.fixed_v2v_power_index]
+        v2v, v2i = self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading
+        onehot = ch[:, :, None] == np.arange(rb)[None, None, :]                      # [E, N, rb]
+        at_bs = 10 ** ((p_v2v - v2i[ei, ki, ch] + self.vehAntGain + self.bsAntGain - self.bsNoiseFigure) / 10)
+        interference = (at_bs[:, :, None] * onehot).sum(axis=1)
+        self.V2I_Interference = interference + self.sig2
+        gain = 2 * self.vehAntGain - self.vehNoiseFigure
+        signal = 10 ** ((p_v2v - v2v[ei, ki, rx, ch] + gain) / 10)
+        v2v_int = np.zeros((E, n))
+        has_v2i = ch < n                                          # the V2I transmitter of that RB is vehicle number RB
+        chc = np.minimum(ch, n - 1)
+        v2v_int += np.where(has_v2i, 10 ** ((self.V2I_power_dB - v2v[ei, chc, rx, ch] + gain) / 10), 0.0)
+        same = (ch[:, :, None] == ch[:, None, :]) & ~np.eye(n, dtype=bool)[None]       # [E, i, k]
+        cross = 10 ** ((p_v2v - v2v[ei[:, :, None], np.arange(n)[None, None, :], rx[:, :, None], ch[:, :, None]] + gain) / 10)
+        v2v_int += (cross * same).sum(axis=2)
+        self.V2V_Interference = v2v_int[..., None] + self.sig2
+        v2v_rate = np.log2(1 + np.divide(signal[..., None], self.V2V_Interference))
+        m = min(rb, n)
+        v2i_signals = self.V2I_power_dB - self.V2I_channels_abs[:, 0:m] + self.vehAntGain + self.bsAntGain - self.bsNoiseFigure
+        v2i_rate = np.log2(1 + np.divide(10 ** (v2i_signals / 10), self.V2I_Interference[:, 0:m]))
+        return v2v_rate, v2i_rate, interference
+
+    def Compute_Interference(self, actions):
+        """Environment.py:460-493 (observable part: noise + the co-channel V2I transmitter), [E, N, 1, rb] in dB."""
+        E, n, rb = self.E, self.n_Veh, self.n_RB
+        r = np.arange(rb)
+        out = np.zeros((E, n, 1, rb)) + self.sig2
+        v2v = self.V2V_channels_with_fastfading
+        out += 10 ** ((self.V2I_power_dB - v2v[np.arange(E)[:, None, None], r[None, None, :], self.dest[:, :, None], r[None, None, :]][:, :, None, :]
+                       + 2 * self.vehAntGain - self.vehNoiseFigure) / 10)
+        self.V2V_Interference_all = 10 * np.log10(out)
+
+    def act(self, actions):
+        """Agent.act (BS_brain.py:366-376) for all environments: rates under `actions`, then one simulator step."""
+        rates = self.compute_reward_with_channel_selection(actions)
+        self.renew_positions()
+        self.renew_channels_fastfading()
+        self.Compute_Interference(actions)
+        return rates
+
+    # ------------------------------------------------------------------ the agent's view
+    def observe(self, n_channels=4):
+        """Agent.observe for all environments -> D2D_State [E, N, 2C+1+C] = [V2V gain | V2I gain | power | edge gain]
+        (BS_brain.py:389-407, :458-467) and the adjacency [E, N, N] (Adj[p, q] = 0 for p == q and for the receiver p of
+        link q, :441-445)."""
+        E, n, C = self.E, self.n_Veh, n_channels
+        A, Bc = 80, 60
+        v2v, v2i = self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading
+        ei = np.arange(E)[:, None]
+        k = np.arange(n)[None, :]
+        dst = self.dest
+        ch = (v2v[ei, k, dst, :] - A) / Bc
+        towards = v2v[ei[:, :, None], np.arange(n)[None, None, :], dst[:, :, None], :]             # [E, k, p, C]: p -> receiver of k
+        edge = (((np.sum(towards, axis=2) - v2v[ei, dst, dst, :]) - (n - 1) * A) / Bc - ch) / (n - 2)
+        state = np.zeros((E, n, 2 * C + 1 + C))
+        state[:, :, 0:C] = ch
+        state[:, :, C:2 * C] = (v2i - A) / Bc
+        state[:, :, 2 * C] = self.V2V_power_dB_List[self.fixed_v2v_power_index]
+        state[:, :, 2 * C + 1:] = edge
+        adj = np.ones((E, n, n)) - np.eye(n)[None]
+        adj[ei, dst, k] = 0
+        return state, adj
+
+    # ------------------------------------------------------------------ single-environment views (tests, tools)
+    def directions(self, e=0):
+        return [_DIRS[c] for c in self.dirs[e]]

@@ -183,8 +183,8 @@ class Environ(object):
     # ------------------------------------------------------------------ channels
     def _v2v_pathloss(self, pos):
         """WINNER-style urban V2V path loss, LOS when the vehicles share a street (Environment.py:94-122)."""
-        d1 = np.abs(pos[:, None, 0] - pos[None, :, 0])
-        d2 = np.abs(pos[:, None, 1] - pos[None, :, 1])
+        d1 = np.abs(pos[..., :, None, 0] - pos[..., None, :, 0])       # (leading batch axes allowed: batched_env.py)
+        d2 = np.abs(pos[..., :, None, 1] - pos[..., None, :, 1])
         d = np.hypot(d1, d2) + 0.001
         fc, h = self.FC, self.V2V_H
         d_bp = 4 * (h - 1) * (h - 1) * fc * (10 ** 9) / (3 * 10 ** 8)
@@ -206,7 +206,7 @@ class Environ(object):
 
     def _v2i_pathloss(self, pos):
         """Environment.py:140-146"""
-        dist = np.hypot(np.abs(pos[:, 0] - self.BS_POSITION[0]), np.abs(pos[:, 1] - self.BS_POSITION[1]))
+        dist = np.hypot(np.abs(pos[..., 0] - self.BS_POSITION[0]), np.abs(pos[..., 1] - self.BS_POSITION[1]))
         return 128.1 + 37.6 * np.log10(np.sqrt(dist ** 2 + (self.V2I_H_BS - self.V2I_H_MS) ** 2) / 1000)
 
     def renew_channel(self):

@@ -38,6 +38,19 @@ def start_env(n_links=None):
     return env
 
 
+def start_env_batched(n_links, n_envs, seed):
+    """E environments on the same lane grid, environment e seeded with seed + 104729 e (rl/batched_env.py)."""
+    from .batched_env import BatchedEnviron
+    up_lanes = [3.5 / 2, 3.5 / 2 + 3.5, 250 + 3.5 / 2, 250 + 3.5 + 3.5 / 2, 500 + 3.5 / 2, 500 + 3.5 + 3.5 / 2]
+    down_lanes = [250 - 3.5 - 3.5 / 2, 250 - 3.5 / 2, 500 - 3.5 - 3.5 / 2, 500 - 3.5 / 2, 750 - 3.5 - 3.5 / 2, 750 - 3.5 / 2]
+    left_lanes = [3.5 / 2, 3.5 / 2 + 3.5, 433 + 3.5 / 2, 433 + 3.5 + 3.5 / 2, 866 + 3.5 / 2, 866 + 3.5 + 3.5 / 2]
+    right_lanes = [433 - 3.5 - 3.5 / 2, 433 - 3.5 / 2, 866 - 3.5 - 3.5 / 2, 866 - 3.5 / 2, 1299 - 3.5 - 3.5 / 2, 1299 - 3.5 / 2]
+    env = BatchedEnviron(down_lanes, up_lanes, left_lanes, right_lanes, 750, 1299, n_envs=n_envs,
+                         seeds=[seed + 104729 * e for e in range(n_envs)])
+    env.new_random_game(n_links)
+    return env
+
+
 def run_train(env, cfg, brain=None, save_dir=None, verbose=False, **brain_kwargs):
     """RL_Train_main.py:98-118"""
     agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, cfg.Num_Feedback, env, cfg, brain=brain, **brain_kwargs)
@@ -56,6 +69,8 @@ def main(argv=None):
     ap.add_argument("--seed", type=int, default=1001)           # RL_Train_main.py:44
     ap.add_argument("--save-dir", default=None)
     ap.add_argument("--use-graph", action="store_true")
+    ap.add_argument("--envs", type=int, default=0,
+                    help="step this many independent simulators as arrays (rl/batched_env.py) instead of one")
     ap.add_argument("--rollouts", choices=["replicated", "sharded"], default="replicated",
                     help="data-parallel runs: every rank steps the same simulator (bit-identical to one process) or every "
                          "rank its own, contributing 50/G transitions per train step (Agent docstring)")
@@ -84,7 +99,8 @@ def main(argv=None):
     cfg = RL_Config()
     cfg.set_train_value(args.feedback, args.gamma, args.batch, 1, 0.1)       # RL_Train_main.py:33-35,60
     cfg.Num_Episodes, cfg.Num_Train_Steps = args.episodes, args.train_steps
-    env = start_env(args.links)
+    env = (start_env_batched(args.links, args.envs, args.seed + (7919 * rank if sharded else 0)) if args.envs > 0
+           else start_env(args.links))
     t0 = time.perf_counter()
     import contextlib
     ctx = contextlib.nullcontext()

@@ -1,0 +1,173 @@
+"""CPU: the batched simulator (v2xgnn.rl.BatchedEnviron).  One environment on the process-wide stdlib
+generator reproduces the trajectories captured from the reference Environment.py (tests/golden/golden_env_*.npz) like the
+single simulator does; environment e of a seeded batch IS the single simulator run after random.seed(seeds[e])."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from v2xgnn.rl import Environ, BatchedEnviron
+from v2xgnn.rl.mtstream import MTStream
+from test_rl_env import make_env
+from util import GOLDEN
+
+UP = [3.5 / 2, 3.5 / 2 + 3.5, 250 + 3.5 / 2, 250 + 3.5 + 3.5 / 2, 500 + 3.5 / 2, 500 + 3.5 + 3.5 / 2]
+DOWN = [250 - 3.5 - 3.5 / 2, 250 - 3.5 / 2, 500 - 3.5 - 3.5 / 2, 500 - 3.5 / 2, 750 - 3.5 - 3.5 / 2, 750 - 3.5 / 2]
+LEFT = [3.5 / 2, 3.5 / 2 + 3.5, 433 + 3.5 / 2, 433 + 3.5 + 3.5 / 2, 866 + 3.5 / 2, 866 + 3.5 + 3.5 / 2]
+RIGHT = [433 - 3.5 - 3.5 / 2, 433 - 3.5 / 2, 866 - 3.5 - 3.5 / 2, 866 - 3.5 / 2, 1299 - 3.5 - 3.5 / 2, 1299 - 3.5 / 2]
+
+
+def make_batched(n_envs=1, seeds=None):
+    env = BatchedEnviron(DOWN, UP, LEFT, RIGHT, 750, 1299, n_envs=n_envs, seeds=seeds)
+    env.new_random_game(env.n_Veh)
+    return env
+
+
+def test_mtstream_is_the_stdlib_generator():
+    for seed in (0, 1001, 2 ** 40 + 5):
+        r, s = random.Random(seed), MTStream(seed)
+        for _ in range(3):
+            assert r.random() == s.random() and r.uniform(0, 1) == s.uniform(0, 1)
+            assert [r.randint(10, 15) for _ in range(20)] == [s.randint(10, 15) for _ in range(20)]
+            assert [r.randrange(0, 6) for _ in range(20)] == [s.randrange(0, 6) for _ in range(20)]
+            assert [r.randint(0, 1299) for _ in range(20)] == [s.randint(0, 1299) for _ in range(20)]
+            assert np.array_equal([r.gauss(0, 3) for _ in range(7)], s.gauss_array((7,), 3))          # odd: caches a value
+            assert np.array_equal([r.gauss(0, 1) for _ in range(8)], s.gauss_array((2, 4), 1).ravel())
+            assert r.sample(list(range(17)), 1) == s.sample(list(range(17)), 1)                         # pool method
+            assert r.sample(list(range(97)), 1) == s.sample(list(range(97)), 1)                         # rejection set
+            assert r.sample(list(range(40)), 7) == s.sample(list(range(40)), 7)
+        r2 = random.Random()
+        s.return_stdlib(r2)
+        assert r2.random() == r.random() and r2.gauss(0, 1) == r.gauss(0, 1)
+
+
+@pytest.mark.parametrize("n_veh", [4, 20])
+def test_one_batched_environment_matches_reference_trajectory(n_veh):
+    g = np.load(os.path.join(GOLDEN, 'golden_env_n%d.npz' % n_veh))
+    random.seed(2020 + n_veh)
+    np.random.seed(2020 + n_veh)
+    env = make_batched()
+    if n_veh != env.n_Veh:
+        env.new_random_game(n_veh)
+    assert np.array_equal(env.pos[0], g['init_pos']) and env.directions(0) == list(g['init_dir'])
+    assert np.array_equal(env.vel[0], g['velocity']) and np.array_equal(env.dest[0], g['init_dest'])
+    assert np.allclose(env.V2V_channels_with_fastfading[0], g['init_v2v'], rtol=1e-11, atol=1e-9)
+    assert np.allclose(env.V2I_channels_with_fastfading[0], g['init_v2i'], rtol=1e-11, atol=1e-9)
+    for t in range(int(g['steps'])):
+        a = np.random.randint(0, env.n_RB, size=(n_veh, 1))
+        v2v_rate, v2i_rate, interference = env.act(a[None])
+        assert np.allclose(v2v_rate[0], g['v2v_rate'][t], rtol=1e-9, atol=1e-12), t
+        assert np.allclose(v2i_rate[0], g['v2i_rate'][t], rtol=1e-9, atol=1e-12), t
+        assert np.allclose(interference[0], g['interference'][t], rtol=1e-9, atol=0), t
+        assert np.array_equal(env.pos[0], g['pos'][t]), t
+        assert env.directions(0) == list(g['dirs'][t])
+        assert np.allclose(env.V2V_channels_with_fastfading[0], g['v2v'][t], rtol=1e-11, atol=1e-9), t
+        assert np.allclose(env.V2I_channels_with_fastfading[0], g['v2i'][t], rtol=1e-11, atol=1e-9), t
+        assert np.allclose(env.V2V_Interference_all[0], g['v2v_interference_all'][t], rtol=1e-10, atol=1e-9), t
+
+
+def _agent_observe(env):
+    """Agent.observe on a single simulator (v2xgnn.rl.Agent, same arithmetic as BS_brain.py:389-467)."""
+    from v2xgnn.rl import Agent, RL_Config
+    import types
+    brain = types.SimpleNamespace(num_D2D_Input=0, num_One_D2D_Input=13, num_One_Node_Input=9, num_Feedback=16)
+    agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, 16, env, RL_Config(), brain=brain, device_replay=False)
+    return agent.observe()
+
+
+@pytest.mark.parametrize("n_veh,steps", [(4, 300), (20, 60)])
+def test_every_environment_of_a_batch_is_the_seeded_single_simulator(n_veh, steps):
+    seeds = [11, 12, 1001]
+    batch = make_batched(n_envs=3, seeds=seeds)
+    batch.new_random_game(n_veh)
+    singles = []
+    for s in seeds:
+        random.seed(s)
+        env = make_env()
+        env.new_random_game(n_veh)
+        singles.append((env, random.getstate()))
+    rng = np.random.default_rng(5)
+    turned = 0
+    for t in range(steps):
+        a = rng.integers(0, 4, size=(3, n_veh, 1))
+        sb, ab = batch.observe()
+        rb = batch.act(a)
+        for e, (env, st) in enumerate(singles):
+            random.setstate(st)                               # each single simulator continues ITS stdlib stream
+            s1, a1 = _agent_observe(env)
+            assert np.allclose(sb[e], s1, rtol=1e-12, atol=1e-12) and np.array_equal(ab[e], a1)
+            v2v, v2i, intf = env.compute_reward_with_channel_selection(a[e].copy())
+            before = [v.direction for v in env.vehicles]
+            env.renew_positions()
+            env.renew_channels_fastfading()
+            env.Compute_Interference(a[e].copy())
+            turned += sum(b != v.direction for b, v in zip(before, env.vehicles))
+            singles[e] = (env, random.getstate())
+            assert np.array_equal(batch.pos[e], np.array([v.position for v in env.vehicles], float)), (t, e)
+            assert batch.directions(e) == [v.direction for v in env.vehicles]
+            assert np.array_equal(batch.dest[e], [v.destinations[0] for v in env.vehicles])
+            assert np.allclose(batch.V2V_channels_with_fastfading[e], env.V2V_channels_with_fastfading, rtol=1e-13, atol=1e-11)
+            assert np.allclose(rb[0][e], v2v, rtol=1e-10, atol=1e-13) and np.allclose(rb[1][e], v2i, rtol=1e-10, atol=1e-13)
+            assert np.allclose(rb[2][e], intf, rtol=1e-10, atol=0)
+            assert np.allclose(batch.V2V_Interference_all[e], env.V2V_Interference_all, rtol=1e-11, atol=1e-10)
+    if n_veh == 4:
+        assert turned > 0                                     # the run really crossed lanes (RNG draws in renew_positions)
+    # the streams end where the single simulators' stdlib generators end
+    for e, (env, st) in enumerate(singles):
+        r = random.Random()
+        r.setstate(st)
+        assert batch.streams[e].random() == r.random()
+
+
+def _rollout_and_replay(env, seed):
+    """40 transitions + one replay with the recording fake brain: the memory and the exact fit payload"""
+    from v2xgnn.rl import Agent, RL_Config
+    from test_rl_agent import RecordingBrain
+    np.random.seed(seed)
+    cfg = RL_Config()
+    cfg.set_train_value(16, 0.5, 32, 1, 0.1)
+    brain = RecordingBrain(4, 3, 1, 16, 1, 4)
+    agent = Agent(4, 4, 1, 16, env, cfg, brain=brain, device_replay=False)
+    agent.num_Episodes, agent.num_Train_Step, agent.num_transition = 1, 2, 40
+    agent.num_step = 20                                        # mid-schedule: both random and greedy actions occur
+    rewards = agent.generate_d2d_transition(40)
+    agent.replay()
+    mem = agent.memory.samples
+    return rewards, mem, brain.fits[0], len(brain.predicts), agent.num_step
+
+
+def test_agent_on_one_batched_environment_equals_agent_on_the_single_simulator():
+    random.seed(31)
+    r1, m1, f1, p1, n1 = _rollout_and_replay(make_env(), 8)
+    random.seed(31)
+    r2, m2, f2, p2, n2 = _rollout_and_replay(make_batched(), 8)
+    assert np.allclose(r1, r2, rtol=1e-10, atol=0) and p1 == p2 and n1 == n2 == 60 and len(m1) == len(m2) == 40
+    for a, b in zip(m1, m2):
+        assert np.allclose(a[0], b[0], rtol=1e-11, atol=1e-12) and np.array_equal(a[1], b[1])
+        assert np.isclose(a[2], b[2], rtol=1e-10) and np.allclose(a[3], b[3], rtol=1e-11, atol=1e-12)
+    (x1, y1, _), (x2, y2, _) = f1, f2
+    for k in x1:
+        assert np.allclose(x1[k], x2[k], rtol=1e-11, atol=1e-12), k
+    for k in y1:
+        assert np.allclose(y1[k], y2[k], rtol=1e-6, atol=1e-7), k
+
+
+def test_agent_training_loop_on_a_batch_of_environments():
+    """Agent.train on 4 simulators stepped as arrays (engine injected: the oracle): 52 = ceil(50 / 4) x 4 transitions per
+    train step, greedy environments share one forward pass, losses finite, the loop trains."""
+    from v2xgnn import BS
+    from v2xgnn.rl import Agent, RL_Config
+    from oracle_engine import OracleEngine
+    np.random.seed(3)
+    cfg = RL_Config()
+    cfg.set_train_value(16, 0.5, 32, 1, 0.1)
+    env = make_batched(4, seeds=[1, 2, 3, 4])
+    brain = BS(4, 3, 1, 16, 1, 4, seed=3, engine_factory=lambda spec: OracleEngine(spec))
+    w0 = np.concatenate([a.ravel() for a in brain.model.get_weights()])
+    agent = Agent(4, 4, 1, 16, env, cfg, brain=brain)
+    loss, reward_step, _, q_mean, q_max, _, _ = agent.train(1, 3)
+    assert agent.num_transition == 52 and agent.num_step == 156 and len(agent.memory.samples) == 156
+    assert reward_step.shape == (1, 3, 52) and np.all(np.isfinite(reward_step)) and np.all(reward_step > 0)
+    assert np.all(np.isfinite(loss)) and np.all(q_max >= q_mean - 1e-12)
+    assert not np.allclose(w0, np.concatenate([a.ravel() for a in brain.model.get_weights()]))

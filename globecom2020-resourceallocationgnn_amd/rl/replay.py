@@ -6,9 +6,13 @@ torch tensors own the memory; every data movement on the device is one of the C-
 `v2x_gather_rows` / `v2x_dqn_targets` (include/v2xgnn.h).  Sampling indices still come from the caller's numpy RNG
 (same draws as `Memory.sample`), 4 bytes per sampled transition.
 
-Layout per transition (n links, E = edges of the graph, constant per memory -- the reference topology has in-degree
-n-2 for every link):  xe[n][16] of s, xe'[n][16] of s', col_idx[E] (CSR by destination, graph-local sources),
-action[n] int32, reward double.  New transitions are staged on the host and flushed in one copy per tensor before
+Layout per transition (n links):  xe[n][16] of s, xe'[n][16] of s', the adjacency as one source bit mask per link
+(mask[n] int32, bit p of mask[q] = edge p -> q), action[n] int32, reward double -- and, for the regular case, the
+ready-made CSR columns col_idx[E].  The reference topology gives every link the in-degree n-2 (self and own receiver
+excluded, BS_brain.py:441-445), so a gathered minibatch is CSR with a constant row pointer and the gathered col_idx
+rows as is.  The simulator can, rarely, make a link its own receiver (two vehicles on the same spot: the distance sort
+of Environment.py:365-375 then puts the other one first); such transitions have in-degree n-1 and a minibatch that
+contains one is expanded from the masks instead (torch ops, variable edge count).  New transitions are staged on the host and flushed in one copy per tensor before
 the next sample (the reference stores 50 transitions between replays, BS_brain.py:758).
 """
 import ctypes as C
@@ -33,6 +37,7 @@ class DeviceReplay(object):
         self._stage = []
         self._row_ptr = {}
         self._bufs = {}
+        self._regular = np.ones(0, bool)       # host-side: slot holds a graph with in-degree n-2 everywhere
 
     # ------------------------------------------------------------------ storage
     def _grow(self, need):
@@ -50,21 +55,28 @@ class DeviceReplay(object):
         self.xe = grow(None if first else self.xe, (n, 16), torch.float32)
         self.xe_next = grow(None if first else self.xe_next, (n, 16), torch.float32)
         self.col = grow(None if first else self.col, (max(E, 1),), torch.int32)
+        self.mask = grow(None if first else self.mask, (n,), torch.int32)
+        reg = np.ones(new, bool)
+        reg[:self._alloc] = self._regular[:self._alloc]
+        self._regular = reg
         self.action = grow(None if first else self.action, (n,), torch.int32)
         self.reward = grow(None if first else self.reward, (), torch.float64)
         self._alloc = new
 
     def add(self, x, e, adj, action, reward, x_next, e_next):
         """x, x_next [n, Dn]; e, e_next [n, De]; adj [n, n] (Adj[p, q] = 1: p sends to q); action [n]; reward scalar."""
-        row_ptr, col, _ = adj_to_csr(np.asarray(adj)[None])
+        adj = np.asarray(adj)
+        if self.n > 31:
+            raise ValueError("DeviceReplay keeps the adjacency as one 32-bit source mask per link: at most 31 links")
+        row_ptr, col, _ = adj_to_csr(adj[None])
         if self.n_edges is None:
-            self.n_edges = int(col.shape[0])
-        if col.shape[0] != self.n_edges or np.any(np.diff(row_ptr) != self.n_edges // max(self.n, 1)):
-            raise ValueError("DeviceReplay needs the same in-degree for every link of every transition "
-                             "(reference topology: n-2); got a graph with %d edges" % col.shape[0])
+            self.n_edges = self.n * (self.n - 2)
+        regular = col.shape[0] == self.n_edges and not np.any(np.diff(row_ptr) != self.n - 2)
+        mask = ((adj != 0).astype(np.int64) << np.arange(self.n, dtype=np.int64)[:, None]).sum(axis=0).astype(np.int32)   # [q]: bits p
+        colrow = col.astype(np.int32) if regular else np.zeros(max(self.n_edges, 1), np.int32)
         self._stage.append((pack_xe(np.asarray(x, np.float32), np.asarray(e, np.float32)),
                             pack_xe(np.asarray(x_next, np.float32), np.asarray(e_next, np.float32)),
-                            col.astype(np.int32), np.asarray(action, np.int32).reshape(-1), float(reward)))
+                            colrow, np.asarray(action, np.int32).reshape(-1), float(reward), mask, regular))
 
     def __len__(self):
         return min(self.capacity, self.size + len(self._stage))
@@ -78,12 +90,15 @@ class DeviceReplay(object):
         self._grow(min(self.capacity, self.size + k))
         cols = [np.stack([s[i] for s in self._stage]) for i in range(4)]
         cols.append(np.array([s[4] for s in self._stage], np.float64))
-        dst = (self.xe, self.xe_next, self.col, self.action, self.reward)
+        cols.append(np.stack([s[5] for s in self._stage]))
+        regular = np.array([s[6] for s in self._stage], bool)
+        dst = (self.xe, self.xe_next, self.col, self.action, self.reward, self.mask)
         pos, done = self.head, 0
         while done < k:
             m = min(k - done, self._alloc - pos)
             for t, a in zip(dst, cols):
                 t[pos:pos + m].copy_(torch.from_numpy(np.ascontiguousarray(a[done:done + m])))
+            self._regular[pos:pos + m] = regular[done:done + m]
             pos, done = pos + m, done + m
             if pos == self.capacity:                   # full ring: overwrite the oldest transitions
                 pos = 0
@@ -123,14 +138,23 @@ class DeviceReplay(object):
         self.flush()
         torch = self.torch
         k = len(idx)
-        idx_dev = torch.from_numpy(self.logical_to_slot(idx)).to(self.device)
+        slots = self.logical_to_slot(idx)
+        idx_dev = torch.from_numpy(slots).to(self.device)
         xe = self._gather(self.xe, idx_dev, k, 'xe').view(k * self.n, 16)
         xe_next = self._gather(self.xe_next, idx_dev, k, 'xe_next').view(k * self.n, 16)
-        col = self._gather(self.col, idx_dev, k, 'col').view(-1)
         action = self._gather(self.action, idx_dev, k, 'action')
         reward = self._gather(self.reward, idx_dev, k, 'reward')
-        rp = self.row_ptr(k)
-        mk = lambda t: DeviceBatch.from_tensors(k, self.n, t, rp, col, self.n_edges)
+        if self._regular[slots].all():                             # every sampled graph has in-degree n-2: CSR as stored
+            col = self._gather(self.col, idx_dev, k, 'col').view(-1)
+            rp, max_edges = self.row_ptr(k), self.n_edges
+        else:                                                      # expand the source masks (ascending sources per row)
+            masks = self._gather(self.mask, idx_dev, k, 'mask')                                  # [k, n(q)]
+            bits = ((masks[:, :, None] >> torch.arange(self.n, device=self.device, dtype=torch.int32)) & 1).bool()
+            col = bits.nonzero()[:, 2].to(torch.int32).contiguous()                               # (graph, q, p) order
+            rp = torch.zeros(k * self.n + 1, dtype=torch.int32, device=self.device)
+            rp[1:] = torch.cumsum(bits.sum(dim=2).view(-1), 0).to(torch.int32)
+            max_edges = self.n * (self.n - 1)
+        mk = lambda t: DeviceBatch.from_tensors(k, self.n, t, rp, col, max_edges)
         return mk(xe), mk(xe_next), action, reward
 
     def target_buffer(self, k, n_channels):

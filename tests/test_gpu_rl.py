@@ -209,3 +209,40 @@ def test_device_replay_index_sharding_sums_to_the_full_batch_gradient():
     assert_grad_close(parts[0] + parts[1], full.grad, "sum of the two ranks' gradients")
     tot = (stats[0] + stats[1]) / 64
     assert np.allclose(tot[0], qm_full, rtol=1e-5) and np.allclose(tot[1], qx_full, rtol=1e-5)
+
+
+def test_device_replay_handles_a_link_that_is_its_own_receiver():
+    """Two vehicles on one spot can make a link its own receiver (Environment.py:365-375): in-degree n-1 instead of
+    n-2.  Minibatches containing such a transition are expanded from the per-link source masks; the CSR must equal the
+    host packer's and the forward pass must agree with the host path."""
+    import torch
+    from v2xgnn import GnnSpec, GnnEngine, PackedBatch
+    from v2xgnn.packing import adj_to_csr
+    from v2xgnn.rl.replay import DeviceReplay
+    from oracle import compact as oc
+    from util import f32_params
+    rng = np.random.default_rng(4)
+    n = 8
+    rep = DeviceReplay(64, n)
+    log = []
+    for i in range(20):
+        adj = np.ones((n, n)) - np.eye(n)
+        for q in range(n):
+            adj[(q + 1 + i) % n if (q + 1 + i) % n != q else (q + 2) % n, q] = 0
+        if i in (5, 11):
+            adj[:, 3] = 1
+            adj[3, 3] = 0                                     # link 3 is its own receiver: in-degree n-1
+        x, e = rng.normal(size=(n, 9)), rng.normal(size=(n, 4))
+        rep.add(x, e, adj, rng.integers(0, 4, size=n), 0.5, x + 1, e)
+        log.append((x, e, adj))
+    for idx in (np.array([0, 1, 2, 7]), np.array([4, 5, 6, 11, 11, 19])):
+        sb, sb_next, action, reward = rep.sample(idx)
+        xs, es, adjs = (np.stack([log[i][j] for i in idx]) for j in range(3))
+        ref = PackedBatch.from_dense(xs, es, adjs)
+        assert np.array_equal(sb.row_ptr.cpu().numpy(), ref.row_ptr) and np.array_equal(sb.col_idx.cpu().numpy()[:ref.n_edges], ref.col_idx)
+        assert sb.n_edges == ref.n_edges and sb.max_edges >= ref.max_edges
+        spec = GnnSpec(n_nodes=n, feat_dim=16)
+        eng = GnnEngine(spec)
+        eng.set_weights(oc.params_to_list(f32_params(spec, np.random.default_rng(1))))
+        assert np.array_equal(eng.forward(sb).cpu().numpy(), eng.forward(ref))
+        eng.close()

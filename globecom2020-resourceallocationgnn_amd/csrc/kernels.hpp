@@ -43,28 +43,43 @@ __device__ __forceinline__ int real_row(const RowPad& p, int rp) {
 // Compile-time shape => constant divisors, fully unrolled; every global load is unconditional from an
 // always-valid address (masked in registers afterwards) so that all PASSES loads are in flight at once:
 // a conditional load makes hipcc branch around each one and serialises the L2 round trips.
-template <int KP, int NP, int LD>
-__device__ __forceinline__ void fill_weight_image(float* sW, const float* Wg, RowPad pad, int n_real) {
+template <int KP, int NP>
+struct WeightImageRegs { float4 v[(KP * (NP / 4) + 255) / 256]; };
+
+// the two halves of the copy, so that a caller with several images can have ALL their loads in flight together
+template <int KP, int NP>
+__device__ __forceinline__ void weight_image_load(WeightImageRegs<KP, NP>& r, const float* Wg, RowPad pad, int n_real, int tid) {
   constexpr int C4 = NP / 4;
   constexpr int TOTAL = KP * C4;
   constexpr int PASSES = (TOTAL + 255) / 256;
-  float4 v[PASSES];
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
-    const int i = threadIdx.x + 256 * p;
+    const int i = tid + 256 * p;
     const int rp = i / C4, c = (i - rp * C4) << 2;
     const int rr = real_row(pad, rp);
     const bool ok = i < TOTAL && rr >= 0 && c < n_real;
     const float4 t = *reinterpret_cast<const float4*>(Wg + (ok ? (int64_t)rr * n_real + c : 0));
     const float mk = ok ? 1.f : 0.f;
-    v[p] = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
+    r.v[p] = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
   }
+}
+template <int KP, int NP, int LD>
+__device__ __forceinline__ void weight_image_store(float* sW, const WeightImageRegs<KP, NP>& r, int tid) {
+  constexpr int C4 = NP / 4;
+  constexpr int TOTAL = KP * C4;
+  constexpr int PASSES = (TOTAL + 255) / 256;
 #pragma unroll
   for (int p = 0; p < PASSES; ++p) {
-    const int i = threadIdx.x + 256 * p;
+    const int i = tid + 256 * p;
     const int rp = i / C4, c = (i - rp * C4) << 2;
-    if (i < TOTAL) *reinterpret_cast<float4*>(sW + rp * LD + c) = v[p];
+    if (i < TOTAL) *reinterpret_cast<float4*>(sW + rp * LD + c) = r.v[p];
   }
+}
+template <int KP, int NP, int LD>
+__device__ __forceinline__ void fill_weight_image(float* sW, const float* Wg, RowPad pad, int n_real) {
+  WeightImageRegs<KP, NP> r;
+  weight_image_load<KP, NP>(r, Wg, pad, n_real, threadIdx.x);
+  weight_image_store<KP, NP, LD>(sW, r, threadIdx.x);
 }
 __device__ __forceinline__ void fill_bias(float* sB, int np, const float* bg, int n_real) {
   for (int i = threadIdx.x; i < np; i += blockDim.x) sB[i] = i < n_real ? bg[i] : 0.f;
@@ -555,7 +570,7 @@ struct MlpLds {
 };
 
 template <int F>
-__device__ __forceinline__ void mlp_fill_lds(float* smem, const MlpArgs& a, int slot, bool with_bias) {
+__device__ __forceinline__ void mlp_fill_lds(float* smem, const MlpArgs& a, int slot, bool with_bias, int ti) {
   using L = MlpLds<F>;
   const int C = a.C;
   const float* w1 = a.W[0] + slot * a.slot_stride[0];
@@ -566,16 +581,32 @@ __device__ __forceinline__ void mlp_fill_lds(float* smem, const MlpArgs& a, int 
   // Dense-0 rows [h(F) | x(2C+1) | agg(F)]: the image keeps xe's 16 columns; the edge-feature
   // and pad rows are ZERO so the packed xe block can be used as-is (BS_brain.py:175 feeds
   // only the node features to the decision DNN).
-  if constexpr (F > 0)
-    fill_weight_image<L::K1P, H1, LD1>(smem + L::W1, w1, RowPad{F + 2 * C + 1, XE - (2 * C + 1), k1}, H1);
-  fill_weight_image<H1, H2P, LD2>(smem + L::W2, w2, RowPad{H1, 0, H1}, H2);
-  fill_weight_image<H2P, H3P, LD3>(smem + L::W3, w3, RowPad{H2, H2P - H2, H2}, H3);
-  fill_weight_image<H3P, CP, LD4>(smem + L::W4, w4, RowPad{H3, H3P - H3, H3}, C);
+  // all four images' loads are issued before the first LDS store (measured: the four fills one after the other, each a
+  // dependent L2 round trip, took 9 us of every MLP launch)
+  WeightImageRegs<(F > 0 ? L::K1P : 16), H1> r1;
+  WeightImageRegs<H1, H2P> r2;
+  WeightImageRegs<H2P, H3P> r3;
+  WeightImageRegs<H3P, CP> r4;
+  if constexpr (F > 0) weight_image_load<L::K1P, H1>(r1, w1, RowPad{F + 2 * C + 1, XE - (2 * C + 1), k1}, H1, ti);
+  weight_image_load<H1, H2P>(r2, w2, RowPad{H1, 0, H1}, H2, ti);
+  weight_image_load<H2P, H3P>(r3, w3, RowPad{H2, H2P - H2, H2}, H3, ti);
+  weight_image_load<H3P, CP>(r4, w4, RowPad{H3, H3P - H3, H3}, C, ti);
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (with_bias) {                          // one bias value per thread and layer (widths <= 80 < 256 threads)
+    if constexpr (F > 0) bv[0] = w1[(int64_t)k1 * H1 + min(ti, H1 - 1)];
+    bv[1] = w2[H1 * H2 + min(ti, H2 - 1)];
+    bv[2] = w3[H2 * H3 + min(ti, H3 - 1)];
+    bv[3] = w4[H3 * C + min(ti, C - 1)];
+  }
+  if constexpr (F > 0) weight_image_store<L::K1P, H1, LD1>(smem + L::W1, r1, ti);
+  weight_image_store<H1, H2P, LD2>(smem + L::W2, r2, ti);
+  weight_image_store<H2P, H3P, LD3>(smem + L::W3, r3, ti);
+  weight_image_store<H3P, CP, LD4>(smem + L::W4, r4, ti);
   if (with_bias) {
-    if constexpr (F > 0) fill_bias(smem + L::B1, H1, w1 + (int64_t)k1 * H1, H1);
-    fill_bias(smem + L::B2, H2P, w2 + H1 * H2, H2);
-    fill_bias(smem + L::B3, H3P, w3 + H2 * H3, H3);
-    fill_bias(smem + L::B4, CP, w4 + H3 * C, C);
+    if constexpr (F > 0) { if (ti < H1) smem[L::B1 + ti] = bv[0]; }
+    if (ti < H2P) smem[L::B2 + ti] = ti < H2 ? bv[1] : 0.f;
+    if (ti < H3P) smem[L::B3 + ti] = ti < H3 ? bv[2] : 0.f;
+    if (ti < CP) smem[L::B4 + ti] = ti < C ? bv[3] : 0.f;
   }
 }
 
@@ -741,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fwd(MlpArgs a) {
 
   MlpFwdIn<F> inA, inB;
   V2X_TILE_PROLOGUE(blockIdx.x * per + wv, t_end, inA, load_in)
-  mlp_fill_lds<F>(smem, a, slot, true);
+  mlp_fill_lds<F>(smem, a, slot, true, threadIdx.x);
   __syncthreads();
   V2X_TILE_LOOP(inA, inB, load_in, compute)
 }
@@ -853,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd(MlpArgs a) {
 
   MlpBwdIn<F> inA, inB;
   V2X_TILE_PROLOGUE(blockIdx.x * per + wv, t_end, inA, load_in)
-  mlp_fill_lds<F>(smem, a, slot, false);
+  mlp_fill_lds<F>(smem, a, slot, false, threadIdx.x);
   __syncthreads();
   V2X_TILE_LOOP(inA, inB, load_in, compute)
 }
@@ -1002,7 +1033,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_train(MlpArgs a) {
 
   MlpTrainIn<F> inA, inB;
   V2X_TILE_PROLOGUE(blockIdx.x * per + wv, t_end, inA, load_in)
-  mlp_fill_lds<F>(smem, a, slot, true);
+  mlp_fill_lds<F>(smem, a, slot, true, threadIdx.x);
   __syncthreads();
   V2X_TILE_LOOP(inA, inB, load_in, compute)
 }

@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include "kernels_wide.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_mlpwg.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -191,6 +192,7 @@ void set_attrs_f() {
   allow_big_lds((const void*)k_mlp_fwd<F>);
   allow_big_lds((const void*)k_mlp_bwd<F>);
   allow_big_lds((const void*)k_mlp_train<F>);
+  allow_big_lds((const void*)k_mlp_train_wg<F>);
   allow_big_lds((const void*)k_wgrad<F, 0>);
   allow_big_lds((const void*)k_wgrad<F, 1>);
   allow_big_lds((const void*)k_wgrad<F, 2>);
@@ -782,6 +784,61 @@ int launch_mlp_train(v2x_model* m, hipStream_t st, MlpArgs& a) {
   FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
 }
 
+// ... and with the four Dense weight gradients in the same pass (kernels_mlpwg.hpp): one workgroup per CU, each
+// writes one partial-sum slab of the Dense layers
+bool mlp_wg_path(const v2x_model* m) {
+  static const bool off = env_int("V2X_MLP_WG", 1) == 0;
+  return !off && mlp_fused_training(m);
+}
+
+// work split of k_mlp_train_wg (MlpWgArgs): one workgroup per CU, equal shares of the slot-major tile list
+struct MlpWgSplit { int tiles_per_slot, slot_span, tiles_per_wg, n_wgs, n_slabs; };
+MlpWgSplit mlp_wg_split(int n_idx, int n_slots) {
+  MlpWgSplit s;
+  const int T = (n_idx + 15) / 16, cus = n_cus();
+  s.tiles_per_slot = T;
+  auto up4 = [](int v) { return (v + 3) / 4 * 4; };          // whole rounds of the 4 waves
+  // whole workgroups per slot (see MlpWgArgs for the packed alternative that was tried)
+  int gx = std::max(1, std::min(cus / std::max(n_slots, 1), (T + 3) / 4));
+  const int qa = up4((T + gx - 1) / gx);
+  gx = (T + qa - 1) / qa;
+  s.slot_span = gx * qa; s.tiles_per_wg = qa;
+  s.n_wgs = gx * n_slots;
+  s.n_slabs = gx;
+  return s;
+}
+
+template <int F>
+int launch_mlp_train_wg_f(v2x_model* m, hipStream_t st, const MlpArgs& a, int n_slots) {
+  const size_t lds = (size_t)MlpWgLds<F>::TOTAL * 4;
+  const MlpWgSplit sp = mlp_wg_split(a.n_idx, n_slots);
+  if (sp.n_slabs > m->slab_cap) FAIL(m, V2X_ESTATE, "mlp_train_wg: slabs not pre-sized (%d > %d)", sp.n_slabs, m->slab_cap);
+  MlpTrainWgArgs t;
+  memset(&t, 0, sizeof(t));
+  t.a = a;
+  t.w.slab = m->slab; t.w.slab_stride = m->P;
+  t.w.tiles_per_slot = sp.tiles_per_slot; t.w.slot_span = sp.slot_span; t.w.tiles_per_wg = sp.tiles_per_wg; t.w.n_slots = n_slots; t.w.n_slabs = sp.n_slabs;
+  t.w.ts = m->ts_buf ? m->ts_buf + 2 * 8 * 64 : nullptr;
+  for (int i = 0; i < 4; ++i) {
+    LayerDesc& ld = m->dense[i];
+    ld.n_slabs = sp.n_slabs;              // remembered for the slab reduction
+    t.w.l[i] = MlpWgLayer{ld.off, ld.slot_stride, ld.n_out, ld.pad};
+  }
+  auto k = k_mlp_train_wg<F>;
+  LAUNCH(m, "k_mlp_train_wg", k, dim3(sp.n_wgs), lds, st, t);
+  return V2X_OK;
+}
+
+int launch_mlp_train_wg(v2x_model* m, hipStream_t st, const MlpArgs& a) {
+  const int gy = m->S == 1 ? 1 : m->N;
+  switch (m->F) {
+    case 16: return launch_mlp_train_wg_f<16>(m, st, a, gy);
+    case 32: return launch_mlp_train_wg_f<32>(m, st, a, gy);
+    case 64: return launch_mlp_train_wg_f<64>(m, st, a, gy);
+  }
+  FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
+}
+
 int launch_mlp(v2x_model* m, hipStream_t st, MlpArgs& a, bool bwd) {
   const int gy = m->S == 1 ? 1 : m->N;
   if (is_wide(m)) {
@@ -1177,11 +1234,13 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
   a.y = y_dev;
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
-  if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
+  const bool mlp_wg = mlp_wg_path(m);      // the Dense weight gradients come out of the MLP launch itself
+  if (mlp_wg) CHK(launch_mlp_train_wg(m, st, a));
+  else if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
   else CHK(launch_mlp(m, st, a, true));
-  const bool merged = !two && wgrad_all_fits(m) && env_int("V2X_WG_SPLIT", 0) == 0;
+  const bool merged = !mlp_wg && !two && wgrad_all_fits(m) && env_int("V2X_WG_SPLIT", 0) == 0;
   CHK(fork());
-  if (!merged) CHK(wgrad_mlp(m, sw, x, d.xe, m->h[L], m->a[L]));        // 4 Dense layers, one launch (side stream if two)
+  if (!merged && !mlp_wg) CHK(wgrad_mlp(m, sw, x, d.xe, m->h[L], m->a[L]));        // 4 Dense layers, one launch (side stream if two)
   // V2X_WG_PER_STAGE=1: every GNN stage's weight gradient goes to the side stream as soon as its dpre exists
   // (overlaps the remaining agg/dgrad chain) instead of one fused launch after the chain
   static const bool per_stage = env_int("V2X_WG_PER_STAGE", 0) != 0;
@@ -1296,6 +1355,7 @@ int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), 768})
     nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
   if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 1, n_slots));     // the fewest tiles (one) split most
+  else nc = std::max(nc, mlp_wg_split(n_idx, n_slots).n_slabs);         // k_mlp_train_wg: one slab per workgroup and slot
   return nc + 1;
 }
 
@@ -1382,8 +1442,8 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     m->pk_stale = true;             // first forward packs whatever the parameters are by then
   }
   if (m->pk_fwd && env_int("V2X_FUSED_TS", 0)) {
-    if (dev_alloc(m, &m->ts_buf, 2 * 8 * 64)) return fail("allocation");
-    hipMemset(m->ts_buf, 0, 2 * 8 * 64 * 8);
+    if (dev_alloc(m, &m->ts_buf, 3 * 8 * 64)) return fail("allocation");
+    hipMemset(m->ts_buf, 0, 3 * 8 * 64 * 8);
   }
   if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->loss_part, 0, 512) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
@@ -1546,9 +1606,13 @@ int v2x_forward_backward_phase(v2x_model* m, const v2x_batch* b, const float* y,
       mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
       a.y = yd;
       a.inv_denom = 1.0f / loss_denominator(m, n_global);
-      if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
-      else CHK(launch_mlp(m, st, a, true));
-      CHK(wgrad_mlp(m, st, x, d.xe, m->h[L], m->a[L]));
+      if (mlp_wg_path(m)) {
+        CHK(launch_mlp_train_wg(m, st, a));
+      } else {
+        if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
+        else CHK(launch_mlp(m, st, a, true));
+        CHK(wgrad_mlp(m, st, x, d.xe, m->h[L], m->a[L]));
+      }
       return launch_reduce_adam(m, st, 1, false, nullptr, LossJob{0, 0, 0, 0.f, 0}, 0);
     }));
     m->have_fwd = true;
@@ -1715,13 +1779,17 @@ int v2x_mlp_huber_bwd(v2x_model* m, int32_t n_rows, int32_t n_global, const floa
   mlp_args(m, a, x, xe, h, agg);
   a.y = y;
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
-  if (mlp_fused_training(m)) {
-    CHK(launch_mlp_train(m, st, a));
+  if (mlp_wg_path(m)) {
+    CHK(launch_mlp_train_wg(m, st, a));
   } else {
-    CHK(launch_mlp(m, st, a, false));
-    CHK(launch_mlp(m, st, a, true));
+    if (mlp_fused_training(m)) {
+      CHK(launch_mlp_train(m, st, a));
+    } else {
+      CHK(launch_mlp(m, st, a, false));
+      CHK(launch_mlp(m, st, a, true));
+    }
+    CHK(wgrad_mlp(m, st, x, xe, h, agg));
   }
-  CHK(wgrad_mlp(m, st, x, xe, h, agg));
   if (grad_out) CHK(launch_reduce_adam(m, st, 1, false, grad_out));
   if (dh) CHK(copy_cols(m, dh, m->F, m->gha, 2 * m->F, 0, n_rows, st));
   if (dagg) CHK(copy_cols(m, dagg, m->F, m->gha, 2 * m->F, m->F, n_rows, st));
@@ -1812,7 +1880,7 @@ int v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n) {
   if (!m || !out) FAIL(m, V2X_EINVAL, "null argument");
   if (!m->ts_buf) FAIL(m, V2X_ESTATE, "phase stamps need V2X_FUSED_TS=1 when the model is created");
   HIPCHK(m, hipDeviceSynchronize());
-  HIPCHK(m, hipMemcpy(out, m->ts_buf, (size_t)std::min(n, 2 * 8 * 64) * 8, hipMemcpyDeviceToHost));
+  HIPCHK(m, hipMemcpy(out, m->ts_buf, (size_t)std::min(n, 3 * 8 * 64) * 8, hipMemcpyDeviceToHost));
   return V2X_OK;
 }
 

@@ -119,7 +119,7 @@ def test_two_rank_dqn_loop_with_device_replay_on_the_engine():
         w, loss, rew, qm = ret[r]
         assert np.array_equal(rew, rew1)                            # identical rollouts (same weights -> same actions)
         assert np.allclose(loss, loss1, rtol=2e-4, atol=1e-6)
-        assert np.allclose(qm, qm1, rtol=1e-4, atol=1e-6)
+        assert np.allclose(qm, qm1, rtol=1e-3, atol=1e-4)          # (3 fit steps of fp32 rounding differences: the shard sums differ)
         assert np.allclose(w, w1, rtol=1e-3, atol=2e-5)
 
 

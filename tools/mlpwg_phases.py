@@ -1,0 +1,38 @@
+"""Where does k_mlp_train_wg spend its time?  Shader-clock stamps of workgroup (1, 0) (V2X_FUSED_TS=1)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["V2X_FUSED_TS"] = "1"
+import bench  # noqa: E402
+from v2xgnn import GnnSpec, PackedBatch, GnnEngine  # noqa: E402
+
+N, F, B = 20, 64, 4096
+rng = np.random.default_rng(1001)
+x, e, adj, y = bench.synth_batch(rng, B, N)
+eng = GnnEngine(GnnSpec(n_nodes=N, feat_dim=F))
+db = eng.to_device(PackedBatch.from_dense(x, e, adj))
+import torch  # noqa: E402
+yd = torch.from_numpy(y).cuda()
+for _ in range(5):
+    eng.train_step(db, yd)
+torch.cuda.synchronize()
+buf = (C.c_int64 * (3 * 512))()
+assert eng._lib.v2x_debug_phase_stamps(eng._h, buf, 3 * 512) == 0
+t = np.array(buf[:], np.int64).reshape(3, 8, 64)[2][:4]
+print("marks: [0] wall(100MHz) [1] clk start | [2] weights staged | per tile: fwd0, fwd1-3+huber, wg3+bwd3+wg2+bwd2, wg1+bwd1, bwd0+stores, wg0 | loop end | slab written | wall")
+for w in range(4):
+    row = t[w]
+    n = int((row != 0).sum())
+    clk = row[1:n - 1]
+    wall = (row[n - 1] - row[0]) / 100.0
+    d = np.diff(clk)
+    print("wave %d: wall %.2f us, %d clk => %.2f GHz" % (w, wall, clk[-1] - clk[0], (clk[-1] - clk[0]) / wall / 1e3))
+    print("   staged +%d" % d[0])
+    body = d[1:-4]
+    for k in range(len(body) // 6):
+        print("   tile %d: " % k + " ".join("%6d" % v for v in body[6 * k:6 * k + 6]) + "  = %d" % body[6 * k:6 * k + 6].sum())
+    print("   end (to barrier | stored | added | slab written): " + " ".join("%d" % v for v in d[1 + 6 * (len(body) // 6):]))

@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace v2x {
 
@@ -1280,10 +1281,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     mfma_block(b0);
   }
 
-  // ---- sum the 4 waves' accumulators through LDS (wave 0 stores, waves 1..3 add in turn; fixed order =>
-  //      deterministic).  Lane (kg, j) of tile (kt, nt) holds rows feature_k(kt, 4*kg + r), column feature_n(nt, j).
-  f32x4* sAcc = reinterpret_cast<f32x4*>(smem);                  // [KT*NT][64 lanes]
-  float* sBias = smem + KT * NT * 64 * 4;                        // [NT][16]
+  // ---- sum the 4 waves' accumulators through LDS as (w0 + w1) + (w2 + w3): two sets (one per wave pair); in a pair
+  //      one wave STORES a tile and the other adds its own in place -- the even wave stores the first half of the tiles
+  //      and adds the second, the odd wave the other way round (a + b == b + a bitwise), so both work in both rounds; the
+  //      writer below adds the two sets.  Fixed order => deterministic.  (Until round 2 this was "wave 0 stores, 1..3
+  //      add in turn": three rounds of dependent LDS read-modify-writes by ONE wave, measured ~0.4 us per tile.)
+  //      Lane (kg, j) of tile (kt, nt) holds rows feature_k(kt, 4*kg + r), column feature_n(nt, j).
+  constexpr int TILES_X = KT * NT, XHALF = TILES_X / 2;
+  f32x4* sAcc = reinterpret_cast<f32x4*>(smem);                  // set A [KT*NT][64 lanes]
+  f32x4* sAcc2 = sAcc + TILES_X * 64;                            // set B
+  float* sBias4 = smem + 2 * TILES_X * 64 * 4;                   // [wave][NT][16]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {                              // bias: fold the 4 row groups of the wave
     float v = bsum[nt];
@@ -1291,24 +1298,29 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     v += __shfl_xor(v, 32);
     bsum[nt] = v;
   }
-#pragma unroll 1
-  for (int w = 0; w < 4; ++w) {
-    if (wv == w) {
+  if (kg == 0) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) sBias4[(wv * NT + nt) * 16 + j] = bsum[nt];
+  }
+  {
+    f32x4* sSet = (wv >> 1 ? sAcc2 : sAcc) + lane;
+    const bool even = (wv & 1) == 0;
+    auto xchg = [&](auto STORE, auto LOW) {
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          f32x4* p = sAcc + (kt * NT + nt) * 64 + lane;
-          if (w == 0) *p = acc[kt][nt]; else *p += acc[kt][nt];
+          const int ti = kt * NT + nt;
+          if ((ti < XHALF) == decltype(LOW)::value) {
+            if (decltype(STORE)::value) sSet[ti * 64] = acc[kt][nt];
+            else sSet[ti * 64] += acc[kt][nt];
+            if ((ti & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          }
         }
-      if (kg == 0) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          float* p = sBias + nt * 16 + j;
-          if (w == 0) *p = bsum[nt]; else *p += bsum[nt];
-        }
-      }
-    }
+    };
+    if (even) xchg(std::true_type{}, std::true_type{}); else xchg(std::true_type{}, std::false_type{});
+    __syncthreads();
+    if (even) xchg(std::false_type{}, std::false_type{}); else xchg(std::false_type{}, std::true_type{});
     __syncthreads();
   }
   // ---- write the partial.  Padded K row of (kt, lane index i): operand column offset + feature(); output column of
@@ -1331,20 +1343,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
       if (nn < NG) {                                             // 4 tiles -> 4 consecutive columns
         const int col = 64 * nn + 4 * j;
         float4 v;
-        v.x = sAcc[(kt * NT + 4 * nn + 0) * 64 + lane][r];
-        v.y = sAcc[(kt * NT + 4 * nn + 1) * 64 + lane][r];
-        v.z = sAcc[(kt * NT + 4 * nn + 2) * 64 + lane][r];
-        v.w = sAcc[(kt * NT + 4 * nn + 3) * 64 + lane][r];
+        v.x = sAcc[(kt * NT + 4 * nn + 0) * 64 + lane][r] + sAcc2[(kt * NT + 4 * nn + 0) * 64 + lane][r];
+        v.y = sAcc[(kt * NT + 4 * nn + 1) * 64 + lane][r] + sAcc2[(kt * NT + 4 * nn + 1) * 64 + lane][r];
+        v.z = sAcc[(kt * NT + 4 * nn + 2) * 64 + lane][r] + sAcc2[(kt * NT + 4 * nn + 2) * 64 + lane][r];
+        v.w = sAcc[(kt * NT + 4 * nn + 3) * 64 + lane][r] + sAcc2[(kt * NT + 4 * nn + 3) * 64 + lane][r];
         if (col + 3 < a.n_real) *reinterpret_cast<float4*>(dst + (int64_t)rr * a.n_real + col) = v;
       } else {
         const int nt = 4 * NG + (nn - NG), col = 64 * NG + 16 * (nn - NG) + j;
-        if (col < a.n_real) dst[(int64_t)rr * a.n_real + col] = sAcc[(kt * NT + nt) * 64 + lane][r];
+        if (col < a.n_real) dst[(int64_t)rr * a.n_real + col] = sAcc[(kt * NT + nt) * 64 + lane][r] + sAcc2[(kt * NT + nt) * 64 + lane][r];
       }
     }
   }
   if (tid < NT * 16) {
     const int nt = tid >> 4, jj = tid & 15, col = WgOperand<NW>::feature(nt, jj);
-    if (col < a.n_real) dst[(int64_t)a.pad.k_real * a.n_real + col] = sBias[tid];
+    if (col < a.n_real)
+      dst[(int64_t)a.pad.k_real * a.n_real + col] =
+          (sBias4[tid] + sBias4[NT * 16 + tid]) + (sBias4[2 * NT * 16 + tid] + sBias4[3 * NT * 16 + tid]);
   }
 }
 

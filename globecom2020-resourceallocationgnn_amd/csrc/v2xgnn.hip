@@ -871,8 +871,11 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
   const bool gnn_kind = kind < WG_KIND_DENSE0 || kind == WG_KIND_EMBED_NONBR;
   // measured at batch 4096 x 20 nodes in the merged launch: the SAME 1024 rows per workgroup for every role (87 us) beats
   // 1024 / 768 for the GNN / Dense families (102 us, the optimum when the two families were separate launches)
-  static const int rows_gnn = env_int("V2X_WG_CHUNK_GNN", 1024), rows_dense = env_int("V2X_WG_CHUNK_DENSE", 1024);
-  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, gnn_kind ? rows_gnn : rows_dense);
+  // (the graph layers on their own -- the Dense gradients come out of k_mlp_train_wg -- : 896, i.e. 5 x 832 rows per
+  //  slot at batch 4096: 46.8 us against 53.1 at 1024, 48.7 at 768, 49.4 at 704, 57.2 at 640)
+  static const int rows_gnn = env_int("V2X_WG_CHUNK_GNN", 0), rows_dense = env_int("V2X_WG_CHUNK_DENSE", 1024);
+  const int rows_g = rows_gnn > 0 ? rows_gnn : (mlp_wg_path(m) ? 896 : 1024);
+  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, gnn_kind ? rows_g : rows_dense);
   if (nc > m->slab_cap) FAIL(m, V2X_ESTATE, "wgrad: slabs not pre-sized (%d > %d)", nc, m->slab_cap);
   ld.n_slabs = nc;                       // remembered for the slab reduction
   memset(&a, 0, sizeof(a));
@@ -896,7 +899,7 @@ int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti
     maxt = std::max(maxt, (mu.w[i].kp / 16) * (mu.w[i].np / 16));
     nc = std::max(nc, mu.w[i].n_chunks);
   }
-  const size_t lds = (size_t)(maxt * 64 * 4 + 5 * 16) * 4;      // accumulator exchange + bias
+  const size_t lds = (size_t)(2 * maxt * 64 * 4 + 4 * 5 * 16) * 4;      // accumulator exchange (two sets) + bias (per wave)
   const dim3 grid(nc, x.grid_y, n_roles);
   bool dense = false, gnn = false;
   for (int i = 0; i < n_roles; ++i) ((mu.w[i].kind >= WG_KIND_DENSE0 && mu.w[i].kind <= WG_KIND_DENSE3) ? dense : gnn) = true;
@@ -1352,7 +1355,7 @@ GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
 
 int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   int chunk, nc = 1;
-  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), 768})
+  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), 768, 896})
     nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
   if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 1, n_slots));     // the fewest tiles (one) split most
   else nc = std::max(nc, mlp_wg_split(n_idx, n_slots).n_slabs);         // k_mlp_train_wg: one slab per workgroup and slot

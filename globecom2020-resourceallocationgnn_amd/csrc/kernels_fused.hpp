@@ -101,9 +101,20 @@ struct FusedFwdArgs {
   int n_graphs, N, L, S;                             // S = weight slots (N per-node, 1 shared)
   int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
   int n_edges;                                       // E of the whole batch
+  int compl_sums;                                    // dense graphs: Agg(h)[q] = colsum(h) - sum over the NON-neighbours of q
   int* err;
   long long* ts;                                     // TS builds: [8 waves][64] 100 MHz time stamps of workgroup 7
 };
+
+// Aggregation through the complement (compl_sums).  The reference's interference graph is almost complete: link q hears
+// every other link but itself and one more (in-degree N - 2), so the gather of 18 neighbour rows per node -- LDS-bound,
+// 5 us per aggregation, 6 aggregations per fit step -- is replaced by   Agg[q] = S - sum_{p not in N(q)} row[p]   with
+// S the column sum of the graph's rows: two rows instead of eighteen.  S costs nothing to produce: every wave adds up
+// the output rows of ITS slots while they are still in registers and parks that partial sum ([wave][kg][graph] float4
+// rows, same conflict-free geometry as the tile) next to the rows it writes into the tile; a lane then adds the 8
+// partials in wave order (fixed order: deterministic).  The host selects this form when the average in-degree exceeds
+// (N - 1) / 2; the values differ from the edge-ordered gather by rounding only.
+constexpr int FZ_SUMS_ROWS = FZ_WAVES * 4 * FZ_TG;     // rows of ROWF floats
 
 // phase time stamps of one workgroup (measurement builds only; v2x_debug_phase_stamps)
 template <bool TS>
@@ -185,7 +196,7 @@ __device__ __forceinline__ void csr_commit(const FzCsrEarly& c, const int32_t* r
 }
 
 struct FzCtx {
-  float* sH; int* sRp; unsigned char* sCol;
+  float* sH; int* sRp; unsigned char* sCol; float* sS; unsigned* sC;
   int N, L, SUB, lane, wv, jc, kg, g0;
 };
 
@@ -231,14 +242,30 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     return;
   }
   csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
+  const bool compl_sums = a.compl_sums != 0;                     // workgroup-uniform
+  if (compl_sums) {                      // non-neighbour masks of the tile's rows (while the embed operands are in flight)
+    __syncthreads();
+    const unsigned valid = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
+    for (int r = threadIdx.x; r < FZ_TG * N; r += FZ_THREADS) {
+      unsigned nb = 0u;
+      if (r < nrows)
+        for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) nb |= 1u << x.sCol[e];
+      x.sC[r] = ~nb & valid;
+    }
+  }
 
   typedef const __attribute__((address_space(4))) uint64_t* CQ;
   CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
   auto hptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedFwdArgs, h) / 8 + s]); };
   auto aptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedFwdArgs, a) / 8 + s]); };
   float* myrow = x.sH + kg * x.SUB + jc * ROWF;                  // + p*16*ROWF + kb*4
+  float* mysum = x.sS + ((wv * 4 + kg) * FZ_TG + jc) * ROWF;     // this wave's partial column sum (compl_sums)
+  const float* sums0 = x.sS + (kg * FZ_TG + jc) * ROWF;          // wave 0's; wave w: + w * 4 * FZ_TG * ROWF
 
   // ---- stage 0 (embed): h_0 = relu(xe . W0 + b0); the neighbour-init block is absent (always zero in the reference)
+  f32x4 psum[FB];                        // sum of this wave's output rows of the current stage
+#pragma unroll
+  for (int nt = 0; nt < FB; ++nt) psum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     float* hp = hptr(0);
 #pragma unroll
@@ -256,7 +283,12 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
         const f32x4 v = relu4(acc[nt] + b0[i][nt]);
         stg4(hp + rowi[i] * F + nt * 16 + 4 * kg, v);
         st4(myrow + k * FZ_TG * ROWF + nt * 4, v);
+        psum[nt] = i == 0 ? v : psum[nt] + v;
       }
+    }
+    if (compl_sums) {
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(mysum + nt * 4, NS > 0 ? psum[nt] : (f32x4){0.f, 0.f, 0.f, 0.f});
     }
   }
   ts.mark();                                                     // 1: embed done (before barrier)
@@ -288,6 +320,29 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     }
   };
 
+  // the same through the complement: column sum (8 partials, wave order) minus the rows of the non-neighbours
+  f32x4 csum[FB];
+  auto colsum = [&]() {
+#pragma unroll
+    for (int kb = 0; kb < FB; ++kb) csum[kb] = ld4(sums0 + kb * 4);
+#pragma unroll
+    for (int w = 1; w < FZ_WAVES; ++w)
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) csum[kb] += ld4(sums0 + w * 4 * FZ_TG * ROWF + kb * 4);
+  };
+  auto gather_c = [&](int k, f32x4 (&ag)[FB]) {
+#pragma unroll
+    for (int kb = 0; kb < FB; ++kb) ag[kb] = csum[kb];
+    unsigned bits = x.sC[jc * N + k];
+    while (bits) {
+      const int p = __builtin_ctz(bits);
+      bits &= bits - 1;
+      const float* bp = myrow + p * (FZ_TG * ROWF);
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) ag[kb] -= ld4(bp + kb * 4);
+    }
+  };
+
   // ---- stages 1..L: a_{s-1} = Agg(h_{s-1}) from LDS, h_s = act([h_{s-1} | xe | a_{s-1}] . W_s + b_s)
   for (int s = 1; s <= L; ++s) {
     float* hp = hptr(s);
@@ -295,9 +350,11 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     const bool relu = s < L;
     f32x4 ag[NSA][FB];                     // gathered a_{s-1} rows; slot i's registers become its output h_s afterwards
     // (1) gather phase
+    if (compl_sums) colsum();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      gather(wv + FZ_WAVES * i, ag[i]);
+      if (compl_sums) gather_c(wv + FZ_WAVES * i, ag[i]);
+      else gather(wv + FZ_WAVES * i, ag[i]);
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) stg4(ap + rowi[i] * F + kb * 16 + 4 * kg, ag[i][kb]);
     }
@@ -342,15 +399,20 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
         if (relu) v = relu4(v);
         stg4(hp + rowi[i] * F + nt * 16 + 4 * kg, v);
         ag[i][nt] = v;
+        psum[nt] = i == 0 ? v : psum[nt] + v;
       }
       ts.mark();                                                 // slot: MFMAs + stores issued
     }
-    __syncthreads();                       // every wave is done reading the h_{s-1} tile
+    __syncthreads();                       // every wave is done reading the h_{s-1} tile (and the partial sums)
     ts.mark();                                                   // stage: barrier passed
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, ag[i][nt]);
+    }
+    if (compl_sums) {
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(mysum + nt * 4, NS > 0 ? psum[nt] : (f32x4){0.f, 0.f, 0.f, 0.f});
     }
     __syncthreads();
     ts.mark();                                                   // stage: tile replaced
@@ -359,10 +421,12 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   // ---- a_L = Agg(h_L) for the decision MLP
   {
     float* ap = aptr(L);
+    if (compl_sums) colsum();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       f32x4 ag[FB];
-      gather(wv + FZ_WAVES * i, ag);
+      if (compl_sums) gather_c(wv + FZ_WAVES * i, ag);
+      else gather(wv + FZ_WAVES * i, ag);
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) stg4(ap + rowi[i] * F + kb * 16 + 4 * kg, ag[kb]);
     }
@@ -379,8 +443,10 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
   x.N = a.N; x.L = a.L;
   x.SUB = a.N * FZ_TG * P::ROWF;                                 // floats per k-group sub-array
   x.sH = smem;                                                   // [4][N*16][ROWF]
-  x.sRp = reinterpret_cast<int*>(x.sH + 4 * x.SUB);              // [16 N + 1] edge offsets relative to the tile
-  x.sCol = reinterpret_cast<unsigned char*>(x.sRp + FZ_TG * a.N + 1);   // [edges] graph-local sources
+  x.sS = x.sH + 4 * x.SUB;                                       // compl_sums: [8 waves][4][16][ROWF] partial column sums
+  x.sRp = reinterpret_cast<int*>(x.sS + (a.compl_sums ? FZ_SUMS_ROWS * P::ROWF : 0));   // [16 N + 1] edge offsets relative to the tile
+  x.sC = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // compl_sums: [16 N] non-neighbour masks
+  x.sCol = reinterpret_cast<unsigned char*>(x.sC + (a.compl_sums ? FZ_TG * a.N : 0));   // [edges] graph-local sources
   x.lane = threadIdx.x & 63;
   x.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   x.kg = x.lane >> 4;
@@ -407,12 +473,13 @@ struct FusedBwdArgs {
   float* dpre[FZ_MAXL + 1];
   float* gha;                                        // [R][2F]
   int n_graphs, N, L, S, edges_cap, n_edges;
+  int compl_sums;                                    // see FusedFwdArgs
   int* err;
   long long* ts;
 };
 
 struct FzCtxB {
-  float* sD; int* sRp; unsigned* sM; unsigned char* sCol;
+  float* sD; int* sRp; unsigned* sM; unsigned char* sCol; float* sS;
   int N, L, SUB, lane, wv, jc, kg, g0;
 };
 
@@ -459,10 +526,26 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   }
   for (int i = threadIdx.x; i < FZ_TG * N; i += FZ_THREADS) x.sM[i] = 0u;
   csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
+  const bool compl_sums = a.compl_sums != 0;                     // workgroup-uniform
+  float* mysum = x.sS + ((wv * 4 + kg) * FZ_TG + jc) * ROWF;     // this wave's partial column sum of the dagg tile
+  const float* sums0 = x.sS + (kg * FZ_TG + jc) * ROWF;
+  auto park = [&]() {                    // own dagg rows into the tile (+ their sum for the complement form)
+    f32x4 ps[FB];
 #pragma unroll
-  for (int i = 0; i < NS; ++i)
+    for (int nt = 0; nt < FB; ++nt) ps[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int nt = 0; nt < FB; ++nt) st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, dg[i][nt]);
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) {
+        st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, dg[i][nt]);
+        ps[nt] = i == 0 ? dg[i][nt] : ps[nt] + dg[i][nt];
+      }
+    if (compl_sums) {
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(mysum + nt * 4, ps[nt]);
+    }
+  };
+  park();
   __syncthreads();
   // transposed adjacency: bit q of sM[j*N + p] = edge p -> q (integer atomics: order-independent)
   for (int r = threadIdx.x; r < nrows; r += FZ_THREADS) {
@@ -472,6 +555,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   __syncthreads();
   ts.mark();                                                     // 1: tile + masks ready
 
+  const unsigned valid = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
   typedef const __attribute__((address_space(4))) uint64_t* CQ;
   CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
   auto hptr = [&](int s) { return reinterpret_cast<const float*>(kq[offsetof(FusedBwdArgs, h) / 8 + s]); };
@@ -492,6 +576,15 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
       for (int nt = 0; nt < FB; ++nt) hm[i & 1][nt] = ldg4(hp + rowi[i] * F + nt * 16 + 4 * kg);
     };
     if (NS > 0 && gate) request(0);
+    f32x4 csum[FB];
+    if (compl_sums) {
+#pragma unroll
+      for (int kb = 0; kb < FB; ++kb) csum[kb] = ld4(sums0 + kb * 4);
+#pragma unroll
+      for (int w = 1; w < FZ_WAVES; ++w)
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) csum[kb] += ld4(sums0 + w * 4 * FZ_TG * ROWF + kb * 4);
+    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       if (i + 1 < NS && gate) request(i + 1);
@@ -499,6 +592,18 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       unsigned bits = x.sM[jc * N + wv + FZ_WAVES * i];
+      if (compl_sums) {                                          // column sum minus the rows of the non-successors
+        bits = ~bits & valid;
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) acc[kb] = csum[kb];
+        while (bits) {
+          const int q0 = __builtin_ctz(bits);
+          bits &= bits - 1;
+          const float* b0 = myrow + q0 * (FZ_TG * ROWF);
+#pragma unroll
+          for (int kb = 0; kb < FB; ++kb) acc[kb] -= ld4(b0 + kb * 4);
+        }
+      }
       while (bits) {
         const int q0 = __builtin_ctz(bits);
         bits &= bits - 1;
@@ -560,10 +665,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
     }
     __syncthreads();                       // all gathers from the dagg_s tile are done
     ts.mark();
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-      for (int nt = 0; nt < FB; ++nt) st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, dg[i][nt]);
+    park();
     __syncthreads();
     ts.mark();                                                   // stage: tile replaced
   }
@@ -578,7 +680,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
   x.N = a.N; x.L = a.L;
   x.SUB = a.N * FZ_TG * P::ROWF;
   x.sD = smem;                                                   // dagg tile, same layout as the forward tile
-  x.sRp = reinterpret_cast<int*>(x.sD + 4 * x.SUB);              // [16 N + 1]
+  x.sS = x.sD + 4 * x.SUB;                                       // compl_sums: partial column sums
+  x.sRp = reinterpret_cast<int*>(x.sS + (a.compl_sums ? FZ_SUMS_ROWS * P::ROWF : 0));   // [16 N + 1]
   x.sM = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // [16 N] out-neighbour bit masks (N <= 32)
   x.sCol = reinterpret_cast<unsigned char*>(x.sM + FZ_TG * a.N);
   x.lane = threadIdx.x & 63;

@@ -71,6 +71,7 @@ struct v2x_model {
   long long* ts_buf = nullptr;                  // V2X_FUSED_TS=1: phase time stamps of the fused forward (measurement)
   bool raw_params = false;                      // v2x_param_ptr was called: re-pack before every fused forward
   bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
+  bool compl_sums = true;                       // V2X_FUSED_COMPL (read at create): dense graphs aggregate through the complement
   float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
   int* flag_host = nullptr;     // pinned, device-mapped word the kernels raise on a contract violation (tile guards,
   int* flag_dev = nullptr;      // k_validate_batch); read by the host after any synchronising call
@@ -1095,16 +1096,23 @@ LossJob loss_job(const v2x_model* m, const DevBatch& d, int n_global) {
 // ------------------------------------------------------------------------------------ fused graph layers
 // (kernels_fused.hpp) fixed-size graphs of <= 32 nodes, narrow features, no neighbour-init input, tile fits the LDS
 int fused_rowf(int F) { return 4 * ((F / 16) | 1); }
-size_t fused_lds(const v2x_model* m, const DevBatch& d, bool bwd) {
+size_t fused_lds(const v2x_model* m, const DevBatch& d, bool bwd, bool compl_sums = false) {
   const size_t rows = (size_t)FZ_TG * m->N;
   size_t b = 4 * rows * fused_rowf(m->F) * 4 + (rows + 1) * 4 + (size_t)FZ_TG * d.max_edges;
-  if (bwd) b += rows * 4;
+  b += rows * 4;                                       // bit masks: backward always, forward with compl_sums
+  if (compl_sums) b += (size_t)FZ_SUMS_ROWS * fused_rowf(m->F) * 4;
   return (b + 15) / 16 * 16;
 }
 bool fused_path(const v2x_model* m, const DevBatch& d) {
   if (!m->pk_fwd || m->cfg.variable_graphs || d.goff || d.nbr || m->F > 64 || m->N > 32 || m->L > FZ_MAXL) return false;
   if (d.max_nodes != m->N) return false;
   return fused_lds(m, d, true) <= 160 * 1024;
+}
+// Aggregations through the complement (kernels_fused.hpp, compl_sums): dense graphs whose extra LDS fits
+bool fused_compl(const v2x_model* m, const DevBatch& d) {
+  if (!m->compl_sums || m->N < 4) return false;
+  if (2 * (int64_t)d.E <= (int64_t)d.B * m->N * (m->N - 1)) return false;      // average in-degree <= (N - 1) / 2
+  return fused_lds(m, d, true, true) <= 160 * 1024;
 }
 
 int launch_pack(v2x_model* m, hipStream_t st) {
@@ -1147,7 +1155,8 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.a[s] = m->a[s]; }
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
-  const size_t lds = fused_lds(m, d, false);
+  a.compl_sums = fused_compl(m, d) ? 1 : 0;
+  const size_t lds = fused_lds(m, d, false, a.compl_sums != 0);
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
 #define V2X_FZ_FWD(FF, SP)                                                                                            \
   if (m->F == FF && spw == SP) {                                                                                      \
@@ -1169,7 +1178,8 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.dpre[s] = m->dpre[s]; }
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
-  const size_t lds = fused_lds(m, d, true);
+  a.compl_sums = fused_compl(m, d) ? 1 : 0;
+  const size_t lds = fused_lds(m, d, true, a.compl_sums != 0);
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
 #define V2X_FZ_BWD(FF, SP)                                                                                            \
   if (m->F == FF && spw == SP) {                                                                                      \
@@ -1437,6 +1447,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     return fail("allocation");
   // V2X_FUSED=0 (read when the model is created) keeps the layer-by-layer kernels: A/B measurements and the test that
   // the two paths agree bitwise
+  m->compl_sums = env_int("V2X_FUSED_COMPL", 1) != 0;
   if (env_int("V2X_FUSED", 1) != 0 && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
     const int FB = m->F / 16, KB = 2 * FB + 1;
     const size_t fwd0 = (size_t)FB * 256 + m->F, fwd = (size_t)KB * FB * 256 + m->F, bwd = (size_t)FB * 2 * FB * 256;

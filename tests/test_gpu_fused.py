@@ -13,16 +13,20 @@ from oracle import compact as oc
 pytestmark = pytest.mark.gpu
 
 
-def _engine(spec, weights, fused, **kw):
-    old = os.environ.get("V2X_FUSED")
-    os.environ["V2X_FUSED"] = "1" if fused else "0"          # read by v2x_create
+def _engine(spec, weights, fused, compl=False, **kw):
+    """compl: let dense graphs aggregate through the complement (column sum minus the non-neighbours' rows; the default
+    of the library) -- same values up to rounding, so the bitwise comparisons below switch it off."""
+    env = {"V2X_FUSED": "1" if fused else "0", "V2X_FUSED_COMPL": "1" if compl else "0"}     # read by v2x_create
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         eng = GnnEngine(spec, **kw)
     finally:
-        if old is None:
-            del os.environ["V2X_FUSED"]
-        else:
-            os.environ["V2X_FUSED"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
     eng.set_weights(weights)
     return eng
 
@@ -69,6 +73,44 @@ def test_fused_equals_layerwise_bitwise_and_oracle(N, F, L, B, share, ref_topo):
         fused.train_step(pb, y)
         plain.train_step(pb, y)
     assert np.array_equal(fused.get_flat(), plain.get_flat())
+    fused.close()
+    plain.close()
+
+
+@pytest.mark.parametrize("N,F,L,B,share,ref_topo", CASES)
+def test_complement_aggregation_matches_layerwise_and_oracle(N, F, L, B, share, ref_topo):
+    """Dense graphs (the reference topology has in-degree N - 2): Agg through the column sum minus the non-neighbours.
+    Equal to the edge-ordered gather up to fp32 rounding; sparse batches must not take that form at all (bitwise)."""
+    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=share)
+    rng = np.random.default_rng(100 + N + F + B)
+    P = f32_params(spec, rng)
+    weights = oc.params_to_list(P)
+    x, e, adj = random_inputs(rng, B, N, ref_topology=ref_topo, density=0.4)
+    y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+    pb = PackedBatch.from_dense(x, e, adj)
+    fused, plain = _engine(spec, weights, True, compl=True), _engine(spec, weights, False)
+    qf, qp = fused.forward(pb), plain.forward(pb)
+    lf, lp = fused.forward_backward(pb, y), plain.forward_backward(pb, y)
+    gf, gp = fused.get_grad_flat(), plain.get_grad_flat()
+    rowf = 4 * ((F // 16) | 1)                                 # fused_lds() of csrc/v2xgnn.hip with the partial column sums
+    lds = 4 * 16 * N * rowf * 4 + (16 * N + 1) * 4 + 16 * pb.max_edges + 16 * N * 4 + 512 * rowf * 4
+    dense = 2 * pb.col_idx.size > B * N * (N - 1) and N >= 4 and lds <= 160 * 1024
+    if not dense:
+        assert np.array_equal(qf, qp) and np.array_equal(gf, gp)
+    else:
+        assert not np.array_equal(gf, gp)                      # the complement form really ran
+    assert np.allclose(qf, qp, rtol=1e-5, atol=1e-5 * np.abs(qp).max()), np.abs(qf - qp).max()
+    assert np.allclose(lf, lp, rtol=1e-5, atol=1e-7)
+    assert np.allclose(gf, gp, rtol=1e-3, atol=1e-4 * np.abs(gp).max()), np.abs(gf - gp).max()
+    os_ = ospec(spec)
+    M = oc.csr_to_matrix((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx, np.float64)
+    q_ref, cache = oc.forward(os_, P, x.reshape(B * N, -1).astype(np.float64), e.reshape(B * N, -1).astype(np.float64), M)
+    assert_fwd_close(qf, q_ref, "complement forward vs oracle")
+    loss_ref, dq = oc.huber_loss_and_grad(os_, qf.astype(np.float64), y.astype(np.float64))
+    g_ref = oc.backward(os_, P, cache, dq)
+    assert_close(lf, loss_ref, 2e-4, 1e-6, "loss")
+    for i, (a_, b_) in enumerate(zip(v2xgnn.flat_to_keras_list(spec, gf), oc.params_to_list(g_ref))):
+        assert_grad_close(a_, b_, "complement gradient array %d vs oracle" % i)
     fused.close()
     plain.close()
 

@@ -101,7 +101,7 @@ struct FusedFwdArgs {
   int n_graphs, N, L, S;                             // S = weight slots (N per-node, 1 shared)
   int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
   int n_edges;                                       // E of the whole batch
-  int compl_sums;                                    // dense graphs: Agg(h)[q] = colsum(h) - sum over the NON-neighbours of q
+  int compl_sums;                                    // (informative; the COMPL kernel instance is what runs) dense graphs: Agg(h)[q] = colsum(h) - sum over the NON-neighbours of q
   int* err;
   long long* ts;                                     // TS builds: [8 waves][64] 100 MHz time stamps of workgroup 7
 };
@@ -200,7 +200,7 @@ struct FzCtx {
   int N, L, SUB, lane, wv, jc, kg, g0;
 };
 
-template <int F, int NS, bool TS>
+template <int F, int NS, bool TS, bool COMPL>
 __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCtx& x, const int nrows, const int r_begin) {
   using P = FzPack<F>;
   constexpr int FB = P::FB, KB = P::KB, ROWF = P::ROWF;
@@ -242,7 +242,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     return;
   }
   csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
-  const bool compl_sums = a.compl_sums != 0;                     // workgroup-uniform
+  constexpr bool compl_sums = COMPL;     // (a compile-time form: both gathers side by side cost registers and spill)
   if (compl_sums) {                      // non-neighbour masks of the tile's rows (while the embed operands are in flight)
     __syncthreads();
     const unsigned valid = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
@@ -435,7 +435,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
 }
 
 // SPW = ceil(N / 8) slots for the first N - 8 (SPW - 1) waves, SPW - 1 for the others
-template <int F, int SPW, bool TS = false>
+template <int F, int SPW, bool TS = false, bool COMPL = false>
 __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a) {
   using P = FzPack<F>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -444,9 +444,9 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
   x.SUB = a.N * FZ_TG * P::ROWF;                                 // floats per k-group sub-array
   x.sH = smem;                                                   // [4][N*16][ROWF]
   x.sS = x.sH + 4 * x.SUB;                                       // compl_sums: [8 waves][4][16][ROWF] partial column sums
-  x.sRp = reinterpret_cast<int*>(x.sS + (a.compl_sums ? FZ_SUMS_ROWS * P::ROWF : 0));   // [16 N + 1] edge offsets relative to the tile
+  x.sRp = reinterpret_cast<int*>(x.sS + (COMPL ? FZ_SUMS_ROWS * P::ROWF : 0));   // [16 N + 1] edge offsets relative to the tile
   x.sC = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // compl_sums: [16 N] non-neighbour masks
-  x.sCol = reinterpret_cast<unsigned char*>(x.sC + (a.compl_sums ? FZ_TG * a.N : 0));   // [edges] graph-local sources
+  x.sCol = reinterpret_cast<unsigned char*>(x.sC + (COMPL ? FZ_TG * a.N : 0));   // [edges] graph-local sources
   x.lane = threadIdx.x & 63;
   x.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   x.kg = x.lane >> 4;
@@ -454,8 +454,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
   const int ng = min(FZ_TG, a.n_graphs - x.g0);
   x.jc = min(x.lane & 15, ng - 1);
   const int r_begin = x.g0 * a.N, nrows = ng * a.N;
-  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_fwd_body<F, SPW, TS>(a, x, nrows, r_begin);
-  else fused_fwd_body<F, SPW - 1, TS>(a, x, nrows, r_begin);
+  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_fwd_body<F, SPW, TS, COMPL>(a, x, nrows, r_begin);
+  else fused_fwd_body<F, SPW - 1, TS, COMPL>(a, x, nrows, r_begin);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -483,7 +483,7 @@ struct FzCtxB {
   int N, L, SUB, lane, wv, jc, kg, g0;
 };
 
-template <int F, int NS, bool TS>
+template <int F, int NS, bool TS, bool COMPL>
 __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCtxB& x, const int nrows, const int r_begin) {
   using P = FzPack<F>;
   constexpr int FB = P::FB, ROWF = P::ROWF;
@@ -526,7 +526,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   }
   for (int i = threadIdx.x; i < FZ_TG * N; i += FZ_THREADS) x.sM[i] = 0u;
   csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
-  const bool compl_sums = a.compl_sums != 0;                     // workgroup-uniform
+  constexpr bool compl_sums = COMPL;
   float* mysum = x.sS + ((wv * 4 + kg) * FZ_TG + jc) * ROWF;     // this wave's partial column sum of the dagg tile
   const float* sums0 = x.sS + (kg * FZ_TG + jc) * ROWF;
   auto park = [&]() {                    // own dagg rows into the tile (+ their sum for the complement form)
@@ -576,15 +576,6 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
       for (int nt = 0; nt < FB; ++nt) hm[i & 1][nt] = ldg4(hp + rowi[i] * F + nt * 16 + 4 * kg);
     };
     if (NS > 0 && gate) request(0);
-    f32x4 csum[FB];
-    if (compl_sums) {
-#pragma unroll
-      for (int kb = 0; kb < FB; ++kb) csum[kb] = ld4(sums0 + kb * 4);
-#pragma unroll
-      for (int w = 1; w < FZ_WAVES; ++w)
-#pragma unroll
-        for (int kb = 0; kb < FB; ++kb) csum[kb] += ld4(sums0 + w * 4 * FZ_TG * ROWF + kb * 4);
-    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       if (i + 1 < NS && gate) request(i + 1);
@@ -592,10 +583,17 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       unsigned bits = x.sM[jc * N + wv + FZ_WAVES * i];
-      if (compl_sums) {                                          // column sum minus the rows of the non-successors
+      if constexpr (COMPL) {                                          // column sum minus the rows of the non-successors
+        // (the column sum is re-added per slot, 8 partials in wave order: keeping it in registers across the slots
+        //  spills next to the weight ring)
         bits = ~bits & valid;
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) acc[kb] = csum[kb];
+        for (int kb = 0; kb < FB; ++kb) acc[kb] = ld4(sums0 + kb * 4);
+#pragma unroll 1
+        for (int w = 1; w < FZ_WAVES; ++w) {
+#pragma unroll
+          for (int kb = 0; kb < FB; ++kb) acc[kb] += ld4(sums0 + w * 4 * FZ_TG * ROWF + kb * 4);
+        }
         while (bits) {
           const int q0 = __builtin_ctz(bits);
           bits &= bits - 1;
@@ -603,21 +601,22 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
 #pragma unroll
           for (int kb = 0; kb < FB; ++kb) acc[kb] -= ld4(b0 + kb * 4);
         }
-      }
-      while (bits) {
-        const int q0 = __builtin_ctz(bits);
-        bits &= bits - 1;
-        const bool two = bits != 0;
-        const int q1 = two ? __builtin_ctz(bits) : q0;
-        bits &= bits - 1;                                        // (0 & anything stays 0)
-        const float m1 = two ? 1.f : 0.f;
-        const float* b0 = myrow + q0 * (FZ_TG * ROWF);
-        const float* b1 = myrow + q1 * (FZ_TG * ROWF);
-        f32x4 v0[FB], v1[FB];
+      } else {
+        while (bits) {
+          const int q0 = __builtin_ctz(bits);
+          bits &= bits - 1;
+          const bool two = bits != 0;
+          const int q1 = two ? __builtin_ctz(bits) : q0;
+          bits &= bits - 1;                                        // (0 & anything stays 0)
+          const float m1 = two ? 1.f : 0.f;
+          const float* b0 = myrow + q0 * (FZ_TG * ROWF);
+          const float* b1 = myrow + q1 * (FZ_TG * ROWF);
+          f32x4 v0[FB], v1[FB];
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) { v0[kb] = ld4(b0 + kb * 4); v1[kb] = ld4(b1 + kb * 4); }
+          for (int kb = 0; kb < FB; ++kb) { v0[kb] = ld4(b0 + kb * 4); v1[kb] = ld4(b1 + kb * 4); }
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) { acc[kb] += v0[kb]; acc[kb] += v1[kb] * m1; }
+          for (int kb = 0; kb < FB; ++kb) { acc[kb] += v0[kb]; acc[kb] += v1[kb] * m1; }
+        }
       }
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) {
@@ -672,7 +671,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   ts.mark(true);
 }
 
-template <int F, int SPW, bool TS = false>
+template <int F, int SPW, bool TS = false, bool COMPL = false>
 __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a) {
   using P = FzPack<F>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -681,7 +680,7 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
   x.SUB = a.N * FZ_TG * P::ROWF;
   x.sD = smem;                                                   // dagg tile, same layout as the forward tile
   x.sS = x.sD + 4 * x.SUB;                                       // compl_sums: partial column sums
-  x.sRp = reinterpret_cast<int*>(x.sS + (a.compl_sums ? FZ_SUMS_ROWS * P::ROWF : 0));   // [16 N + 1]
+  x.sRp = reinterpret_cast<int*>(x.sS + (COMPL ? FZ_SUMS_ROWS * P::ROWF : 0));   // [16 N + 1]
   x.sM = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // [16 N] out-neighbour bit masks (N <= 32)
   x.sCol = reinterpret_cast<unsigned char*>(x.sM + FZ_TG * a.N);
   x.lane = threadIdx.x & 63;
@@ -691,8 +690,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
   const int ng = min(FZ_TG, a.n_graphs - x.g0);
   x.jc = min(x.lane & 15, ng - 1);
   const int r_begin = x.g0 * a.N, nrows = ng * a.N;
-  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_bwd_body<F, SPW, TS>(a, x, nrows, r_begin);
-  else fused_bwd_body<F, SPW - 1, TS>(a, x, nrows, r_begin);
+  if (x.wv < a.N - FZ_WAVES * (SPW - 1)) fused_bwd_body<F, SPW, TS, COMPL>(a, x, nrows, r_begin);
+  else fused_bwd_body<F, SPW - 1, TS, COMPL>(a, x, nrows, r_begin);
 }
 
 }  // namespace v2x

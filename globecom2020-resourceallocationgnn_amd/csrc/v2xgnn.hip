@@ -201,15 +201,18 @@ void set_attrs_f() {
 
 template <int F>
 void set_attrs_fused() {
-  allow_big_lds((const void*)k_gnn_fwd_fused<F, 1>);
-  allow_big_lds((const void*)k_gnn_fwd_fused<F, 2>);
-  allow_big_lds((const void*)k_gnn_fwd_fused<F, 3>);
-  allow_big_lds((const void*)k_gnn_fwd_fused<F, 4>);
-  allow_big_lds((const void*)k_gnn_bwd_fused<F, 1>);
-  allow_big_lds((const void*)k_gnn_bwd_fused<F, 2>);
-  allow_big_lds((const void*)k_gnn_bwd_fused<F, 3>);
-  allow_big_lds((const void*)k_gnn_bwd_fused<F, 4>);
-  if (F == 64) { allow_big_lds((const void*)k_gnn_fwd_fused<64, 3, true>); allow_big_lds((const void*)k_gnn_bwd_fused<64, 3, true>); }
+  allow_big_lds((const void*)k_gnn_fwd_fused<F, 1>); allow_big_lds((const void*)k_gnn_fwd_fused<F, 1, false, true>);
+  allow_big_lds((const void*)k_gnn_fwd_fused<F, 2>); allow_big_lds((const void*)k_gnn_fwd_fused<F, 2, false, true>);
+  allow_big_lds((const void*)k_gnn_fwd_fused<F, 3>); allow_big_lds((const void*)k_gnn_fwd_fused<F, 3, false, true>);
+  allow_big_lds((const void*)k_gnn_fwd_fused<F, 4>); allow_big_lds((const void*)k_gnn_fwd_fused<F, 4, false, true>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F, 1>); allow_big_lds((const void*)k_gnn_bwd_fused<F, 1, false, true>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F, 2>); allow_big_lds((const void*)k_gnn_bwd_fused<F, 2, false, true>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F, 3>); allow_big_lds((const void*)k_gnn_bwd_fused<F, 3, false, true>);
+  allow_big_lds((const void*)k_gnn_bwd_fused<F, 4>); allow_big_lds((const void*)k_gnn_bwd_fused<F, 4, false, true>);
+  if (F == 64) {
+    allow_big_lds((const void*)k_gnn_fwd_fused<64, 3, true>); allow_big_lds((const void*)k_gnn_bwd_fused<64, 3, true>);
+    allow_big_lds((const void*)k_gnn_fwd_fused<64, 3, true, true>); allow_big_lds((const void*)k_gnn_bwd_fused<64, 3, true, true>);
+  }
 }
 
 void set_attrs(int F) {
@@ -1160,7 +1163,11 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
 #define V2X_FZ_FWD(FF, SP)                                                                                            \
   if (m->F == FF && spw == SP) {                                                                                      \
-    if (FF == 64 && SP == 3 && m->ts_buf) { a.ts = m->ts_buf; auto k = k_gnn_fwd_fused<64, 3, true>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
+    if (FF == 64 && SP == 3 && m->ts_buf) {                                                                          \
+      a.ts = m->ts_buf;                                                                                               \
+      if (a.compl_sums) { auto k = k_gnn_fwd_fused<64, 3, true, true>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
+      else { auto k = k_gnn_fwd_fused<64, 3, true>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
+    } else if (a.compl_sums) { auto k = k_gnn_fwd_fused<FF, SP, false, true>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
     else { auto k = k_gnn_fwd_fused<FF, SP>; LAUNCH_T(m, "k_gnn_fwd_fused", k, grid, FZ_THREADS, lds, st, a); }        \
     return V2X_OK;                                                                                                    \
   }
@@ -1183,7 +1190,11 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
 #define V2X_FZ_BWD(FF, SP)                                                                                            \
   if (m->F == FF && spw == SP) {                                                                                      \
-    if (FF == 64 && SP == 3 && m->ts_buf) { a.ts = m->ts_buf; auto k = k_gnn_bwd_fused<64, 3, true>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
+    if (FF == 64 && SP == 3 && m->ts_buf) {                                                                          \
+      a.ts = m->ts_buf;                                                                                               \
+      if (a.compl_sums) { auto k = k_gnn_bwd_fused<64, 3, true, true>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
+      else { auto k = k_gnn_bwd_fused<64, 3, true>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
+    } else if (a.compl_sums) { auto k = k_gnn_bwd_fused<FF, SP, false, true>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); } \
     else { auto k = k_gnn_bwd_fused<FF, SP>; LAUNCH_T(m, "k_gnn_bwd_fused", k, grid, FZ_THREADS, lds, st, a); }        \
     return V2X_OK;                                                                                                    \
   }

@@ -80,6 +80,7 @@ def algorithmic_flops(name, R, F, L, C=4, Dn=9, De=4):
              "k_mlp_bwd": (2 * R * 80 * 2 * F if F < 128 else 0) + tail,
              "k_wgrad_dense": (dense0 if F < 128 else 0) + tail}
     table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"]
+    table["k_mlp_train_wg"] = table["k_mlp_train"] + table["k_wgrad_dense"]   # + the four Dense weight gradients, same launch
     table["k_wgrad_all"] = table["k_wgrad_gnn"] + table["k_wgrad_dense"]
     table["k_gnn_fwd_fused"] = embed + L * gnn                        # embed + L stages (graph-major fused launch)
     table["k_gnn_bwd_fused"] = L * table["k_node_dgrad"]              # L data gradients
@@ -114,6 +115,7 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     table["k_gnn_fwd_fused"] = 4 * R * (Dn + De) + csr + 2 * (L + 1) * 4 * R * F
     table["k_gnn_bwd_fused"] = 4 * R * 2 * F + L * 4 * R * F + csr + (L + 1) * 4 * R * F
     table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"] - 4 * R * C  # fwd + Huber + bwd fused: q is not re-read
+    table["k_mlp_train_wg"] = table["k_mlp_train"]    # weight gradients from the values on chip: no further node-row bytes
     return table.get(name)
 
 

@@ -14,7 +14,7 @@ import sys
 NAMES = [(r"k_agg<false>", "k_agg_fwd"), (r"k_agg<true>", "k_agg_bwd"),
          (r"k_gemm_rows<\d+, false, (false|true), false>", "k_node_fwd_embed"),
          (r"k_gemm_rows<\d+, true, true, false>", "k_node_fwd"), (r"k_gemm_rows<\d+, true, false, true>", "k_node_dgrad"),
-         (r"k_mlp_fwd", "k_mlp_fwd"), (r"k_mlp_bwd", "k_mlp_bwd"), (r"k_mlp_train", "k_mlp_train"), (r"k_wgrad<\d+, 0>", "k_wgrad_gnn"),
+         (r"k_mlp_fwd", "k_mlp_fwd"), (r"k_mlp_bwd", "k_mlp_bwd"), (r"k_mlp_train_wg", "k_mlp_train_wg"), (r"k_mlp_train", "k_mlp_train"), (r"k_wgrad<\d+, 0>", "k_wgrad_gnn"),
          (r"k_wgrad<\d+, 1>", "k_wgrad_dense"), (r"k_wgrad<\d+, 2>", "k_wgrad_all"),
          (r"k_agg_small<false", "k_agg_fwd"), (r"k_agg_small<true", "k_agg_bwd"), (r"k_reduce_adam", "k_reduce_adam"),
          (r"k_gnn_fwd_fused", "k_gnn_fwd_fused"), (r"k_gnn_bwd_fused", "k_gnn_bwd_fused"), (r"k_pack_weights", "k_pack_weights")]

@@ -1058,6 +1058,7 @@ struct WgradArgs {
   int n_chunks;                                   // workgroups (slabs) of THIS role; blockIdx.x >= n_chunks exits
   int kind;                                       // WG_KIND_*: selects the compile-time operand widths
   int dpre_slot_major; int srow_stride;           // row layout of dpre / of slot-major segments
+  long long* ts;                                  // phase stamps (diagnostics, V2X_FUSED_TS=1) or null
 };
 
 constexpr int WG_TR = 16;        // rows per MFMA block (chunk sizes are multiples of it)
@@ -1128,6 +1129,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
   const int j = lane & 15, kg = lane >> 4;
   const int i_begin = bx * a.chunk, i_end = min(i_begin + a.chunk, a.n_idx);
+  long long* tsp = (a.ts && bx == 1 && slot == 0 && blockIdx.z == 0 && lane == 0) ? a.ts + wv * 64 : nullptr;
+  int tsn = 0;
+  auto mark = [&]() {
+    if (tsp && tsn < 64) tsp[tsn] = tsn == 0 ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter();
+    ++tsn;
+  };
+  mark(); mark();
 
   // (the descriptor was copied out of the kernarg segment as raw words: cast to the global address space
   //  explicitly, else hipcc emits flat loads and waits vmcnt(0) lgkmcnt(0) before every MFMA)
@@ -1229,41 +1237,27 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     } else if (nb - k == 1) {
       mfma_block(b0);
     }
-  } else if (nb == 1) {
-    load_full(wv, b0);
-    V2X_SB;
-    mfma_block(b0);
-  } else if (nb >= 2) {
-    Block b2;
-    load_full(wv, b0);
-    load_full(wv + 4, b1);
+  } else if (nb > 0) {
+    // DEPTH register buffers, DEPTH - 1 blocks of loads in flight while one is multiplied.  Block k + u of a group of
+    // DEPTH lives in buffer u; loads past the wave's last block re-request that block (unconditional: a load under an
+    // `if` would force vmcnt(0) at the join; the repeats hit the L1 / L2)
+    Block br[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) load_full(wv + 4 * min(d, nb - 1), br[d]);
     V2X_SB;
 #pragma unroll 1
-    for (; k + 4 < nb; k += 3) {             // invariant: b0 = block k, b1 = block k+1 (loaded or in flight)
-      load_full(wv + 4 * (k + 2), b2);
-      mfma_block(b0); V2X_ILV;
-      load_full(wv + 4 * (k + 3), b0);
-      mfma_block(b1); V2X_ILV;
-      load_full(wv + 4 * (k + 4), b1);
-      mfma_block(b2); V2X_ILV;
+    for (; k + DEPTH <= nb; k += DEPTH) {
+#pragma unroll
+      for (int u = 0; u < DEPTH; ++u) {
+        load_full(wv + 4 * min(k + u + DEPTH - 1, nb - 1), br[(u + DEPTH - 1) % DEPTH]);
+        mfma_block(br[u]); V2X_ILV;
+        mark();
+      }
     }
-    const int rem = nb - k;                  // 2, 3 or 4 blocks left
-    if (rem == 2) {
-      mfma_block(b0);
-      mfma_block(b1);
-    } else if (rem == 3) {
-      load_full(wv + 4 * (k + 2), b2); V2X_SB;
-      mfma_block(b0);
-      mfma_block(b1);
-      mfma_block(b2);
-    } else {
-      load_full(wv + 4 * (k + 2), b2); V2X_SB;
-      mfma_block(b0); V2X_SB;
-      load_full(wv + 4 * (k + 3), b0); V2X_SB;
-      mfma_block(b1);
-      mfma_block(b2);
-      mfma_block(b0);
-    }
+    const int rem = nb - k;                  // 0 .. DEPTH - 1 blocks left, already requested, in buffers 0 .. rem - 1
+#pragma unroll
+    for (int u = 0; u < DEPTH - 1; ++u)
+      if (u < rem) mfma_block(br[u]);
   }
 #undef V2X_ILV
 #undef V2X_SB
@@ -1287,6 +1281,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   //      writer below adds the two sets.  Fixed order => deterministic.  (Until round 2 this was "wave 0 stores, 1..3
   //      add in turn": three rounds of dependent LDS read-modify-writes by ONE wave, measured ~0.4 us per tile.)
   //      Lane (kg, j) of tile (kt, nt) holds rows feature_k(kt, 4*kg + r), column feature_n(nt, j).
+  mark();
   constexpr int TILES_X = KT * NT, XHALF = TILES_X / 2;
   f32x4* sAcc = reinterpret_cast<f32x4*>(smem);                  // set A [KT*NT][64 lanes]
   f32x4* sAcc2 = sAcc + TILES_X * 64;                            // set B
@@ -1360,6 +1355,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
       dst[(int64_t)a.pad.k_real * a.n_real + col] =
           (sBias4[tid] + sBias4[NT * 16 + tid]) + (sBias4[2 * NT * 16 + tid] + sBias4[3 * NT * 16 + tid]);
   }
+  mark();
+  if (tsp && tsn < 64) tsp[tsn] = (long long)wall_clock64();
 }
 
 // Several independent weight-gradient problems (roles) in ONE launch: blockIdx.z selects the layer and each
@@ -1368,6 +1365,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
 // share one launch each instead of 4 (L+1).  Kernarg structs indexed by blockIdx.z would be copied to scratch
 // (runtime-indexed array): the role's descriptor is read through the constant-address-space kernarg pointer.
 constexpr int WG_MAX_ROLES = 8;
+#ifndef V2X_WG_DEPTH_GNN
+#define V2X_WG_DEPTH_GNN 3
+#endif
 struct WgradMulti { WgradArgs w[WG_MAX_ROLES]; };
 enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 3, WG_KIND_DENSE2 = 4, WG_KIND_DENSE3 = 5,
        WG_KIND_EMBED_NONBR = 6 };
@@ -1385,7 +1385,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
 #pragma unroll
   for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
   if constexpr (MODE != 1) {
-    if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN>(a, smem, blockIdx.x, blockIdx.y); return; }
     if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
     if (a.kind == WG_KIND_EMBED_NONBR) { wgrad_body<XE, F, 0, F, 3, true>(a, smem, blockIdx.x, blockIdx.y); return; }
   }

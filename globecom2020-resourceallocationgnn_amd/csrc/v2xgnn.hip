@@ -878,7 +878,9 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
   // (the graph layers on their own -- the Dense gradients come out of k_mlp_train_wg -- : 896, i.e. 5 x 832 rows per
   //  slot at batch 4096: 46.8 us against 53.1 at 1024, 48.7 at 768, 49.4 at 704, 57.2 at 640)
   static const int rows_gnn = env_int("V2X_WG_CHUNK_GNN", 0), rows_dense = env_int("V2X_WG_CHUNK_DENSE", 1024);
-  const int rows_g = rows_gnn > 0 ? rows_gnn : (mlp_wg_path(m) ? 896 : 1024);
+  int rows_g = rows_gnn > 0 ? rows_gnn : (mlp_wg_path(m) ? 896 : 1024);
+  static const int rows_embed = env_int("V2X_WG_CHUNK_EMBED", 0);       // the (light) embed role on its own chunking
+  if (rows_embed > 0 && (kind == WG_KIND_EMBED || kind == WG_KIND_EMBED_NONBR)) rows_g = rows_embed;
   const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, gnn_kind ? rows_g : rows_dense);
   if (nc > m->slab_cap) FAIL(m, V2X_ESTATE, "wgrad: slabs not pre-sized (%d > %d)", nc, m->slab_cap);
   ld.n_slabs = nc;                       // remembered for the slab reduction
@@ -893,6 +895,7 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
   a.dpre_slot_major = (kind >= WG_KIND_DENSE1 && kind <= WG_KIND_DENSE3) ? 1 : 0;      // dz2, dz3, dq (MlpArgs::srow_stride)
   a.srow_stride = (int)srow_stride(m);
   a.zeros = m->zero_buf;
+  a.ts = (m->ts_buf && kind == WG_KIND_GNN) ? m->ts_buf + 3 * 8 * 64 : nullptr;
   return V2X_OK;
 }
 
@@ -1376,7 +1379,7 @@ GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
 
 int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   int chunk, nc = 1;
-  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), 768, 896})
+  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), env_int("V2X_WG_CHUNK_EMBED", 1024), 768, 896})
     nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
   if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 1, n_slots));     // the fewest tiles (one) split most
   else nc = std::max(nc, mlp_wg_split(n_idx, n_slots).n_slabs);         // k_mlp_train_wg: one slab per workgroup and slot
@@ -1467,8 +1470,8 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     m->pk_stale = true;             // first forward packs whatever the parameters are by then
   }
   if (m->pk_fwd && env_int("V2X_FUSED_TS", 0)) {
-    if (dev_alloc(m, &m->ts_buf, 3 * 8 * 64)) return fail("allocation");
-    hipMemset(m->ts_buf, 0, 3 * 8 * 64 * 8);
+    if (dev_alloc(m, &m->ts_buf, 4 * 8 * 64)) return fail("allocation");
+    hipMemset(m->ts_buf, 0, 4 * 8 * 64 * 8);
   }
   if (hipMemset(m->zero_buf, 0, 4096) || hipMemset(m->loss_part, 0, 512) || hipMemset(m->params, 0, pb) || hipMemset(m->grads, 0, pb) || hipMemset(m->mom, 0, pb) || hipMemset(m->vel, 0, pb))
     return fail("memset");
@@ -1905,7 +1908,7 @@ int v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n) {
   if (!m || !out) FAIL(m, V2X_EINVAL, "null argument");
   if (!m->ts_buf) FAIL(m, V2X_ESTATE, "phase stamps need V2X_FUSED_TS=1 when the model is created");
   HIPCHK(m, hipDeviceSynchronize());
-  HIPCHK(m, hipMemcpy(out, m->ts_buf, (size_t)std::min(n, 3 * 8 * 64) * 8, hipMemcpyDeviceToHost));
+  HIPCHK(m, hipMemcpy(out, m->ts_buf, (size_t)std::min(n, 4 * 8 * 64) * 8, hipMemcpyDeviceToHost));
   return V2X_OK;
 }
 

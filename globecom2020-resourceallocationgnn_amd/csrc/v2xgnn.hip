@@ -6,6 +6,7 @@
 #include "kernels_wide.hpp"
 #include "kernels_fused.hpp"
 #include "kernels_mlpwg.hpp"
+#include "kernels_small.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -72,6 +73,9 @@ struct v2x_model {
   bool raw_params = false;                      // v2x_param_ptr was called: re-pack before every fused forward
   bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
   bool compl_sums = true;                       // V2X_FUSED_COMPL (read at create): dense graphs aggregate through the complement
+  bool small_predict = true;                    // V2X_SMALL_PREDICT (read at create): few-graph forwards in one launch (kernels_small.hpp)
+  float* small_h = nullptr;                     // its exchange buffer [2][SMALL_ROWS][F]
+  unsigned* small_sync = nullptr;               // and per-graph barrier counters [SMALL_ROWS][2]
   float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
   int* flag_host = nullptr;     // pinned, device-mapped word the kernels raise on a contract violation (tile guards,
   int* flag_dev = nullptr;      // k_validate_batch); read by the host after any synchronising call
@@ -1209,6 +1213,33 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
 }
 
 // ------------------------------------------------------------------------------------ passes
+// ------------------------------------------------------------------------------------ few-graph predict, one launch
+constexpr int SMALL_ROWS = 256;             // node rows (= workgroups) of one launch: all co-resident on any gfx950 part
+bool small_path(const v2x_model* m, const DevBatch& d) {
+  if (!m->small_predict || !m->small_h || m->cfg.variable_graphs || d.goff || d.nbr || m->F > 64 || m->L > FZ_MAXL) return false;
+  return d.max_nodes == m->N && d.R <= std::min(SMALL_ROWS, n_cus());
+}
+
+int launch_small_forward(v2x_model* m, hipStream_t st, const DevBatch& d) {
+  SmallFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xe = d.xe; a.row_ptr = d.rp; a.col_idx = d.ci; a.params = m->params;
+  for (int s = 0; s <= m->L; ++s) { a.gnn_off[s] = m->gnn[s].off; a.gnn_sstride[s] = m->gnn[s].slot_stride; }
+  for (int i = 0; i < 4; ++i) { a.dense_off[i] = m->dense[i].off; a.dense_sstride[i] = m->dense[i].slot_stride; }
+  a.hbuf = m->small_h; a.sync = m->small_sync; a.q = m->q;
+  a.N = m->N; a.L = m->L; a.S = m->S; a.C = m->C; a.Dn = m->Dn; a.De = m->De; a.n_rows = d.R;
+  const dim3 grid(m->N, d.B);
+#define V2X_SMALL(FF)                                                                                   \
+  if (m->F == FF) {                                                                                     \
+    auto k = k_predict_small<FF>;                                                                       \
+    LAUNCH(m, "k_predict_small", k, grid, 0, st, a);                                                    \
+    return V2X_OK;                                                                                      \
+  }
+  V2X_SMALL(16) V2X_SMALL(32) V2X_SMALL(64)
+#undef V2X_SMALL
+  FAIL(m, V2X_EINVAL, "small forward: unsupported feat_dim %d", m->F);
+}
+
 int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool with_mlp = true) {
   const int F = m->F, L = m->L;
   const IdxMap x = idx_map(m, d, r);
@@ -1462,6 +1493,15 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   // V2X_FUSED=0 (read when the model is created) keeps the layer-by-layer kernels: A/B measurements and the test that
   // the two paths agree bitwise
   m->compl_sums = env_int("V2X_FUSED_COMPL", 1) != 0;
+  m->small_predict = env_int("V2X_SMALL_PREDICT", 1) != 0;
+  if (m->small_predict && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
+    const size_t hb = (size_t)2 * SMALL_ROWS * m->F * sizeof(float), sb = (size_t)2 * SMALL_ROWS * sizeof(unsigned);
+    void *ph = nullptr, *ps = nullptr;
+    if (hipMalloc(&ph, hb) != hipSuccess || hipMalloc(&ps, sb) != hipSuccess) return fail("allocation");
+    m->small_h = static_cast<float*>(ph);
+    m->small_sync = static_cast<unsigned*>(ps);
+    if (hipMemset(m->small_sync, 0, (size_t)2 * SMALL_ROWS * sizeof(unsigned))) return fail("memset");
+  }
   if (env_int("V2X_FUSED", 1) != 0 && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
     const int FB = m->F / 16, KB = 2 * FB + 1;
     const size_t fwd0 = (size_t)FB * 256 + m->F, fwd = (size_t)KB * FB * 256 + m->F, bwd = (size_t)FB * 2 * FB * 256;
@@ -1506,6 +1546,8 @@ void v2x_destroy(v2x_model* m) {
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (m->flag_host) hipHostFree(m->flag_host);
   if (m->ts_buf) hipFree(m->ts_buf);
+  if (m->small_h) hipFree(m->small_h);
+  if (m->small_sync) hipFree(m->small_sync);
   delete m;
 }
 
@@ -1569,8 +1611,11 @@ int v2x_forward(v2x_model* m, const v2x_batch* b, float* q_out, int q_on_device,
   DevBatch d;
   CHK(resolve_batch(m, b, &d, st));
   CHK(presize(m, d));
-  CHK(run_maybe_graph(m, st, make_key(1, d, nullptr, 0), [&]() { return run_step(m, st, d, false, nullptr, 0); }));
-  m->have_fwd = true;
+  // a few graphs (the rollout predict): the whole network in one launch, nothing saved for a backward pass
+  const bool small = small_path(m, d);
+  if (small) CHK(run_maybe_graph(m, st, make_key(7, d, nullptr, 0), [&]() { return launch_small_forward(m, st, d); }));
+  else CHK(run_maybe_graph(m, st, make_key(1, d, nullptr, 0), [&]() { return run_step(m, st, d, false, nullptr, 0); }));
+  m->have_fwd = !small;
   const size_t qb = (size_t)d.R * m->C * sizeof(float);
   if (q_on_device) {
     HIPCHK(m, hipMemcpyAsync(q_out, m->q, qb, hipMemcpyDeviceToDevice, st));

@@ -116,7 +116,10 @@ float* v2x_param_ptr(v2x_model* m);
 float* v2x_grad_ptr(v2x_model* m);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
-/* forward only: q_out[R][C]  (Model.predict, BS_brain.py:225-231)                           */
+/* forward only: q_out[R][C]  (Model.predict, BS_brain.py:225-231).  Batches of at most 256 node
+ * rows of fixed-size graphs (the rollout predict, BS_brain.py:336,1108,1394: one graph per call) run as
+ * ONE launch (csrc/kernels_small.hpp); nothing is saved for a backward pass, which is only ever
+ * driven by v2x_forward_backward / v2x_train_step / v2x_dqn_step (they run their own forward).      */
 int  v2x_forward(v2x_model* m, const v2x_batch* b, float* q_out, int q_on_device, void* stream);
 
 /* one fit step = forward + Huber + backward + Keras-Adam (Model.fit, BS_brain.py:218-223).

@@ -7,6 +7,8 @@ A ReLU whose pre-activation is ~1e-6 of its layer's scale is gated differently b
 contribution appears / disappears from a bias gradient summed over few rows); that is conditioning, not parity, and it
 is tied to the random draw, so a shape is retried on a fresh draw before it counts as a failure (a kernel bug fails
 every draw)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -33,7 +35,13 @@ def _check(N, F, L, shared, B, topo, seed):
     P = f32_params(spec, rng)
     x, e, adj = random_inputs(rng, B, N, ref_topology=topo and N > 2)
     pb = PackedBatch.from_dense(x, e, adj)
-    eng = GnnEngine(spec)
+    # (the loss below is differentiated at the q of `forward`: keep `forward` on the training path's kernels -- the
+    #  few-graph predict kernel has its own summation order and its own test, test_small_predict_*)
+    os.environ["V2X_SMALL_PREDICT"] = "0"
+    try:
+        eng = GnnEngine(spec)
+    finally:
+        del os.environ["V2X_SMALL_PREDICT"]
     eng.set_weights(oc.params_to_list(P))
     graph = ((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
     M = oc.csr_to_matrix(*graph, dtype=np.float64)
@@ -66,3 +74,51 @@ def test_model_parity_over_shapes(N, F, L, shared, B, topo):
             return
         failures.append(bad)
     pytest.fail("every draw failed: %s" % failures)
+
+
+SMALL = [  # N, F, L, shared, B, reference topology: forwards of at most 256 node rows run k_predict_small
+    (1, 16, 1, False, 1, False), (2, 32, 2, False, 3, False), (4, 16, 2, False, 1, True), (4, 16, 2, True, 64, True),
+    (7, 32, 3, False, 5, False), (20, 64, 2, False, 1, True), (20, 64, 2, False, 12, True), (20, 64, 4, True, 2, True),
+    (20, 32, 2, False, 10, False), (32, 64, 1, False, 8, True), (28, 16, 4, False, 9, False), (20, 64, 2, False, 13, True),
+]
+
+
+@pytest.mark.parametrize("N,F,L,shared,B,topo", SMALL)
+def test_small_predict_vs_oracle_and_training_path(N, F, L, shared, B, topo):
+    """The one-launch few-graph forward (csrc/kernels_small.hpp: workgroup per node, grid barriers between the layers)
+    against the float64 oracle and against the training path's forward; repeated calls (the barrier counters must clean
+    up after themselves) and a batch just above the row limit (13 x 20 = 260 rows: training-path kernels)."""
+    rng = np.random.default_rng(7 * N + F + L + B)
+    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=shared)
+    P = f32_params(spec, rng)
+    x, e, adj = random_inputs(rng, B, N, ref_topology=topo and N > 2)
+    pb = PackedBatch.from_dense(x, e, adj)
+    small = GnnEngine(spec)
+    os.environ["V2X_SMALL_PREDICT"] = "0"
+    try:
+        plain = GnnEngine(spec)
+    finally:
+        del os.environ["V2X_SMALL_PREDICT"]
+    for eng in (small, plain):
+        eng.set_weights(oc.params_to_list(P))
+    M = oc.csr_to_matrix((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx, dtype=np.float64)
+    q_ref, _ = oc.forward(ospec(spec), P, x.reshape(B * N, -1).astype(np.float64), e.reshape(B * N, -1).astype(np.float64), M)
+    scale = max(1.0, np.abs(q_ref).max())
+    qp = plain.forward(pb)
+    for rep in range(3):
+        q = small.forward(pb)
+        assert np.all(np.abs(q - q_ref) <= FWD_RTOL * np.abs(q_ref) + FWD_ATOL * scale), "call %d vs oracle" % rep
+        assert np.all(np.abs(q - qp) <= FWD_RTOL * np.abs(qp) + FWD_ATOL * scale), "call %d vs training path" % rep
+    if B * N > 256:
+        assert np.array_equal(q, qp)                      # above the limit both engines run the same kernels
+    # a fit step after a small predict still works (the predict saved nothing for a backward pass) and moves the weights
+    y = (q_ref + rng.normal(0, 1.0, size=q_ref.shape)).astype(np.float32)
+    w0 = small.get_flat().copy()
+    small.train_step(pb, y)
+    plain.train_step(pb, y)
+    assert not np.array_equal(small.get_flat(), w0)
+    assert np.array_equal(small.get_flat(), plain.get_flat())
+    q2, qp2 = small.forward(pb), plain.forward(pb)
+    assert np.all(np.abs(q2 - qp2) <= FWD_RTOL * np.abs(qp2) + FWD_ATOL * max(1.0, np.abs(qp2).max()))
+    small.close()
+    plain.close()

@@ -171,3 +171,28 @@ def test_agent_training_loop_on_a_batch_of_environments():
     assert reward_step.shape == (1, 3, 52) and np.all(np.isfinite(reward_step)) and np.all(reward_step > 0)
     assert np.all(np.isfinite(loss)) and np.all(q_max >= q_mean - 1e-12)
     assert not np.allclose(w0, np.concatenate([a.ravel() for a in brain.model.get_weights()]))
+
+
+def test_channel_update_threads_do_not_change_the_result():
+    """workers > 1 splits the environments of a step over threads; environments are independent (own stream, own state),
+    so 1, 3 and 8 threads give bit-identical simulators."""
+    from v2xgnn.rl.batched_env import BatchedEnviron
+    up = [3.5 / 2, 3.5 / 2 + 3.5, 250 + 3.5 / 2, 250 + 3.5 + 3.5 / 2, 500 + 3.5 / 2, 500 + 3.5 + 3.5 / 2]
+    dn = [250 - 3.5 - 3.5 / 2, 250 - 3.5 / 2, 500 - 3.5 - 3.5 / 2, 500 - 3.5 / 2, 750 - 3.5 - 3.5 / 2, 750 - 3.5 / 2]
+    le = [3.5 / 2, 3.5 / 2 + 3.5, 433 + 3.5 / 2, 433 + 3.5 + 3.5 / 2, 866 + 3.5 / 2, 866 + 3.5 + 3.5 / 2]
+    ri = [433 - 3.5 - 3.5 / 2, 433 - 3.5 / 2, 866 - 3.5 - 3.5 / 2, 866 - 3.5 / 2, 1299 - 3.5 - 3.5 / 2, 1299 - 3.5 / 2]
+    outs = []
+    for w in (1, 3, 8):
+        env = BatchedEnviron(dn, up, le, ri, 750, 1299, n_envs=11, seeds=[5 + 104729 * e for e in range(11)], workers=w)
+        env.new_random_game(8)
+        rng = np.random.default_rng(3)
+        acc = []
+        for _ in range(6):
+            s, adj = env.observe(4)
+            v2v, v2i, _ = env.act(rng.integers(0, 4, size=(11, 8, 1)))
+            acc += [s.copy(), adj.copy(), v2v.copy(), v2i.copy(), env.pos.copy()]
+        outs.append(acc)
+        assert env.workers == min(w, 11)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert np.array_equal(a, b)

@@ -12,8 +12,11 @@ it is a drop-in for `Environ` in seeded runs.
 
 Only the 1-receiver configuration of the reference (n_Neighbor = 1) is batched.
 """
+import os
+
 import numpy as np
 
+from . import native_sim
 from .environment import Environ
 from .mtstream import MTStream, gauss_uniforms, box_muller
 
@@ -21,7 +24,8 @@ _DIRS = 'udlr'        # direction codes 0..3
 
 
 class BatchedEnviron(object):
-    def __init__(self, down_lane, up_lane, left_lane, right_lane, width, height, n_envs=1, seeds=None, workers=None):
+    def __init__(self, down_lane, up_lane, left_lane, right_lane, width, height, n_envs=1, seeds=None, workers=None,
+                 native=None):
         """seeds: one seed per environment (each environment then reproduces `random.seed(seed); Environ(...)`);
         None with n_envs == 1: the process-wide stdlib generator is used (borrowed and returned around every call).
         workers: threads that share the channel update of a step (3,360 Gaussian draws + their transcendentals per
@@ -29,7 +33,11 @@ class BatchedEnviron(object):
         environments, at most 4 -- measured on the 256-thread host of the MI355X box, 20 links: 100 environments 109 ->
         65 us per environment step with 4 threads, 78 with 8, 115 with 16 (the Python glue between the array
         operations serialises on the GIL); 10 environments are fastest on one thread.  Environments are independent,
-        so the result does not depend on the thread count."""
+        so the result does not depend on the thread count.
+        native: evaluate the array arithmetic of a step (channel update, rates, interference, observation) in
+        libv2xsim.so (csrc/v2xsim.c: the same formulas in C, OpenMP over the environments -- real threads, no GIL).  None:
+        whenever the library is built and there are at least 2 environments (V2X_SIM_NATIVE=0 switches it off); the numpy
+        code below stays the definition, the two agree to the last bits of libm (tests: 1e-12)."""
         self._proto = Environ.__new__(Environ)                 # constants + path-loss models of the single simulator
         p = self._proto
         p.timestep = 0.01
@@ -49,14 +57,26 @@ class BatchedEnviron(object):
         if seeds is None and self.E != 1:
             raise ValueError("n_envs > 1 needs one seed per environment")
         self._shared = seeds is None
-        import os
         if workers is None:
             workers = min(4, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), max(1, self.E // 25))
         self.workers = 1 if self._shared else max(1, min(int(workers), self.E))
+        self.native = (native_sim.available() and self.E >= 2) if native is None else bool(native)
+        if self.native and not native_sim.available():
+            raise RuntimeError("native=True but libv2xsim.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
+        self._mt_keys = self._mt_pos = None
+        if self.native:
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            native_sim.set_threads(max(1, min(self.E, cores, 32)))
+            if not self._shared:                               # the streams' MT19937 states, where the library can advance them
+                self._mt_keys = np.empty((self.E, 624), np.uint32)
+                self._mt_pos = np.zeros(self.E, np.int32)
         self._pool = None
         self.streams = None if self._shared else [MTStream(int(s)) for s in seeds]
         if not self._shared and len(self.streams) != self.E:
             raise ValueError("need %d seeds" % self.E)
+        if self._mt_keys is not None:
+            for e, st in enumerate(self.streams):
+                st.attach(self._mt_keys[e], self._mt_pos, e)
         # lane tables of the mobility rule, in the reference's checking order (Environment.py:247-324):
         # direction -> (moving axis, sign, [(lanes, new direction, side-step sign, gap sign)])
         L, R, U, D = p.left_lanes, p.right_lanes, p.up_lanes, p.down_lanes
@@ -77,11 +97,20 @@ class BatchedEnviron(object):
             if self.env._shared:
                 self.s = [MTStream.borrow_stdlib()]
                 return self.s
+            if self.env._mt_keys is not None:                  # streams whose state lives in the library's arrays: one
+                self.live = []                                 # pull at a stream's first draw of this block, one push at the end
+                for st in self.env.streams:
+                    st.session = self.live
             return self.env.streams
 
         def __exit__(self, *exc):
             if self.env._shared:
                 self.s[0].return_stdlib()
+            elif self.env._mt_keys is not None:
+                for st in self.live:
+                    st._push(end_of_session=True)
+                for st in self.env.streams:
+                    st.session = None
 
     def _rng(self):
         return BatchedEnviron._Borrow(self)
@@ -190,7 +219,16 @@ class BatchedEnviron(object):
         if (n + n * n + 2 * n * rb + 2 * n * n * rb) & 1:      # keep the odd value cached like random.gauss would
             raise NotImplementedError("odd number of draws per step")
         with self._rng() as rs:
-            if self.workers <= 1 or E < 2:
+            if self.native:
+                n_draws = n + n * n + 2 * n * rb + 2 * n * n * rb
+                if self._mt_keys is not None:                  # all streams advance in C, one thread per group of environments
+                    if any(s.gauss_next is not None for s in rs):
+                        raise RuntimeError("a stream holds a cached gauss value")
+                    u = native_sim.mt_uniforms(self._mt_keys, self._mt_pos, n_draws)
+                else:
+                    u = gauss_uniforms(rs, n_draws)
+                out = [native_sim.channels(u, self.vel, self.pos, self._v2i_shadow, self._v2v_shadow, rb)]
+            elif self.workers <= 1 or E < 2:
                 out = [self._channels_of(rs, 0, E)]
             else:
                 if self._pool is None:
@@ -232,6 +270,12 @@ class BatchedEnviron(object):
         station [E, rb] (Environment.py:408-458, every link active, one receiver per link)."""
         E, n, rb = self.E, self.n_Veh, self.n_RB
         ch = np.asarray(actions).reshape(E, n).astype(np.int64)
+        if self.native:
+            v2v_rate, v2i_rate, interference, self.V2I_Interference, self.V2V_Interference = native_sim.reward(
+                ch, self.dest, self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading, self.V2I_channels_abs,
+                self.V2V_power_dB_List[self.fixed_v2v_power_index], self.V2I_power_dB, self.vehAntGain, self.bsAntGain,
+                self.bsNoiseFigure, self.vehNoiseFigure, self.sig2)
+            return v2v_rate, v2i_rate, interference
         ei = np.arange(E)[:, None]
         ki = np.arange(n)[None, :]
         rx = self.dest
@@ -260,6 +304,10 @@ class BatchedEnviron(object):
     def Compute_Interference(self, actions):
         """Environment.py:460-493 (observable part: noise + the co-channel V2I transmitter), [E, N, 1, rb] in dB."""
         E, n, rb = self.E, self.n_Veh, self.n_RB
+        if self.native and rb <= n:
+            self.V2V_Interference_all = native_sim.interference_db(self.dest, self.V2V_channels_with_fastfading, self.V2I_power_dB,
+                                                                   self.vehAntGain, self.vehNoiseFigure, self.sig2)
+            return
         r = np.arange(rb)
         out = np.zeros((E, n, 1, rb)) + self.sig2
         v2v = self.V2V_channels_with_fastfading
@@ -281,6 +329,9 @@ class BatchedEnviron(object):
         (BS_brain.py:389-407, :458-467) and the adjacency [E, N, N] (Adj[p, q] = 0 for p == q and for the receiver p of
         link q, :441-445)."""
         E, n, C = self.E, self.n_Veh, n_channels
+        if self.native and C == self.n_RB and n > 2:
+            return native_sim.observe(self.dest, self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading,
+                                      self.V2V_power_dB_List[self.fixed_v2v_power_index], C)
         A, Bc = 80, 60
         v2v, v2i = self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading
         ei = np.arange(E)[:, None]

@@ -18,18 +18,53 @@ _TWOPI = 2.0 * np.pi
 class MTStream(object):
     def __init__(self, seed=None, _state=None):
         self._rs = np.random.RandomState(0)
+        self._ext = None               # attach(): the MT19937 state lives in caller-owned arrays (bulk draws in C)
+        self.session = None            # a list while the owner is inside one `with env._rng()` block
+        self._live = False             # pulled in during the current session: no per-draw synchronisation until it ends
         self.gauss_next = None
         if _state is None:
             _state = _random.Random(seed).getstate()       # CPython seeds through init_by_array: reuse it verbatim
         self._import(_state)
+
+    # ------------------------------------------------------------------ externally held state (rl/native_sim.py)
+    def attach(self, keys_row, pos_arr, idx):
+        """From now on the authoritative MT19937 state is keys_row[624] / pos_arr[idx] (rows of arrays the batched simulator
+        hands to libv2xsim.so for its bulk draws); every numpy-side draw of this object pulls the state in first and pushes
+        it back afterwards, so the two views never diverge.  Inside a session (`self.session` is a list: the owner's
+        `with _rng()` block) the first draw pulls the state in and the owner pushes it back once at the end."""
+        _, keys, pos = self._rs.get_state()[:3]
+        keys_row[:] = keys
+        pos_arr[idx] = pos
+        self._ext = (keys_row, pos_arr, idx)
+
+    def _pull(self):
+        if self._ext is None or self._live:
+            return
+        keys_row, pos_arr, idx = self._ext
+        self._rs.set_state(('MT19937', keys_row, int(pos_arr[idx])))
+        if self.session is not None:
+            self._live = True
+            self.session.append(self)
+
+    def _push(self, end_of_session=False):
+        if self._ext is None or (self._live and not end_of_session):
+            return
+        keys_row, pos_arr, idx = self._ext
+        _, keys, pos = self._rs.get_state()[:3]
+        keys_row[:] = keys
+        pos_arr[idx] = pos
+        if end_of_session:
+            self._live = False
 
     # ------------------------------------------------------------------ state exchange with the stdlib generator
     def _import(self, state):
         _, st, gauss_next = state
         self._rs.set_state(('MT19937', np.array(st[:-1], dtype=np.uint32), st[-1]))
         self.gauss_next = gauss_next
+        self._push()
 
     def _export(self):
+        self._pull()
         _, keys, pos = self._rs.get_state()[:3]
         return (3, tuple(keys.tolist()) + (int(pos),), self.gauss_next)
 
@@ -43,10 +78,16 @@ class MTStream(object):
 
     # ------------------------------------------------------------------ random.Random's algorithms
     def random(self):
-        return float(self._rs.random_sample())
+        self._pull()
+        v = float(self._rs.random_sample())
+        self._push()
+        return v
 
     def random_array(self, k):
-        return self._rs.random_sample(k)
+        self._pull()
+        v = self._rs.random_sample(k)
+        self._push()
+        return v
 
     def uniform(self, a, b):
         return a + (b - a) * self.random()
@@ -55,7 +96,10 @@ class MTStream(object):
         """k <= 32: one 32-bit output, top bits (random.getrandbits)."""
         if not 0 < k <= 32:
             raise ValueError("getrandbits: 1..32 bits")
-        return int.from_bytes(self._rs.bytes(4), 'little') >> (32 - k)
+        self._pull()
+        v = int.from_bytes(self._rs.bytes(4), 'little') >> (32 - k)
+        self._push()
+        return v
 
     def _randbelow(self, n):
         k = int(n).bit_length()
@@ -113,7 +157,7 @@ class MTStream(object):
             i = 1
         pairs = (n - i + 1) // 2
         if pairs:
-            u = self._rs.random_sample(2 * pairs)
+            u = self.random_array(2 * pairs)
             x2pi = u[0::2] * _TWOPI
             g2rad = np.sqrt(-2.0 * np.log(1.0 - u[1::2]))
             z = np.stack([np.cos(x2pi) * g2rad, np.sin(x2pi) * g2rad], axis=1).reshape(-1)
@@ -131,7 +175,7 @@ def gauss_uniforms(streams, n):
     for e, s in enumerate(streams):
         if s.gauss_next is not None:
             raise RuntimeError("stream %d holds a cached gauss value" % e)
-        u[e] = s._rs.random_sample(2 * pairs)
+        u[e] = s.random_array(2 * pairs)
     return u
 
 

@@ -1,0 +1,118 @@
+"""ctypes binding of libv2xsim.so (csrc/v2xsim.c): the array arithmetic of a batched simulator step in C + OpenMP.
+
+The numpy expressions of rl/batched_env.py stay the definition (and the fallback when the library is not built, or with
+V2X_SIM_NATIVE=0); the library evaluates the same formulas in the same order, one OpenMP thread per group of
+environments -- which numpy cannot do (its Python glue serialises on the GIL: rl/batched_env.py, `workers`).
+Random streams stay in Python; the library is handed the uniforms of a step."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_lib = None
+_tried = False
+
+
+def _load():
+    global _lib, _tried
+    if _tried:
+        return _lib
+    _tried = True
+    if os.environ.get("V2X_SIM_NATIVE", "1") == "0":
+        return None
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.environ.get("V2XSIM_LIB", os.path.join(here, "libv2xsim.so"))
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    if lib.v2xsim_abi() != 1:
+        return None
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
+    lib.v2xsim_channels.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp]
+    lib.v2xsim_reward.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp] + [C.c_double] * 7 + [dp] * 5
+    lib.v2xsim_interference.argtypes = [C.c_int, C.c_int, C.c_int, ip, dp] + [C.c_double] * 4 + [dp]
+    lib.v2xsim_observe.argtypes = [C.c_int, C.c_int, C.c_int, ip, dp, dp, C.c_double, dp, dp]
+    lib.v2xsim_set_threads.argtypes = [C.c_int]
+    lib.v2xsim_mt_uniforms.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), dp, C.c_int]
+    for f in (lib.v2xsim_channels, lib.v2xsim_reward, lib.v2xsim_interference, lib.v2xsim_observe, lib.v2xsim_set_threads,
+              lib.v2xsim_mt_uniforms):
+        f.restype = None
+    _lib = lib
+    return lib
+
+
+def available():
+    return _load() is not None
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def _c(a, dtype=np.float64):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def set_threads(n):
+    _load().v2xsim_set_threads(int(n))
+
+
+def channels(u, vel, pos, v2i_shadow, v2v_shadow, rb):
+    """One channel update of E environments from their uniforms u[E, n_u]; returns the six arrays of
+    BatchedEnviron._channels_of (new shadowing states first)."""
+    lib = _load()
+    E, n = vel.shape
+    u, vel, pos = _c(u), _c(vel), _c(pos)
+    v2i_shadow, v2v_shadow = _c(v2i_shadow).copy(), _c(v2v_shadow).copy()
+    v2v_abs, v2i_abs = np.empty((E, n, n)), np.empty((E, n))
+    v2v_ff, v2i_ff = np.empty((E, n, n, rb)), np.empty((E, n, rb))
+    scratch = np.empty_like(u)
+    lib.v2xsim_channels(E, n, rb, _d(u), u.shape[1], _d(vel), _d(pos), _d(v2i_shadow), _d(v2v_shadow), _d(v2v_abs), _d(v2i_abs),
+                        _d(v2v_ff), _d(v2i_ff), _d(scratch))
+    return v2i_shadow, v2v_shadow, v2v_abs, v2i_abs, v2v_ff, v2i_ff
+
+
+def reward(ch, dest, v2v_ff, v2i_ff, v2i_abs, p_v2v, p_v2i, veh_gain, bs_gain, bs_nf, veh_nf, sig2):
+    lib = _load()
+    E, n, _, rb = v2v_ff.shape
+    m = min(rb, n)
+    ch, dest = _c(ch, np.int64), _c(dest, np.int64)
+    v2v_ff, v2i_ff, v2i_abs = _c(v2v_ff), _c(v2i_ff), _c(v2i_abs)
+    v2v_rate, v2i_rate = np.empty((E, n, 1)), np.empty((E, m))
+    interference, v2i_interf, v2v_interf = np.empty((E, rb)), np.empty((E, rb)), np.empty((E, n, 1))
+    lib.v2xsim_reward(E, n, rb, _i(ch), _i(dest), _d(v2v_ff), _d(v2i_ff), _d(v2i_abs), p_v2v, p_v2i, veh_gain, bs_gain, bs_nf,
+                      veh_nf, sig2, _d(v2v_rate), _d(v2i_rate), _d(interference), _d(v2i_interf), _d(v2v_interf))
+    return v2v_rate, v2i_rate, interference, v2i_interf, v2v_interf
+
+
+def interference_db(dest, v2v_ff, p_v2i, veh_gain, veh_nf, sig2):
+    lib = _load()
+    E, n, _, rb = v2v_ff.shape
+    dest, v2v_ff = _c(dest, np.int64), _c(v2v_ff)
+    out = np.empty((E, n, 1, rb))
+    lib.v2xsim_interference(E, n, rb, _i(dest), _d(v2v_ff), p_v2i, veh_gain, veh_nf, sig2, _d(out))
+    return out
+
+
+def observe(dest, v2v_ff, v2i_ff, power, n_channels):
+    lib = _load()
+    E, n, _, rb = v2v_ff.shape
+    dest, v2v_ff, v2i_ff = _c(dest, np.int64), _c(v2v_ff), _c(v2i_ff)
+    state, adj = np.empty((E, n, 3 * n_channels + 1)), np.empty((E, n, n))
+    lib.v2xsim_observe(E, n, n_channels, _i(dest), _d(v2v_ff), _d(v2i_ff), float(power), _d(state), _d(adj))
+    return state, adj
+
+
+def mt_uniforms(keys, pos, n_u):
+    """The next n_u random.random() values of every stream: keys [E, 624] uint32 and pos [E] int32 are the MT19937 states
+    (numpy RandomState layout) and are advanced in place."""
+    lib = _load()
+    E = keys.shape[0]
+    assert keys.dtype == np.uint32 and keys.flags.c_contiguous and pos.dtype == np.int32 and pos.flags.c_contiguous
+    out = np.empty((E, n_u))
+    lib.v2xsim_mt_uniforms(E, keys.ctypes.data_as(C.POINTER(C.c_uint32)), pos.ctypes.data_as(C.POINTER(C.c_int32)), _d(out), n_u)
+    return out

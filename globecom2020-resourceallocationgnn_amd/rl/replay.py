@@ -78,6 +78,33 @@ class DeviceReplay(object):
                             pack_xe(np.asarray(x_next, np.float32), np.asarray(e_next, np.float32)),
                             colrow, np.asarray(action, np.int32).reshape(-1), float(reward), mask, regular))
 
+    def add_many(self, x, e, adj, action, reward, x_next, e_next):
+        """K transitions at once (the batched rollout stores one per environment and step): x, x_next [K, n, Dn]; e, e_next
+        [K, n, De]; adj [K, n, n]; action [K, n]; reward [K].  Same staged tuples as K calls of add(), built with array
+        operations."""
+        adj = np.asarray(adj)
+        K, n = adj.shape[0], self.n
+        if n > 31:
+            raise ValueError("DeviceReplay keeps the adjacency as one 32-bit source mask per link: at most 31 links")
+        if self.n_edges is None:
+            self.n_edges = n * (n - 2)
+        nz = adj != 0
+        deg = nz.sum(axis=1)                                             # [K, q] in-degrees
+        regular = np.all(deg == n - 2, axis=1)
+        mask = (nz.astype(np.int64) << np.arange(n, dtype=np.int64)[None, :, None]).sum(axis=1).astype(np.int32)   # [K, q]: bits p
+        col = np.zeros((K, max(self.n_edges, 1)), np.int32)
+        if regular.any():                                               # CSR by destination, ascending sources (adj_to_csr order)
+            src = np.nonzero(np.transpose(nz[regular], (0, 2, 1)))[2].astype(np.int32)
+            col[regular] = src.reshape(int(regular.sum()), self.n_edges)
+        x, e = np.asarray(x, np.float32), np.asarray(e, np.float32)
+        xn, en = np.asarray(x_next, np.float32), np.asarray(e_next, np.float32)
+        xe = pack_xe(x.reshape(K * n, -1), e.reshape(K * n, -1)).reshape(K, n, -1)
+        xe_next = pack_xe(xn.reshape(K * n, -1), en.reshape(K * n, -1)).reshape(K, n, -1)
+        action = np.asarray(action, np.int32).reshape(K, n)
+        reward = np.asarray(reward, np.float64).reshape(K)
+        for k in range(K):
+            self._stage.append((xe[k], xe_next[k], col[k], action[k], float(reward[k]), mask[k], bool(regular[k])))
+
     def __len__(self):
         return min(self.capacity, self.size + len(self._stage))
 

@@ -205,3 +205,23 @@ def test_evaluate_training_diff_trials_matches_reference_loop(tmp_path):
         # the reference builds 'cwd\\folder\\name' (Windows separators): compare the file names
         assert loads == [s.split('\\')[-1] for s in g[tag + 'loads']]
     assert os.path.basename(agent.checkpoint_dir('/x')) == 'Train-Result-RealFB-16-Batch-32-Gamma-0.5-V2Iweight-0.1'
+
+
+def test_random_channels_consume_the_numpy_stream_like_the_reference_loop():
+    """agent._random_channels: one randint call for all links == the reference's per-link np.random.choice(range(C), nn)
+    loop, value for value, and it leaves the process-wide stream in the same state."""
+    from v2xgnn.rl.agent import _random_channels
+    for C in (3, 4, 5, 7):
+        for nn in (1, 2):
+            for n in (4, 20):
+                np.random.seed(5 + C)
+                np.random.random()
+                ref = np.zeros((n, nn))
+                for k in range(n):
+                    ref[k, :] = np.random.choice(range(0, C), nn)
+                after_ref = np.random.random()
+                np.random.seed(5 + C)
+                np.random.random()
+                got = _random_channels(n, nn, C)
+                assert np.array_equal(ref.astype(int), got) and got.dtype.kind == 'i'
+                assert np.random.random() == after_ref

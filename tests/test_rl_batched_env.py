@@ -196,3 +196,90 @@ def test_channel_update_threads_do_not_change_the_result():
     for other in outs[1:]:
         for a, b in zip(outs[0], other):
             assert np.array_equal(a, b)
+
+
+def _lanes():
+    up = [3.5 / 2, 3.5 / 2 + 3.5, 250 + 3.5 / 2, 250 + 3.5 + 3.5 / 2, 500 + 3.5 / 2, 500 + 3.5 + 3.5 / 2]
+    dn = [250 - 3.5 - 3.5 / 2, 250 - 3.5 / 2, 500 - 3.5 - 3.5 / 2, 500 - 3.5 / 2, 750 - 3.5 - 3.5 / 2, 750 - 3.5 / 2]
+    le = [3.5 / 2, 3.5 / 2 + 3.5, 433 + 3.5 / 2, 433 + 3.5 + 3.5 / 2, 866 + 3.5 / 2, 866 + 3.5 + 3.5 / 2]
+    ri = [433 - 3.5 - 3.5 / 2, 433 - 3.5 / 2, 866 - 3.5 - 3.5 / 2, 866 - 3.5 / 2, 1299 - 3.5 - 3.5 / 2, 1299 - 3.5 / 2]
+    return dn, up, le, ri
+
+
+@pytest.mark.parametrize("n_links", [4, 20])
+def test_native_step_equals_the_numpy_step(n_links):
+    """csrc/v2xsim.c (C + OpenMP: MT19937 bulk draws, Box-Muller, shadowing, path loss, fast fading, rates, interference,
+    observation) against the numpy expressions it restates: integer state (positions' lane logic, directions, receivers)
+    and the random streams stay IDENTICAL, real-valued outputs agree to libm rounding (the shadowing recursion carries
+    it along: 1e-10 after 150 steps is generous)."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    E = 5
+    envs = []
+    for native in (False, True):
+        env = BatchedEnviron(*_lanes(), 750, 1299, n_envs=E, seeds=[11 + 104729 * e for e in range(E)], workers=1, native=native)
+        env.new_random_game(n_links)
+        envs.append(env)
+    a, b = envs
+    assert not a.native and b.native
+    rng = np.random.default_rng(1)
+    for it in range(150):
+        (sa, aa), (sb, ab) = a.observe(4), b.observe(4)
+        act = rng.integers(0, 4, size=(E, n_links, 1))
+        ra, rb = a.act(act), b.act(act)
+        assert np.array_equal(a.pos, b.pos) and np.array_equal(a.dirs, b.dirs) and np.array_equal(aa, ab)
+        for x, y in list(zip(ra, rb)) + [(sa, sb), (a.V2V_Interference_all, b.V2V_Interference_all),
+                                         (a.V2I_Interference, b.V2I_Interference), (a.V2V_Interference, b.V2V_Interference)]:
+            assert x.shape == y.shape
+            assert np.allclose(x, y, rtol=1e-10, atol=0), (it, np.abs(x - y).max())
+    for s0, s1 in zip(a.streams, b.streams):
+        assert s0._export() == s1._export()                    # same MT19937 position after 150 x 3,360 (or 160) draws
+
+
+def test_native_mt19937_is_the_stdlib_stream():
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    keys, pos = np.empty((3, 624), np.uint32), np.zeros(3, np.int32)
+    streams = [MTStream(s) for s in (0, 12345, 2 ** 40 + 7)]
+    for e, s in enumerate(streams):
+        s.random_array(100 * e + 1)                            # different positions inside the 624-word block
+        s.attach(keys[e], pos, e)
+    want = [random.Random(s) for s in (0, 12345, 2 ** 40 + 7)]
+    for e, r in enumerate(want):
+        for _ in range(100 * e + 1):
+            r.random()
+    got = native_sim.mt_uniforms(keys, pos, 1500)              # crosses two reloads of the state
+    for e, r in enumerate(want):
+        assert got[e].tolist() == [r.random() for _ in range(1500)]
+        assert streams[e].random() == r.random()               # the numpy-side view continues where the C draws stopped
+        assert streams[e].randint(0, 10 ** 6) == r.randint(0, 10 ** 6)
+    assert native_sim.mt_uniforms(keys, pos, 2)[1].tolist() == [want[1].random(), want[1].random()]
+
+
+def test_device_replay_add_many_stages_what_add_stages():
+    """The batched rollout stores E transitions per step with one vectorised call; the staged records (packed features,
+    CSR columns, source masks, regularity flag) must be those of E single adds -- incl. an irregular graph (a link that
+    is its own receiver: in-degree n - 1)."""
+    from v2xgnn.rl.replay import DeviceReplay
+    rng = np.random.default_rng(5)
+    n, K = 6, 7
+    adj = np.ones((K, n, n)) - np.eye(n)[None]
+    for k in range(K):
+        dest = rng.integers(0, n - 1, size=n)
+        dest = dest + (dest >= np.arange(n))
+        adj[k, dest, np.arange(n)] = 0
+    adj[3, :, 2] = 1 - np.eye(n)[2]                            # link 2 of transition 3: receiver == itself -> only the self edge is missing
+    x, e = rng.normal(size=(K, n, 9)), rng.normal(size=(K, n, 4))
+    x2, e2 = rng.normal(size=(K, n, 9)), rng.normal(size=(K, n, 4))
+    act, rew = rng.integers(0, 4, size=(K, n)), rng.normal(size=K)
+    one, many = DeviceReplay(64, n), DeviceReplay(64, n)
+    for k in range(K):
+        one.add(x[k], e[k], adj[k], act[k], rew[k], x2[k], e2[k])
+    many.add_many(x, e, adj, act, rew, x2, e2)
+    assert len(one._stage) == len(many._stage) == K
+    for a, b in zip(one._stage, many._stage):
+        for u, v in zip(a, b):
+            assert np.array_equal(np.asarray(u), np.asarray(v)), (u, v)
+    assert [s[6] for s in many._stage] == [True, True, True, False, True, True, True]

@@ -241,7 +241,9 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
     return;
   }
+  ts.mark();                                                     // (TS) row_ptr[first], row_ptr[last] known
   csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
+  ts.mark();                                                     // (TS) CSR slice in LDS
   constexpr bool compl_sums = COMPL;     // (a compile-time form: both gathers side by side cost registers and spill)
   if (compl_sums) {                      // non-neighbour masks of the tile's rows (while the embed operands are in flight)
     __syncthreads();
@@ -252,6 +254,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
         for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) nb |= 1u << x.sCol[e];
       x.sC[r] = ~nb & valid;
     }
+    ts.mark();                                                   // (TS) masks built
   }
 
   typedef const __attribute__((address_space(4))) uint64_t* CQ;

@@ -30,4 +30,4 @@ for name, t in zip(("forward", "backward"), np.array(buf[:], np.int64).reshape(2
         row = t[w][t[w] > 0]
         print("  wave %d:" % w, " ".join("%6.2f" % ((v - t0) / 100.0) for v in row))
 print("backward marks: 0 start | 1 tile + masks ready | per stage: gathers done, slot done x n, barrier, tile replaced | end")
-print("marks: 0 start | 1 embed done | 2 barrier | per stage: per slot [loads issued, gather done, weights landed, mfma+stores issued] ... | stores drained | barrier | reloaded | ... | end   (us)")
+print("forward marks: 0 start | 1 row_ptr ends known | 2 CSR slice in LDS | 3 masks built (complement form) | 4 embed done | 5 barrier | per stage: gathers done, slot done x n, (stores drained,) barrier, tile replaced | end   (us)")

@@ -246,3 +246,49 @@ def test_device_replay_handles_a_link_that_is_its_own_receiver():
         eng.set_weights(oc.params_to_list(f32_params(spec, np.random.default_rng(1))))
         assert np.array_equal(eng.forward(sb).cpu().numpy(), eng.forward(ref))
         eng.close()
+
+
+@pytest.mark.parametrize("n_veh,feat,batch,n_envs", [(4, 16, 64, 6), (20, 64, 256, 10)])
+def test_batched_rollouts_on_the_engine(n_veh, feat, batch, n_envs):
+    """The DQN loop with E simulators stepped as arrays (native C + OpenMP step when libv2xsim.so is built), one forward
+    pass per step for all greedy environments (k_predict_small for up to 256 node rows), transitions stored in the HBM
+    replay memory with one vectorised add per step: same episode as with the HOST replay memory (same transitions, same
+    minibatches, losses and weights to fp32 rounding), and the numpy simulator step gives the same trajectory."""
+    from v2xgnn.rl import Agent, RL_Config, native_sim
+    from v2xgnn.rl.train import start_env_batched
+
+    def episode(device_replay, native):
+        random.seed(21)
+        np.random.seed(21)
+        old = os.environ.get("V2X_SIM_NATIVE")
+        os.environ["V2X_SIM_NATIVE"] = "1" if native else "0"
+        native_sim._tried, native_sim._lib = False, None
+        try:
+            env = start_env_batched(n_veh, n_envs, 21)
+        finally:
+            if old is None:
+                del os.environ["V2X_SIM_NATIVE"]
+            else:
+                os.environ["V2X_SIM_NATIVE"] = old
+            native_sim._tried, native_sim._lib = False, None
+        cfg = RL_Config()
+        cfg.set_train_value(feat, 0.5, batch, 1, 0.1)
+        agent = Agent(n_veh, env.n_RB, env.n_Neighbor, feat, env, cfg, seed=21, device_replay=device_replay)
+        loss, reward_step, _, q_mean, q_max, _, _ = agent.train(1, 4)
+        w = np.concatenate([a.ravel() for a in agent.brain.model.get_weights()])
+        return env, agent, loss, reward_step, q_mean, w
+
+    env_d, ag_d, loss_d, rew_d, qm_d, w_d = episode(True, native_sim.available())
+    env_h, ag_h, loss_h, rew_h, qm_h, w_h = episode(False, native_sim.available())
+    assert ag_d.device_replay is not None and ag_h.device_replay is None
+    assert env_d.native == native_sim.available()
+    assert np.all(np.isfinite(loss_d)) and ag_d.num_step == ag_h.num_step == 4 * (-(-50 // n_envs) * n_envs)
+    assert np.array_equal(rew_d, rew_h)                       # same rollouts (exploration stream, greedy actions)
+    assert np.allclose(loss_d, loss_h, rtol=2e-4, atol=1e-6) and np.allclose(qm_d, qm_h, rtol=1e-4, atol=1e-5)
+    assert np.allclose(w_d, w_h, rtol=1e-3, atol=2e-5)
+    if native_sim.available():                                # the numpy step: same trajectory to libm rounding
+        env_n, ag_n, loss_n, rew_n, qm_n, w_n = episode(True, False)
+        assert not env_n.native
+        assert np.array_equal(env_n.pos, env_d.pos) and np.array_equal(env_n.dirs, env_d.dirs)
+        assert np.allclose(rew_n, rew_d, rtol=1e-9, atol=1e-12)
+        assert np.allclose(loss_n, loss_d, rtol=2e-4, atol=1e-6)

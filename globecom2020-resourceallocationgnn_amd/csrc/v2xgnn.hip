@@ -1217,6 +1217,7 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
 constexpr int SMALL_ROWS = 256;             // node rows (= workgroups) of one launch: all co-resident on any gfx950 part
 bool small_path(const v2x_model* m, const DevBatch& d) {
   if (!m->small_predict || !m->small_h || m->cfg.variable_graphs || d.goff || d.nbr || m->F > 64 || m->L > FZ_MAXL) return false;
+  if (m->N > 32) return false;                 // the kernel keeps a node's in-neighbours in a 32-entry LDS list
   return d.max_nodes == m->N && d.R <= std::min(SMALL_ROWS, n_cus());
 }
 

@@ -76,6 +76,8 @@ struct v2x_model {
   bool small_predict = true;                    // V2X_SMALL_PREDICT (read at create): few-graph forwards in one launch (kernels_small.hpp)
   float* small_h = nullptr;                     // its exchange buffer [2][SMALL_ROWS][F]
   unsigned* small_sync = nullptr;               // and per-graph barrier counters [SMALL_ROWS][2]
+  char* pin_h = nullptr; char* pin_d = nullptr;  // pinned, device-mapped window for host-resident few-graph predicts: the
+                                                // kernel reads the batch and writes q THROUGH it (no copy launches)
   float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
   int* flag_host = nullptr;     // pinned, device-mapped word the kernels raise on a contract violation (tile guards,
   int* flag_dev = nullptr;      // k_validate_batch); read by the host after any synchronising call
@@ -1221,13 +1223,15 @@ bool small_path(const v2x_model* m, const DevBatch& d) {
   return d.max_nodes == m->N && d.R <= std::min(SMALL_ROWS, n_cus());
 }
 
-int launch_small_forward(v2x_model* m, hipStream_t st, const DevBatch& d) {
+constexpr size_t PIN_XE = 0, PIN_RP = 16384, PIN_CI = 20480, PIN_Q = 53248, PIN_BYTES = 65536;   // SMALL_ROWS rows, <= 31 in-edges each
+
+int launch_small_forward(v2x_model* m, hipStream_t st, const DevBatch& d, float* q_dst = nullptr) {
   SmallFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.xe = d.xe; a.row_ptr = d.rp; a.col_idx = d.ci; a.params = m->params;
   for (int s = 0; s <= m->L; ++s) { a.gnn_off[s] = m->gnn[s].off; a.gnn_sstride[s] = m->gnn[s].slot_stride; }
   for (int i = 0; i < 4; ++i) { a.dense_off[i] = m->dense[i].off; a.dense_sstride[i] = m->dense[i].slot_stride; }
-  a.hbuf = m->small_h; a.sync = m->small_sync; a.q = m->q;
+  a.hbuf = m->small_h; a.sync = m->small_sync; a.q = q_dst ? q_dst : m->q;
   a.N = m->N; a.L = m->L; a.S = m->S; a.C = m->C; a.Dn = m->Dn; a.De = m->De; a.n_rows = d.R;
   const dim3 grid(m->N, d.B);
 #define V2X_SMALL(FF)                                                                                   \
@@ -1501,6 +1505,14 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     if (hipMalloc(&ph, hb) != hipSuccess || hipMalloc(&ps, sb) != hipSuccess) return fail("allocation");
     m->small_h = static_cast<float*>(ph);
     m->small_sync = static_cast<unsigned*>(ps);
+    void *hh = nullptr, *hdv = nullptr;
+    if (env_int("V2X_SMALL_PINNED", 1) != 0 && hipHostMalloc(&hh, PIN_BYTES, hipHostMallocMapped) == hipSuccess &&
+        hipHostGetDevicePointer(&hdv, hh, 0) == hipSuccess) {
+      m->pin_h = static_cast<char*>(hh); m->pin_d = static_cast<char*>(hdv);
+    } else {
+      (void)hipGetLastError();
+      if (hh) hipHostFree(hh);
+    }
     if (hipMemset(m->small_sync, 0, (size_t)2 * SMALL_ROWS * sizeof(unsigned))) return fail("memset");
   }
   if (env_int("V2X_FUSED", 1) != 0 && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
@@ -1549,6 +1561,7 @@ void v2x_destroy(v2x_model* m) {
   if (m->ts_buf) hipFree(m->ts_buf);
   if (m->small_h) hipFree(m->small_h);
   if (m->small_sync) hipFree(m->small_sync);
+  if (m->pin_h) hipHostFree(m->pin_h);
   delete m;
 }
 
@@ -1609,6 +1622,31 @@ int v2x_forward(v2x_model* m, const v2x_batch* b, float* q_out, int q_on_device,
   if (!m || !q_out) FAIL(m, V2X_EINVAL, "forward: null argument");
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(m, hipSetDevice(m->cfg.device));
+  // host batch in, host q out, a few graphs (BS.predict in the rollout loop): the kernel reads the batch from, and writes q
+  // to, a pinned device-mapped window -- one launch and one stream synchronisation, no copy launches at all
+  if (b && !b->on_device && !q_on_device && m->pin_h && b->xe && b->row_ptr && b->n_rows > 0 && b->n_rows <= SMALL_ROWS &&
+      b->n_edges >= 0 && (size_t)b->n_edges * 4 <= PIN_Q - PIN_CI && (b->n_edges == 0 || b->col_idx)) {
+    DevBatch hd;
+    memset(&hd, 0, sizeof(hd));
+    hd.B = b->n_graphs; hd.R = b->n_rows; hd.E = b->n_edges; hd.max_nodes = b->max_nodes; hd.max_edges = b->max_edges;
+    hd.goff = b->graph_off; hd.nbr = b->nbr_init;
+    if (hd.B > 0 && !m->cfg.variable_graphs && hd.R == hd.B * m->N && small_path(m, hd)) {
+      CHK(validate_host_batch(m, b, m->N));
+      memcpy(m->pin_h + PIN_XE, b->xe, (size_t)hd.R * XE * sizeof(float));
+      memcpy(m->pin_h + PIN_RP, b->row_ptr, (size_t)(hd.R + 1) * 4);
+      if (hd.E > 0) memcpy(m->pin_h + PIN_CI, b->col_idx, (size_t)hd.E * 4);
+      hd.xe = reinterpret_cast<const float*>(m->pin_d + PIN_XE);
+      hd.rp = reinterpret_cast<const int32_t*>(m->pin_d + PIN_RP);
+      hd.ci = reinterpret_cast<const int32_t*>(m->pin_d + PIN_CI);
+      float* qd = reinterpret_cast<float*>(m->pin_d + PIN_Q);
+      CHK(run_maybe_graph(m, st, make_key(8, hd, qd, 0), [&]() { return launch_small_forward(m, st, hd, qd); }));
+      m->have_fwd = false;
+      HIPCHK(m, hipStreamSynchronize(st));
+      CHK(check_flag(m));
+      memcpy(q_out, m->pin_h + PIN_Q, (size_t)hd.R * m->C * sizeof(float));
+      return V2X_OK;
+    }
+  }
   DevBatch d;
   CHK(resolve_batch(m, b, &d, st));
   CHK(presize(m, d));

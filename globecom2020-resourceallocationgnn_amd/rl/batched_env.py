@@ -36,7 +36,7 @@ class BatchedEnviron(object):
         so the result does not depend on the thread count.
         native: evaluate the array arithmetic of a step (channel update, rates, interference, observation) in
         libv2xsim.so (csrc/v2xsim.c: the same formulas in C, OpenMP over the environments -- real threads, no GIL).  None:
-        whenever the library is built and there are at least 2 environments (V2X_SIM_NATIVE=0 switches it off); the numpy
+        whenever the library is built and the environments own their streams (V2X_SIM_NATIVE=0 switches it off); the numpy
         code below stays the definition, the two agree to the last bits of libm (tests: 1e-12)."""
         self._proto = Environ.__new__(Environ)                 # constants + path-loss models of the single simulator
         p = self._proto
@@ -60,7 +60,7 @@ class BatchedEnviron(object):
         if workers is None:
             workers = min(4, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), max(1, self.E // 25))
         self.workers = 1 if self._shared else max(1, min(int(workers), self.E))
-        self.native = (native_sim.available() and self.E >= 2) if native is None else bool(native)
+        self.native = (native_sim.available() and not self._shared) if native is None else bool(native)
         if self.native and not native_sim.available():
             raise RuntimeError("native=True but libv2xsim.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
         self._mt_keys = self._mt_pos = None

@@ -17,7 +17,7 @@ class DataParallelTrainer(object):
     grad_tensor() -> flat torch tensor aliasing the gradient buffer, apply_gradients().
     `GnnEngine` is the GPU backend."""
 
-    def __init__(self, backend, process_group=None, force=False, overlap=True):
+    def __init__(self, backend, process_group=None, force=False, overlap=None):
         import torch.distributed as dist
         self.dist = dist
         self.backend = backend
@@ -27,7 +27,15 @@ class DataParallelTrainer(object):
         self._grad = None
         self._buckets = None
         self.force = force          # run the collective even with one rank (exercises the RCCL path)
-        self.overlap = overlap      # split the step so that the Dense-layer bucket is reduced during the graph-layer backward
+        # overlap: split the step so that the Dense-layer bucket is all-reduced during the graph-layer backward
+        # (train_step).  None = the V2X_DP_OVERLAP environment switch, default OFF: the split costs two launches of the
+        # slab sums instead of one and two stream hand-overs per step; measured on one MI355X with the RCCL path forced
+        # (tools/dp_host_overhead.py, 20 links x 64 features, batch 4096, 3 MB of gradients): 301 us per step split
+        # against 271 us unsplit (264 without data parallelism), i.e. the split only pays once hiding the Dense bucket's
+        # all-reduce (1.2 MB, latency-bound on xGMI) is worth more than 30 us -- and the models it applies to (feature
+        # width <= 64) have at most a few MB of gradients.
+        import os
+        self.overlap = (os.environ.get("V2X_DP_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
 
     def shard(self, batch, y):
         """Contiguous shard of whole graphs for this rank (variable-size batches: balanced by edges + nodes,
@@ -46,10 +54,12 @@ class DataParallelTrainer(object):
     def train_step(self, local_batch, local_y, n_graphs_global, want_loss=True):
         """forward+backward on the local shard, all-reduce the gradient, Adam on every rank.
 
-        With a device-resident batch the step is split (SURVEY.md 8 e3 "overlappable with the tail of backward"): the
-        Dense-layer gradients are final as soon as the decision MLP has been differentiated, so their bucket (the tail
-        of the flat gradient) is all-reduced -- asynchronously, RCCL works on its own stream -- while the graph layers
-        are still in their backward pass; the graph-layer bucket follows, and ONE Adam launch runs after both."""
+        With `overlap` and a device-resident batch the step is split (SURVEY.md 8 e3 "overlappable with the tail of
+        backward"): the Dense-layer gradients are final as soon as the decision MLP has been differentiated, so their
+        bucket (the tail of the flat gradient) is all-reduced -- asynchronously, RCCL works on its own stream -- while
+        the graph layers are still in their backward pass; the graph-layer bucket follows, and ONE Adam launch runs
+        after both.  Otherwise: one replayed graph for forward + backward + slab sums, ONE all-reduce of the flat
+        gradient, Adam."""
         reduce_now = self.world > 1 or self.force
         if reduce_now and self._overlapped(local_batch):
             if self._grad is None:

@@ -32,7 +32,7 @@ def _worker(rank, world, port, use_graph, ret):
         pb = PackedBatch.from_dense(x, e, adj)
         eng = GnnEngine(spec, use_graph=use_graph)
         eng.set_weights(oc.params_to_list(P))
-        tr = DataParallelTrainer(eng)
+        tr = DataParallelTrainer(eng, overlap=use_graph)        # the graph-replayed case also runs the two-phase (overlapped) step
         sb, sy = tr.shard(pb, y)
         db, yd = eng.to_device(sb), torch.from_numpy(np.ascontiguousarray(sy)).cuda()
         torch.cuda.synchronize()

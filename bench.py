@@ -269,6 +269,18 @@ def rl_episode(links, feat, batch, gamma, train_steps, seed, engine_factory=None
             "env_steps": int(agent.num_step), "mean_loss": round(float(loss.mean()), 6)}
 
 
+def _print_last(line):
+    """The JSON line must be the LAST line on stdout: RCCL writes its version banner through C stdio, which is fully
+    buffered on a pipe and would otherwise be flushed after everything Python printed -- drain it first."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(line, flush=True)
+
+
 def main_rl(args):
     """--workload cfg0: BASELINE configs[0] (default Sim_Config: 4 links, 16 features, batch 256, gamma 0.2, one episode
     of 20 train steps), on the engine and -- as cpu_baseline, kind "port" -- on the CPU oracle behind the same agent.
@@ -287,7 +299,7 @@ def main_rl(args):
                        envs=args.envs)
         cpu = {"value": r["train_steps_per_s"], "unit": "train-steps/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
                "cpu_model": cpu_model(), "sample": "the same episode (seed 1001) with the numpy fp32 oracle as the Q-network", "detail": r}
-    print(json.dumps({"metric": "DQN train steps/s (50 simulator transitions + 1 replay of batch %d each), %d V2V links, feat_dim %d"
+    _print_last(json.dumps({"metric": "DQN train steps/s (50 simulator transitions + 1 replay of batch %d each), %d V2V links, feat_dim %d"
                                 % (batch, links, feat),
                       "value": gpu["train_steps_per_s"], "unit": "train-steps/s", "n_gpus": 1, "steps": steps, "warmup": 2,
                       "ms_per_step": round(1e3 * gpu["wall_s"] / steps, 3), "higher_is_better": True, "scaling": "weak",
@@ -531,9 +543,10 @@ def main():
                "roofline": roofline, "cpu_baseline": cpu}
         if kernels is not None:
             out["kernels"] = kernels
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        _print_last(json.dumps(out))
 
 
 if __name__ == "__main__":

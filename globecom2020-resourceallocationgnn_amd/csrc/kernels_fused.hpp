@@ -98,6 +98,8 @@ struct FusedFwdArgs {
   const float* xe; const int32_t* row_ptr; const int32_t* col_idx;
   const float* pk;                                   // fragment-major forward weights (k_pack_weights)
   float* h[FZ_MAXL + 1]; float* a[FZ_MAXL + 1];      // stage outputs h_s and their aggregations a_s, [R][F]
+  unsigned short* gate[FZ_MAXL + 1];                 // sign bits of h_s (ReLU' gates, s < L) for the fused backward: 16 bits per lane,
+                                                     // [node][workgroup][64 lanes] (bit 4 nt + c = column nt*16 + 4 kg + c > 0)
   int n_graphs, N, L, S;                             // S = weight slots (N per-node, 1 shared)
   int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
   int n_edges;                                       // E of the whole batch
@@ -114,7 +116,26 @@ struct FusedFwdArgs {
 // rows, same conflict-free geometry as the tile) next to the rows it writes into the tile; a lane then adds the 8
 // partials in wave order (fixed order: deterministic).  The host selects this form when the average in-degree exceeds
 // (N - 1) / 2; the values differ from the edge-ordered gather by rounding only.
-constexpr int FZ_SUMS_ROWS = FZ_WAVES * 4 * FZ_TG;     // rows of ROWF floats
+// The 8 partials are added ONCE per stage, in wave order (fixed order: deterministic), by all threads together (a
+// float2 each) between the two barriers that replace the tile, into a 64-row table of totals that the gathers read: a
+// lane that adds the 8 partials itself reads 32 float4 per sum -- 8x redundant over the workgroup, and the gather phases
+// are LDS-bandwidth-bound (the backward re-added them per slot: 0.8 MB of LDS reads per workgroup and stage).
+constexpr int FZ_SUMS_ROWS = FZ_WAVES * 4 * FZ_TG;     // rows of ROWF floats: the partials
+constexpr int FZ_TOT_ROWS = 4 * FZ_TG;                 // the totals
+
+template <int FB, int ROWF>
+__device__ __forceinline__ void fz_reduce_sums(const float* sS, float* sT) {
+  for (int e = threadIdx.x; e < FZ_TOT_ROWS * FB * 2; e += FZ_THREADS) {
+    const int off = (e / (2 * FB)) * ROWF + 2 * (e % (2 * FB));
+    float2 v = *reinterpret_cast<const float2*>(sS + off);
+#pragma unroll
+    for (int w = 1; w < FZ_WAVES; ++w) {
+      const float2 t = *reinterpret_cast<const float2*>(sS + w * FZ_TOT_ROWS * ROWF + off);
+      v.x += t.x; v.y += t.y;
+    }
+    *reinterpret_cast<float2*>(sT + off) = v;
+  }
+}
 
 // phase time stamps of one workgroup (measurement builds only; v2x_debug_phase_stamps)
 template <bool TS>
@@ -137,6 +158,30 @@ struct FzStamp {
 typedef __attribute__((address_space(1))) f32x4* gvec_wp;
 __device__ __forceinline__ void stg4(float* p, f32x4 v) { *(gvec_wp)p = v; }
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(gvec_p)p; }
+
+// ReLU' gates as bits: the backward needs h_s only to know where it is positive.  Reading the rows back costs it 21 MB per
+// stage, requested by 256 lock-stepped workgroups at the moment they are needed (measured with the gate removed: 7 us of
+// the backward's 51); 16 bits per lane are 0.65 MB per stage and arrive a whole stage ahead.
+__device__ __forceinline__ unsigned gate_bits4(f32x4 v) {
+  return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+}
+__device__ __forceinline__ f32x4 gate_apply4(f32x4 g, unsigned m) {
+  return (f32x4){(m & 1u) ? g[0] : 0.f, (m & 2u) ? g[1] : 0.f, (m & 4u) ? g[2] : 0.f, (m & 8u) ? g[3] : 0.f};
+}
+
+// Loads and stores share ONE in-order counter (vmcnt) but are acknowledged independently: with a store in flight a load
+// cannot be waited for by count, the wait becomes vmcnt(0) -- for the store's acknowledgement AND for every load
+// requested since, i.e. the weight ring loses its prefetch distance.  Hence: no store inside a run of MFMAs that waits
+// for weight chunks (they go in front of it, in the gather phase, or behind it), and the first MFMA of a run is issued
+// before the run's first new request.  The barriers of these kernels order LDS accesses only (__syncthreads() would also
+// drain vmcnt, i.e. wait for the stores just issued): nothing global is exchanged between the waves.
+__device__ __forceinline__ void fz_barrier() {
+#ifdef V2X_FZ_FULL_BARRIER
+  __syncthreads();
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 
 __device__ __forceinline__ f32x4 ldnt4(const float* p) {      // L1-bypassing load (data another wave of this CU just wrote)
   return __builtin_nontemporal_load((gvec_p)p);
@@ -196,7 +241,7 @@ __device__ __forceinline__ void csr_commit(const FzCsrEarly& c, const int32_t* r
 }
 
 struct FzCtx {
-  float* sH; int* sRp; unsigned char* sCol; float* sS; unsigned* sC;
+  float* sH; int* sRp; unsigned char* sCol; float* sS; float* sT; unsigned* sC;
   int N, L, SUB, lane, wv, jc, kg, g0;
 };
 
@@ -261,9 +306,11 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
   auto hptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedFwdArgs, h) / 8 + s]); };
   auto aptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedFwdArgs, a) / 8 + s]); };
+  auto gptr = [&](int s) { return reinterpret_cast<unsigned short*>(kq[offsetof(FusedFwdArgs, gate) / 8 + s]); };
+  const int gate_lane = blockIdx.x * 64 + lane, gate_stride = gridDim.x * 64;     // + node * gate_stride
   float* myrow = x.sH + kg * x.SUB + jc * ROWF;                  // + p*16*ROWF + kb*4
   float* mysum = x.sS + ((wv * 4 + kg) * FZ_TG + jc) * ROWF;     // this wave's partial column sum (compl_sums)
-  const float* sums0 = x.sS + (kg * FZ_TG + jc) * ROWF;          // wave 0's; wave w: + w * 4 * FZ_TG * ROWF
+  const float* tot = x.sT + (kg * FZ_TG + jc) * ROWF;            // column sums of the tile (compl_sums)
 
   // ---- stage 0 (embed): h_0 = relu(xe . W0 + b0); the neighbour-init block is absent (always zero in the reference)
   f32x4 psum[FB];                        // sum of this wave's output rows of the current stage
@@ -271,9 +318,11 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   for (int nt = 0; nt < FB; ++nt) psum[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     float* hp = hptr(0);
+    unsigned short* gp = gptr(0);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int k = wv + FZ_WAVES * i;
+      unsigned gb = 0u;
       f32x4 acc[FB];
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -287,7 +336,9 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
         stg4(hp + rowi[i] * F + nt * 16 + 4 * kg, v);
         st4(myrow + k * FZ_TG * ROWF + nt * 4, v);
         psum[nt] = i == 0 ? v : psum[nt] + v;
+        gb |= gate_bits4(v) << (4 * nt);
       }
+      gp[k * gate_stride + gate_lane] = (unsigned short)gb;
     }
     if (compl_sums) {
 #pragma unroll
@@ -296,6 +347,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   }
   ts.mark();                                                     // 1: embed done (before barrier)
   __syncthreads();
+  if (compl_sums) { fz_reduce_sums<FB, ROWF>(x.sS, x.sT); __syncthreads(); }
   ts.mark();                                                     // 2: after barrier
 
   // neighbour gather of slot k for this lane's graph: a[kb] = sum over in-edges, ascending sources (k_agg_small order)
@@ -323,15 +375,11 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     }
   };
 
-  // the same through the complement: column sum (8 partials, wave order) minus the rows of the non-neighbours
+  // the same through the complement: column sum minus the rows of the non-neighbours
   f32x4 csum[FB];
   auto colsum = [&]() {
 #pragma unroll
-    for (int kb = 0; kb < FB; ++kb) csum[kb] = ld4(sums0 + kb * 4);
-#pragma unroll
-    for (int w = 1; w < FZ_WAVES; ++w)
-#pragma unroll
-      for (int kb = 0; kb < FB; ++kb) csum[kb] += ld4(sums0 + w * 4 * FZ_TG * ROWF + kb * 4);
+    for (int kb = 0; kb < FB; ++kb) csum[kb] = ld4(tot + kb * 4);
   };
   auto gather_c = [&](int k, f32x4 (&ag)[FB]) {
 #pragma unroll
@@ -350,6 +398,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   for (int s = 1; s <= L; ++s) {
     float* hp = hptr(s);
     float* ap = aptr(s - 1);
+    unsigned short* gp = gptr(s);
     const bool relu = s < L;
     f32x4 ag[NSA][FB];                     // gathered a_{s-1} rows; slot i's registers become its output h_s afterwards
     // (1) gather phase
@@ -392,10 +441,14 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
         }
         if (RING) {
 #pragma unroll
-          for (int u = 0; u < CHN; ++u) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
+          for (int u = 0; u < CHN; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      unsigned gb = 0u;
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) {
         f32x4 v = acc[nt] + bias[nt];
@@ -403,20 +456,23 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
         stg4(hp + rowi[i] * F + nt * 16 + 4 * kg, v);
         ag[i][nt] = v;
         psum[nt] = i == 0 ? v : psum[nt] + v;
+        gb |= gate_bits4(v) << (4 * nt);
       }
+      gp[k * gate_stride + gate_lane] = (unsigned short)gb;
       ts.mark();                                                 // slot: MFMAs + stores issued
     }
-    __syncthreads();                       // every wave is done reading the h_{s-1} tile (and the partial sums)
+    if (compl_sums) {                      // (the partials are only read between the two barriers below)
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(mysum + nt * 4, NS > 0 ? psum[nt] : (f32x4){0.f, 0.f, 0.f, 0.f});
+    }
+    __syncthreads();                       // every wave is done reading the h_{s-1} tile (and the totals)
     ts.mark();                                                   // stage: barrier passed
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, ag[i][nt]);
     }
-    if (compl_sums) {
-#pragma unroll
-      for (int nt = 0; nt < FB; ++nt) st4(mysum + nt * 4, NS > 0 ? psum[nt] : (f32x4){0.f, 0.f, 0.f, 0.f});
-    }
+    if (compl_sums) fz_reduce_sums<FB, ROWF>(x.sS, x.sT);
     __syncthreads();
     ts.mark();                                                   // stage: tile replaced
   }
@@ -447,7 +503,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
   x.SUB = a.N * FZ_TG * P::ROWF;                                 // floats per k-group sub-array
   x.sH = smem;                                                   // [4][N*16][ROWF]
   x.sS = x.sH + 4 * x.SUB;                                       // compl_sums: [8 waves][4][16][ROWF] partial column sums
-  x.sRp = reinterpret_cast<int*>(x.sS + (COMPL ? FZ_SUMS_ROWS * P::ROWF : 0));   // [16 N + 1] edge offsets relative to the tile
+  x.sT = x.sS + (COMPL ? FZ_SUMS_ROWS * P::ROWF : 0);            // compl_sums: [4][16][ROWF] their totals
+  x.sRp = reinterpret_cast<int*>(x.sT + (COMPL ? FZ_TOT_ROWS * P::ROWF : 0));    // [16 N + 1] edge offsets relative to the tile
   x.sC = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // compl_sums: [16 N] non-neighbour masks
   x.sCol = reinterpret_cast<unsigned char*>(x.sC + (COMPL ? FZ_TG * a.N : 0));   // [edges] graph-local sources
   x.lane = threadIdx.x & 63;
@@ -472,7 +529,7 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
 struct FusedBwdArgs {
   const int32_t* row_ptr; const int32_t* col_idx;
   const float* pk;                                   // fragment-major backward weights
-  const float* h[FZ_MAXL + 1];                       // forward activations (ReLU' gates)
+  const unsigned short* gate[FZ_MAXL + 1];           // ReLU' gates of h_s (FusedFwdArgs::gate), s < L
   float* dpre[FZ_MAXL + 1];
   float* gha;                                        // [R][2F]
   int n_graphs, N, L, S, edges_cap, n_edges;
@@ -482,7 +539,7 @@ struct FusedBwdArgs {
 };
 
 struct FzCtxB {
-  float* sD; int* sRp; unsigned* sM; unsigned char* sCol; float* sS;
+  float* sD; int* sRp; unsigned* sM; unsigned char* sCol; float* sS; float* sT;
   int N, L, SUB, lane, wv, jc, kg, g0;
 };
 
@@ -531,72 +588,71 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
   constexpr bool compl_sums = COMPL;
   float* mysum = x.sS + ((wv * 4 + kg) * FZ_TG + jc) * ROWF;     // this wave's partial column sum of the dagg tile
-  const float* sums0 = x.sS + (kg * FZ_TG + jc) * ROWF;
-  auto park = [&]() {                    // own dagg rows into the tile (+ their sum for the complement form)
-    f32x4 ps[FB];
-#pragma unroll
-    for (int nt = 0; nt < FB; ++nt) ps[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-#pragma unroll
-      for (int nt = 0; nt < FB; ++nt) {
-        st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, dg[i][nt]);
-        ps[nt] = i == 0 ? dg[i][nt] : ps[nt] + dg[i][nt];
-      }
+  const float* tot = x.sT + (kg * FZ_TG + jc) * ROWF;            // column sums of the dagg tile
+  auto park_sums = [&]() {               // sum of the own dagg rows (complement form); read between the stage's two barriers only
     if (compl_sums) {
+      f32x4 ps[FB];
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) ps[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NS; ++i)
+#pragma unroll
+        for (int nt = 0; nt < FB; ++nt) ps[nt] = i == 0 ? dg[i][nt] : ps[nt] + dg[i][nt];
 #pragma unroll
       for (int nt = 0; nt < FB; ++nt) st4(mysum + nt * 4, ps[nt]);
     }
   };
+  auto park = [&]() {                    // own dagg rows into the tile
+#pragma unroll
+    for (int i = 0; i < NS; ++i)
+#pragma unroll
+      for (int nt = 0; nt < FB; ++nt) st4(myrow + (wv + FZ_WAVES * i) * FZ_TG * ROWF + nt * 4, dg[i][nt]);
+  };
+  park_sums();
   park();
-  __syncthreads();
+  fz_barrier();
+  if (compl_sums) fz_reduce_sums<FB, ROWF>(x.sS, x.sT);
   // transposed adjacency: bit q of sM[j*N + p] = edge p -> q (integer atomics: order-independent)
   for (int r = threadIdx.x; r < nrows; r += FZ_THREADS) {
     const int jj = r / N, q = r - jj * N;
     for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) atomicOr(&x.sM[jj * N + x.sCol[e]], 1u << q);
   }
-  __syncthreads();
+  fz_barrier();
   ts.mark();                                                     // 1: tile + masks ready
 
   const unsigned valid = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
   typedef const __attribute__((address_space(4))) uint64_t* CQ;
   CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();
-  auto hptr = [&](int s) { return reinterpret_cast<const float*>(kq[offsetof(FusedBwdArgs, h) / 8 + s]); };
+  auto gptr = [&](int s) { return reinterpret_cast<const unsigned short*>(kq[offsetof(FusedBwdArgs, gate) / 8 + s]); };
+  const int gate_lane = blockIdx.x * 64 + lane, gate_stride = gridDim.x * 64;
   auto dptr = [&](int s) { return reinterpret_cast<float*>(kq[offsetof(FusedBwdArgs, dpre) / 8 + s]); };
 
   for (int s = L; s >= 0; --s) {
-    const float* hp = hptr(s);
     float* dp = dptr(s);
     const bool gate = s < L;
+    // (no load may be in flight across the loop's back edge or next to a store when it is waited for: hipcc then waits
+    //  for vmcnt(0) -- the gates of a stage are requested at its start, one dword per slot, nothing queued in front)
+    unsigned gb[NSA];
+    {
+      const unsigned short* gp = gptr(min(s, L - 1 > 0 ? L - 1 : 0));
+#pragma unroll
+      for (int i = 0; i < NSA; ++i) gb[i] = gp[(wv + FZ_WAVES * (i < NS ? i : 0)) * gate_stride + gate_lane];
+    }
     // the first two weight chunks of this stage land while the gathers run
     if (RING && s > 0) { wload(0, 0, item_base(s, 0)); wload(1, 1, item_base(s, 0)); }
     f32x4 dpre[NSA][FB];
-    // (1) transposed gathers (ascending destinations, two per iteration: k_agg_small<true> order), + dh, ReLU' gate; the h_s
-    //     row of slot i+1 is requested before slot i is gathered
-    f32x4 hm[2][FB];
-    auto request = [&](int i) {
-#pragma unroll
-      for (int nt = 0; nt < FB; ++nt) hm[i & 1][nt] = ldg4(hp + rowi[i] * F + nt * 16 + 4 * kg);
-    };
-    if (NS > 0 && gate) request(0);
+    // (1) transposed gathers (ascending destinations, two per iteration: k_agg_small<true> order), + dh, ReLU' gate
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      if (i + 1 < NS && gate) request(i + 1);
       f32x4 acc[FB];
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       unsigned bits = x.sM[jc * N + wv + FZ_WAVES * i];
       if constexpr (COMPL) {                                          // column sum minus the rows of the non-successors
-        // (the column sum is re-added per slot, 8 partials in wave order: keeping it in registers across the slots
-        //  spills next to the weight ring)
+        // (the column sum is re-read per slot: keeping it in registers across the slots spills next to the weight ring)
         bits = ~bits & valid;
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) acc[kb] = ld4(sums0 + kb * 4);
-#pragma unroll 1
-        for (int w = 1; w < FZ_WAVES; ++w) {
-#pragma unroll
-          for (int kb = 0; kb < FB; ++kb) acc[kb] += ld4(sums0 + w * 4 * FZ_TG * ROWF + kb * 4);
-        }
+        for (int kb = 0; kb < FB; ++kb) acc[kb] = ld4(tot + kb * 4);
         while (bits) {
           const int q0 = __builtin_ctz(bits);
           bits &= bits - 1;
@@ -624,7 +680,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) {
         acc[kb] += dhk[i][kb];
-        if (gate) acc[kb] = gate4(acc[kb], hm[i & 1][kb]);
+        if (gate) acc[kb] = gate_apply4(acc[kb], gb[i] >> (4 * kb));
         stg4(dp + rowi[i] * F + kb * 16 + 4 * kg, acc[kb]);
         dpre[i][kb] = acc[kb];
       }
@@ -653,6 +709,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
             for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = V2X_MFMA(wr[RING ? n % 3 : 0][q * 2 * FB + nt][s4], dpre[i][kb][s4], o[nt]);
         }
         if (pf) {
+          if (n == 0) __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);            // the run's first wait sees no new request
 #pragma unroll
           for (int u = 0; u < CHN; ++u) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); }
         }
@@ -665,10 +722,12 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
       }
       ts.mark();                                                 // slot done
     }
-    __syncthreads();                       // all gathers from the dagg_s tile are done
+    park_sums();
+    fz_barrier();                       // all gathers from the dagg_s tile are done
     ts.mark();
     park();
-    __syncthreads();
+    if (compl_sums) fz_reduce_sums<FB, ROWF>(x.sS, x.sT);
+    fz_barrier();
     ts.mark();                                                   // stage: tile replaced
   }
   ts.mark(true);
@@ -683,7 +742,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
   x.SUB = a.N * FZ_TG * P::ROWF;
   x.sD = smem;                                                   // dagg tile, same layout as the forward tile
   x.sS = x.sD + 4 * x.SUB;                                       // compl_sums: partial column sums
-  x.sRp = reinterpret_cast<int*>(x.sS + (COMPL ? FZ_SUMS_ROWS * P::ROWF : 0));   // [16 N + 1]
+  x.sT = x.sS + (COMPL ? FZ_SUMS_ROWS * P::ROWF : 0);            // compl_sums: their totals
+  x.sRp = reinterpret_cast<int*>(x.sT + (COMPL ? FZ_TOT_ROWS * P::ROWF : 0));    // [16 N + 1]
   x.sM = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // [16 N] out-neighbour bit masks (N <= 32)
   x.sCol = reinterpret_cast<unsigned char*>(x.sM + FZ_TG * a.N);
   x.lane = threadIdx.x & 63;

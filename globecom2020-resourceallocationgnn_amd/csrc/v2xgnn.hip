@@ -60,6 +60,8 @@ struct v2x_model {
   float *z1 = nullptr, *z2 = nullptr, *z3 = nullptr, *q = nullptr;
   float *dq = nullptr, *dz1 = nullptr, *dz2 = nullptr, *dz3 = nullptr, *gha = nullptr, *rowloss = nullptr;
   std::vector<float*> dpre;     // one pre-activation gradient per GNN stage (read concurrently by k_wgrad)
+  unsigned short* gate_bits = nullptr;   // ReLU' gates of the fused forward for the fused backward: [L][gate_stride]
+  int64_t gate_stride = 0;               // ushorts per stage: N x ceil(B / 16) x 64 <= 4 R + 64 N
   hipStream_t side = nullptr;   // weight-gradient kernels run here, forked/joined around the data chain
   std::vector<hipEvent_t> ev;   // fork / per-stage / join events of the side stream
   float* loss_dev = nullptr;
@@ -265,6 +267,10 @@ int ensure_rows(v2x_model* m, int64_t R) {
   CHK(re(m->dq, m->C)); CHK(re(m->dz1, H1)); CHK(re(m->dz2, H2)); CHK(re(m->dz3, H3));
   CHK(re(m->gha, 2 * F)); CHK(re(m->rowloss, 1));
   for (int s = 0; s <= m->L; ++s) CHK(re(m->dpre[s], F));
+  if (m->gate_bits) HIPCHK(m, hipFree(m->gate_bits));
+  m->gate_bits = nullptr;
+  m->gate_stride = 4 * R + 64 * (int64_t)m->N;
+  HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->gate_bits), (size_t)((m->L + 1) * m->gate_stride) * sizeof(unsigned short)));
   m->cap_rows = R;
   return V2X_OK;
 }
@@ -1112,7 +1118,7 @@ size_t fused_lds(const v2x_model* m, const DevBatch& d, bool bwd, bool compl_sum
   const size_t rows = (size_t)FZ_TG * m->N;
   size_t b = 4 * rows * fused_rowf(m->F) * 4 + (rows + 1) * 4 + (size_t)FZ_TG * d.max_edges;
   b += rows * 4;                                       // bit masks: backward always, forward with compl_sums
-  if (compl_sums) b += (size_t)FZ_SUMS_ROWS * fused_rowf(m->F) * 4;
+  if (compl_sums) b += (size_t)(FZ_SUMS_ROWS + FZ_TOT_ROWS) * fused_rowf(m->F) * 4;
   return (b + 15) / 16 * 16;
 }
 bool fused_path(const v2x_model* m, const DevBatch& d) {
@@ -1164,7 +1170,7 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   FusedFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.xe = d.xe; a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_fwd;
-  for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.a[s] = m->a[s]; }
+  for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.a[s] = m->a[s]; a.gate[s] = m->gate_bits + s * m->gate_stride; }
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   a.compl_sums = fused_compl(m, d) ? 1 : 0;
@@ -1191,7 +1197,8 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   FusedBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_bwd; a.gha = m->gha;
-  for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.dpre[s] = m->dpre[s]; }
+  for (int s = 0; s <= m->L; ++s) a.dpre[s] = m->dpre[s];
+  for (int s = 0; s < m->L; ++s) a.gate[s] = m->gate_bits + s * m->gate_stride;
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   a.compl_sums = fused_compl(m, d) ? 1 : 0;
@@ -1550,6 +1557,7 @@ void v2x_destroy(v2x_model* m) {
   float* ptrs[] = {m->params, m->grads, m->mom, m->vel, m->z1, m->z2, m->z3, m->q, m->dq, m->dz1, m->dz2, m->dz3,
                    m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part, m->pk_fwd, m->pk_bwd};
   for (float* p : m->dpre) if (p) hipFree(p);
+  if (m->gate_bits) hipFree(m->gate_bits);
   for (auto& e : m->ev) if (e) hipEventDestroy(e);
   if (m->side) hipStreamDestroy(m->side);
   for (float* p : ptrs) if (p) hipFree(p);

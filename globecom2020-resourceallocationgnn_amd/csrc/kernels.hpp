@@ -1059,6 +1059,10 @@ struct WgradArgs {
   int kind;                                       // WG_KIND_*: selects the compile-time operand widths
   int dpre_slot_major; int srow_stride;           // row layout of dpre / of slot-major segments
   long long* ts;                                  // phase stamps (diagnostics, V2X_FUSED_TS=1) or null
+  // the embed layer's gradient riding on a graph layer's role (wgrad_body EN > 0): dW0[x|e rows][e_col0 .. + 16 EN) =
+  // xe^T . dpre_0[:, those columns], written to the embed layer's block of the same slab (its neighbour-init rows: zeros)
+  const float* e_dpre; int e_stride, e_col0, e_n_real;
+  int64_t e_layer_off, e_slot_stride; RowPad e_pad;
 };
 
 constexpr int WG_TR = 16;        // rows per MFMA block (chunk sizes are multiples of it)
@@ -1121,9 +1125,13 @@ __device__ __forceinline__ void wg_load(WgOperand<W>& o, const WgSrc& src, unsig
 // does not overlap memory and MFMA phases.)
 // ZERO1: the K1 segment is absent (identically zero input, e.g. the embed layer's neighbour-init): nothing is loaded or
 // multiplied for its tiles, their gradient rows are written as exact zeros.
-template <int K0, int K1, int K2, int NW, int DEPTH = 2, bool ZERO1 = false>
+// EN > 0: this role also produces EN output tiles of the EMBED layer's gradient (K1 must be the [x|e] tile): the light
+// embed role (16 MFMAs per block, load-bound) otherwise needs workgroups of its own, which queue behind the heavy ones.
+template <int K0, int K1, int K2, int NW, int DEPTH = 2, bool ZERO1 = false, int EN = 0>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, const int bx, const int slot) {
   constexpr int T0 = K0 / 16, T1 = K1 / 16, T2 = K2 / 16, KT = T0 + T1 + T2, NT = NW / 16;
+  constexpr int EW = 16 * EN, ENA = EN > 0 ? EN : 1;
+  static_assert(EN == 0 || (T1 == 1 && !ZERO1), "the embed gradient rides on the [x|e] tile");
   if (bx >= a.n_chunks) return;                                  // roles have work-proportional grids
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
@@ -1153,6 +1161,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   srcn.p = (gfloat_p)a.dpre; srcn.stride = a.d_stride; srcn.width = a.n_real;
   srcn.rs = a.dpre_slot_major ? 1u : (unsigned)a.row_stride;
   srcn.off = a.dpre_slot_major ? (unsigned)slot * (unsigned)a.srow_stride : (unsigned)slot * (unsigned)a.base_mul;
+  WgSrc srce;
+  srce.p = (gfloat_p)(EN > 0 ? a.e_dpre + a.e_col0 : a.zeros); srce.stride = EN > 0 ? a.e_stride : 0; srce.width = EW > 0 ? EW : 16;
+  srce.rs = (unsigned)a.row_stride; srce.off = (unsigned)slot * (unsigned)a.base_mul;
+  f32x4 acce[ENA];
+  float bsume[ENA];
+#pragma unroll
+  for (int e = 0; e < ENA; ++e) { acce[e] = (f32x4){0.f, 0.f, 0.f, 0.f}; bsume[e] = 0.f; }
 
   f32x4 acc[KT][NT];
 #pragma unroll
@@ -1164,7 +1179,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
 
   constexpr int K1L = ZERO1 ? 0 : K1;                            // loaded width of the K1 operand
-  struct Block { WgOperand<K0> k0; WgOperand<K1L> k1; WgOperand<K2> k2; WgOperand<NW> n; };
+  struct Block { WgOperand<K0> k0; WgOperand<K1L> k1; WgOperand<K2> k2; WgOperand<NW> n; WgOperand<EW> e; };
   auto kval = [&](const Block& b, int kt, int s) -> float {
     if (kt < T0) return b.k0.get(kt, s);
     if (kt < T0 + T1) return ZERO1 ? 0.f : b.k1.get(kt - T0, s);
@@ -1181,6 +1196,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
       }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bsum[nt] += (b.n.get(nt, 0) + b.n.get(nt, 1)) + (b.n.get(nt, 2) + b.n.get(nt, 3));
+    if constexpr (EN > 0) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int e = 0; e < EN; ++e) acce[e] = V2X_MFMA(kval(b, T0, s), b.e.get(e, s), acce[e]);
+#pragma unroll
+      for (int e = 0; e < EN; ++e) bsume[e] += (b.e.get(e, 0) + b.e.get(e, 1)) + (b.e.get(e, 2) + b.e.get(e, 3));
+    }
   };
   const int n_rows_here = max(i_end - i_begin, 0);
   const int n_full = n_rows_here / WG_TR;
@@ -1193,6 +1216,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
       wg_load<K1L>(b.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
       wg_load<K2>(b.k2, src[2], idx * src[2].rs + src[2].off, s, j, 1.f);
       wg_load<NW>(b.n, srcn, idx * srcn.rs + srcn.off, s, j, 1.f);
+      wg_load<EW>(b.e, srce, idx * srce.rs + srce.off, s, j, 1.f);
     }
   };
 
@@ -1209,8 +1233,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   // texture unit takes them (tools/l2stream.hip, tools/overlapbench.hip).  The loads of the NEXT block are therefore
   // spread between the MFMAs of the current one, one per PER MFMAs.
   constexpr int NLD = 4 * ((K0 > 0 ? WgOperand<K0>::G + WgOperand<K0>::R : 0) + (K1L > 0 ? WgOperand<K1L>::G + WgOperand<K1L>::R : 0) +
-                           (K2 > 0 ? WgOperand<K2>::G + WgOperand<K2>::R : 0) + WgOperand<NW>::G + WgOperand<NW>::R);
-  constexpr int NMF = 4 * (KT - (ZERO1 ? T1 : 0)) * NT;
+                           (K2 > 0 ? WgOperand<K2>::G + WgOperand<K2>::R : 0) + WgOperand<NW>::G + WgOperand<NW>::R +
+                           (EW > 0 ? WgOperand<EW>::G + WgOperand<EW>::R : 0));
+  constexpr int NMF = 4 * (KT - (ZERO1 ? T1 : 0)) * NT + 4 * EN;
   constexpr int PER = NMF / NLD > 0 ? NMF / NLD : 1;
 #define V2X_ILV                                                                                        \
   {                                                                                                    \
@@ -1271,6 +1296,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
       wg_load<K1L>(b0.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
       wg_load<K2>(b0.k2, src[2], idx * src[2].rs + src[2].off, s, j, 1.f);
       wg_load<NW>(b0.n, srcn, idx * srcn.rs + srcn.off, s, j, mk);
+      wg_load<EW>(b0.e, srce, idx * srce.rs + srce.off, s, j, mk);
     }
     mfma_block(b0);
   }
@@ -1282,10 +1308,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   //      add in turn": three rounds of dependent LDS read-modify-writes by ONE wave, measured ~0.4 us per tile.)
   //      Lane (kg, j) of tile (kt, nt) holds rows feature_k(kt, 4*kg + r), column feature_n(nt, j).
   mark();
-  constexpr int TILES_X = KT * NT, XHALF = TILES_X / 2;
-  f32x4* sAcc = reinterpret_cast<f32x4*>(smem);                  // set A [KT*NT][64 lanes]
+  constexpr int TILES_X = KT * NT + EN, XHALF = TILES_X / 2, NTB = NT + EN;
+  f32x4* sAcc = reinterpret_cast<f32x4*>(smem);                  // set A [KT*NT (+ EN)][64 lanes]
   f32x4* sAcc2 = sAcc + TILES_X * 64;                            // set B
-  float* sBias4 = smem + 2 * TILES_X * 64 * 4;                   // [wave][NT][16]
+  float* sBias4 = smem + 2 * TILES_X * 64 * 4;                   // [wave][NT (+ EN)][16]
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {                              // bias: fold the 4 row groups of the wave
     float v = bsum[nt];
@@ -1293,9 +1319,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     v += __shfl_xor(v, 32);
     bsum[nt] = v;
   }
+  if constexpr (EN > 0) {
+#pragma unroll
+    for (int e = 0; e < EN; ++e) {
+      float v = bsume[e];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      bsume[e] = v;
+    }
+  }
   if (kg == 0) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) sBias4[(wv * NT + nt) * 16 + j] = bsum[nt];
+    for (int nt = 0; nt < NT; ++nt) sBias4[(wv * NTB + nt) * 16 + j] = bsum[nt];
+    if constexpr (EN > 0) {
+#pragma unroll
+      for (int e = 0; e < EN; ++e) sBias4[(wv * NTB + NT + e) * 16 + j] = bsume[e];
+    }
   }
   {
     f32x4* sSet = (wv >> 1 ? sAcc2 : sAcc) + lane;
@@ -1312,6 +1351,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
             if ((ti & 3) == 3) __builtin_amdgcn_sched_barrier(0);
           }
         }
+      if constexpr (EN > 0) {
+#pragma unroll
+        for (int e = 0; e < EN; ++e) {
+          const int ti = KT * NT + e;
+          if ((ti < XHALF) == decltype(LOW)::value) {
+            if (decltype(STORE)::value) sSet[ti * 64] = acce[e];
+            else sSet[ti * 64] += acce[e];
+          }
+        }
+      }
     };
     if (even) xchg(std::true_type{}, std::true_type{}); else xchg(std::true_type{}, std::false_type{});
     __syncthreads();
@@ -1353,7 +1402,28 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     const int nt = tid >> 4, jj = tid & 15, col = WgOperand<NW>::feature(nt, jj);
     if (col < a.n_real)
       dst[(int64_t)a.pad.k_real * a.n_real + col] =
-          (sBias4[tid] + sBias4[NT * 16 + tid]) + (sBias4[2 * NT * 16 + tid] + sBias4[3 * NT * 16 + tid]);
+          (sBias4[tid] + sBias4[NTB * 16 + tid]) + (sBias4[2 * NTB * 16 + tid] + sBias4[3 * NTB * 16 + tid]);
+  }
+  if constexpr (EN > 0) {                                        // the embed layer's columns [e_col0, e_col0 + 16 EN)
+    float* dste = a.slab + (int64_t)(a.chunk_base + bx) * a.slab_stride + a.e_layer_off + slot * a.e_slot_stride;
+    const int nre = a.e_n_real;
+    for (int e = wv; e < EN; e += 4) {                           // [x|e] rows x tile e
+      const int ti = KT * NT + e, col = a.e_col0 + WgOperand<EW>::feature(e, j);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rr = real_row(a.e_pad, WgOperand<K1>::feature(0, 4 * kg + r));
+        if (rr >= 0 && rr < a.e_pad.pad_at) dste[(int64_t)rr * nre + col] = sAcc[ti * 64 + lane][r] + sAcc2[ti * 64 + lane][r];
+      }
+    }
+    // rows of the absent neighbour-init block (real rows pad_at .. k_real - 1): exact zeros
+    for (int i = tid; i < (a.e_pad.k_real - a.e_pad.pad_at) * EW; i += 256) {
+      const int rr = a.e_pad.pad_at + i / EW, c = i % EW;
+      dste[(int64_t)rr * nre + a.e_col0 + c] = 0.f;
+    }
+    if (tid < EN * 16) {
+      const int e = tid >> 4, jj = tid & 15, col = a.e_col0 + WgOperand<EW>::feature(e, jj), o = (NT + e) * 16 + jj;
+      dste[(int64_t)a.e_pad.k_real * nre + col] = (sBias4[o] + sBias4[NTB * 16 + o]) + (sBias4[2 * NTB * 16 + o] + sBias4[3 * NTB * 16 + o]);
+    }
   }
   mark();
   if (tsp && tsn < 64) tsp[tsn] = (long long)wall_clock64();
@@ -1370,7 +1440,7 @@ constexpr int WG_MAX_ROLES = 8;
 #endif
 struct WgradMulti { WgradArgs w[WG_MAX_ROLES]; };
 enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 3, WG_KIND_DENSE2 = 4, WG_KIND_DENSE3 = 5,
-       WG_KIND_EMBED_NONBR = 6 };
+       WG_KIND_EMBED_NONBR = 6, WG_KIND_GNN_E1 = 7, WG_KIND_GNN_E2 = 8, WG_KIND_GNN_E4 = 9 };   // _En: + n tiles of the embed gradient
 
 // MODE 0: the GNN stages, 1: the Dense layers, 2: both families in one launch (roles ordered heaviest first)
 template <int F, int MODE>
@@ -1386,6 +1456,13 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
   for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
   if constexpr (MODE != 1) {
     if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_GNN_E1) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN, false, 1>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if constexpr (F >= 32) {
+      if (a.kind == WG_KIND_GNN_E2) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN, false, 2>(a, smem, blockIdx.x, blockIdx.y); return; }
+    }
+    if constexpr (F >= 64) {
+      if (a.kind == WG_KIND_GNN_E4) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN, false, 4>(a, smem, blockIdx.x, blockIdx.y); return; }
+    }
     if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
     if (a.kind == WG_KIND_EMBED_NONBR) { wgrad_body<XE, F, 0, F, 3, true>(a, smem, blockIdx.x, blockIdx.y); return; }
   }

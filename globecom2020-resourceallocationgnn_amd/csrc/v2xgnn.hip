@@ -882,9 +882,9 @@ int launch_mlp(v2x_model* m, hipStream_t st, MlpArgs& a, bool bwd) {
 int layer_work(const LayerDesc& ld) { return (ld.kp / 16) * (ld.np / 16); }
 
 int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total_work, const WgSeg* segs, int n_seg,
-               const float* dpre, int d_stride, WgradArgs& a) {
+               const float* dpre, int d_stride, WgradArgs& a, int rows_override = 0) {
   int chunk;
-  const bool gnn_kind = kind < WG_KIND_DENSE0 || kind == WG_KIND_EMBED_NONBR;
+  const bool gnn_kind = kind < WG_KIND_DENSE0 || kind >= WG_KIND_EMBED_NONBR;
   // measured at batch 4096 x 20 nodes in the merged launch: the SAME 1024 rows per workgroup for every role (87 us) beats
   // 1024 / 768 for the GNN / Dense families (102 us, the optimum when the two families were separate launches)
   // (the graph layers on their own -- the Dense gradients come out of k_mlp_train_wg -- : 896, i.e. 5 x 832 rows per
@@ -893,6 +893,7 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
   int rows_g = rows_gnn > 0 ? rows_gnn : (mlp_wg_path(m) ? 896 : 1024);
   static const int rows_embed = env_int("V2X_WG_CHUNK_EMBED", 0);       // the (light) embed role on its own chunking
   if (rows_embed > 0 && (kind == WG_KIND_EMBED || kind == WG_KIND_EMBED_NONBR)) rows_g = rows_embed;
+  if (rows_override > 0) rows_g = rows_override;
   const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, gnn_kind ? rows_g : rows_dense);
   if (nc > m->slab_cap) FAIL(m, V2X_ESTATE, "wgrad: slabs not pre-sized (%d > %d)", nc, m->slab_cap);
   ld.n_slabs = nc;                       // remembered for the slab reduction
@@ -907,7 +908,7 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
   a.dpre_slot_major = (kind >= WG_KIND_DENSE1 && kind <= WG_KIND_DENSE3) ? 1 : 0;      // dz2, dz3, dq (MlpArgs::srow_stride)
   a.srow_stride = (int)srow_stride(m);
   a.zeros = m->zero_buf;
-  a.ts = (m->ts_buf && kind == WG_KIND_GNN) ? m->ts_buf + 3 * 8 * 64 : nullptr;
+  a.ts = (m->ts_buf && (kind == WG_KIND_GNN || kind >= WG_KIND_GNN_E1)) ? m->ts_buf + 3 * 8 * 64 : nullptr;
   return V2X_OK;
 }
 
@@ -915,10 +916,10 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
 int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti& mu, int n_roles, const char* name) {
   int maxt = 1, nc = 1;
   for (int i = 0; i < n_roles; ++i) {
-    maxt = std::max(maxt, (mu.w[i].kp / 16) * (mu.w[i].np / 16));
+    maxt = std::max(maxt, (mu.w[i].kp / 16) * (mu.w[i].np / 16) + (mu.w[i].kind >= WG_KIND_GNN_E1 ? 4 : 0));
     nc = std::max(nc, mu.w[i].n_chunks);
   }
-  const size_t lds = (size_t)(2 * maxt * 64 * 4 + 4 * 5 * 16) * 4;      // accumulator exchange (two sets) + bias (per wave)
+  const size_t lds = (size_t)(2 * maxt * 64 * 4 + 4 * 9 * 16) * 4;      // accumulator exchange (two sets) + bias (per wave)
   const dim3 grid(nc, x.grid_y, n_roles);
   bool dense = false, gnn = false;
   for (int i = 0; i < n_roles; ++i) ((mu.w[i].kind >= WG_KIND_DENSE0 && mu.w[i].kind <= WG_KIND_DENSE3) ? dense : gnn) = true;
@@ -940,14 +941,21 @@ int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti
 }
 
 int wgrad_gnn_role(v2x_model* m, int stage, const IdxMap& x, int total_work, const float* xe, const float* h_prev,
-                   const float* agg_prev, const float* dpre, WgradArgs& a) {
+                   const float* agg_prev, const float* dpre, WgradArgs& a, int embed_tiles = 0, int rows_override = 0) {
   const int F = m->F;
   WgSeg s[3];
   int n = 0;
   if (stage > 0) { s[n++] = WgSeg{h_prev, F, F, 0, 0}; s[n++] = WgSeg{xe, XE, XE, F, 0}; s[n++] = WgSeg{agg_prev, F, F, F + XE, 0}; }
   else { s[n++] = WgSeg{xe, XE, XE, 0, 0}; s[n++] = WgSeg{agg_prev /* neighbour-init or null */, F, F, XE, 0}; }
-  const int kind = stage ? WG_KIND_GNN : (agg_prev ? WG_KIND_EMBED : WG_KIND_EMBED_NONBR);
-  return wgrad_role(m, m->gnn[stage], kind, x, total_work, s, n, dpre, F, a);
+  int kind = stage ? WG_KIND_GNN : (agg_prev ? WG_KIND_EMBED : WG_KIND_EMBED_NONBR);
+  if (stage && embed_tiles) kind = embed_tiles == 1 ? WG_KIND_GNN_E1 : (embed_tiles == 2 ? WG_KIND_GNN_E2 : WG_KIND_GNN_E4);
+  CHK(wgrad_role(m, m->gnn[stage], kind, x, total_work, s, n, dpre, F, a, rows_override));
+  if (stage && embed_tiles) {            // + the embed layer's columns [(stage - 1) * 16 * embed_tiles, ...): kernels.hpp, wgrad_body EN
+    const LayerDesc& e = m->gnn[0];
+    a.e_dpre = m->dpre[0]; a.e_stride = F; a.e_col0 = (stage - 1) * 16 * embed_tiles; a.e_n_real = e.n_out;
+    a.e_layer_off = e.off; a.e_slot_stride = e.slot_stride; a.e_pad = e.pad;
+  }
+  return V2X_OK;
 }
 
 int wide_wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const float* xe, const float* h_prev,
@@ -968,6 +976,16 @@ int wide_wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, con
   return wide_wgrad(m, st, m->gnn[stage], x, s, kp, n, dpre, F, stage ? "k_wgrad_gnn" : "k_wgrad_embed");
 }
 
+// rows per workgroup of the graph layers' roles when the embed gradient rides on them: one workgroup per CU if that
+// leaves >= 256 rows each, else the default chunking (0)
+int merged_wg_rows(const v2x_model* m, int n_idx, int n_slots) {
+  static const int rows_env = env_int("V2X_WG_CHUNK_MERGED", 0);
+  if (rows_env > 0) return rows_env;
+  const int nc_fit = n_cus() / std::max(1, m->L * n_slots);
+  if (nc_fit >= 1 && n_idx / nc_fit >= 256) return ((n_idx + nc_fit - 1) / nc_fit + 63) / 64 * 64;
+  return 0;
+}
+
 // one GNN stage on its own (per-kernel entry point)
 int wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const float* xe, const float* h_prev,
               const float* agg_prev, const float* dpre) {
@@ -986,6 +1004,23 @@ int wgrad_gnn_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch&
     return V2X_OK;
   }
   WgradMulti mu;
+  // The embed layer's gradient (16 MFMAs per block, load-bound) rides on the graph layers' roles when its F / 16 output
+  // tiles divide evenly over the L stages: no workgroups of its own, and the heavy roles get one workgroup per CU --
+  // n_cus / (L * slots) chunks per slot (batch 4096 x 20 slots x 2 stages: 6 chunks = 240 workgroups x 11 blocks per wave
+  // instead of 5 chunks = 200 x 13 with 100 embed workgroups queueing behind them).
+  static const int merge_env = env_int("V2X_WG_EMBED_MERGE", 1);
+  const int NTf = m->F / 16;
+  if (merge_env && !d.nbr && m->L >= 1 && m->L <= NTf && NTf % m->L == 0 && m->L + 1 <= WG_MAX_ROLES) {
+    const int en = NTf / m->L;
+    const int rows = merged_wg_rows(m, x.n_idx, x.grid_y);
+    memset(&mu, 0, sizeof(mu));
+    int total = 0, n = 0;
+    for (int t = m->L; t >= 1; --t) total += layer_work(m->gnn[t]);
+    for (int s = m->L; s >= 1; --s)
+      CHK(wgrad_gnn_role(m, s, x, total, d.xe, m->h[s - 1], m->a[s - 1], m->dpre[s], mu.w[n++], en, rows));
+    m->gnn[0].n_slabs = m->gnn[1].n_slabs;                     // every stage role writes its columns of every embed slab
+    return launch_wgrad_multi(m, st, x, mu, n, "k_wgrad_gnn");
+  }
   int n = 0, s_first = m->L;
   for (int s = m->L; s >= 0; --s) {
     if (n == 0) { memset(&mu, 0, sizeof(mu)); s_first = s; }
@@ -1422,7 +1457,8 @@ GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
 
 int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   int chunk, nc = 1;
-  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), env_int("V2X_WG_CHUNK_EMBED", 1024), 768, 896})
+  const int mr = m->L >= 1 ? merged_wg_rows(m, n_idx, n_slots) : 0;
+  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), env_int("V2X_WG_CHUNK_EMBED", 1024), 768, 896, mr > 0 ? mr : 1024})
     nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
   if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 1, n_slots));     // the fewest tiles (one) split most
   else nc = std::max(nc, mlp_wg_split(n_idx, n_slots).n_slabs);         // k_mlp_train_wg: one slab per workgroup and slot

@@ -554,6 +554,11 @@ struct MlpArgs {
   // rows lie N rows apart and a 16..160-byte row costs a whole 128-byte line per access (measured: 30 % more HBM
   // traffic than the algorithmic bytes in the weight-gradient launch).  Shared weights: one slot, identical layout.
   int64_t srow_stride;
+  // k_mlp_train_wg between the fused graph-layer kernels (per-node weights, whole 16-graph groups): h, agg and gha are
+  // FRAGMENT-major, [slot][group][n-tile][64 lanes] float4 -- the value a lane of those kernels holds for (slot, group,
+  // tile), so that a wave's access is 1 KiB contiguous instead of 64 pieces of 16 bytes from 16 rows (the texture
+  // path handles a wave's request line by line).  0: row-major, else the number of groups per slot.
+  int frag_groups;
 };
 
 template <int F>    // F == 0: "tail" form without the Dense-0 image (wide features: Dense-0 runs in k_wide_gemm)

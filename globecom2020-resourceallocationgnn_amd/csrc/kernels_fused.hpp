@@ -104,6 +104,7 @@ struct FusedFwdArgs {
   int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
   int n_edges;                                       // E of the whole batch
   int compl_sums;                                    // (informative; the COMPL kernel instance is what runs) dense graphs: Agg(h)[q] = colsum(h) - sum over the NON-neighbours of q
+  int frag_out;                                      // h_L and a_L fragment-major for k_mlp_train_wg (MlpArgs::frag_groups); L >= 1
   int* err;
   long long* ts;                                     // TS builds: [8 waves][64] 100 MHz time stamps of workgroup 7
 };
@@ -400,6 +401,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     float* ap = aptr(s - 1);
     unsigned short* gp = gptr(s);
     const bool relu = s < L;
+    const bool fro = a.frag_out && s == L;                       // the last stage's rows go to k_mlp_train_wg only
     f32x4 ag[NSA][FB];                     // gathered a_{s-1} rows; slot i's registers become its output h_s afterwards
     // (1) gather phase
     if (compl_sums) colsum();
@@ -453,10 +455,20 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
       for (int nt = 0; nt < FB; ++nt) {
         f32x4 v = acc[nt] + bias[nt];
         if (relu) v = relu4(v);
-        stg4(hp + rowi[i] * F + nt * 16 + 4 * kg, v);
         ag[i][nt] = v;
         psum[nt] = i == 0 ? v : psum[nt] + v;
         gb |= gate_bits4(v) << (4 * nt);
+      }
+      // (two store sequences under a uniform branch, each with immediate offsets: a stride selected at run time gives
+      //  every store its own 64-bit address -- measured +2 us on this kernel)
+      if (fro) {
+        float* hf = hp + ((int64_t)k * gridDim.x + blockIdx.x) * (FB * 256) + lane * 4;
+#pragma unroll
+        for (int nt = 0; nt < FB; ++nt) stg4(hf + nt * 256, ag[i][nt]);
+      } else {
+        float* hr = hp + rowi[i] * F + 4 * kg;
+#pragma unroll
+        for (int nt = 0; nt < FB; ++nt) stg4(hr + nt * 16, ag[i][nt]);
       }
       gp[k * gate_stride + gate_lane] = (unsigned short)gb;
       ts.mark();                                                 // slot: MFMAs + stores issued
@@ -486,8 +498,15 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
       f32x4 ag[FB];
       if (compl_sums) gather_c(wv + FZ_WAVES * i, ag);
       else gather(wv + FZ_WAVES * i, ag);
+      if (a.frag_out) {
+        float* af = ap + ((int64_t)(wv + FZ_WAVES * i) * gridDim.x + blockIdx.x) * (FB * 256) + lane * 4;
 #pragma unroll
-      for (int kb = 0; kb < FB; ++kb) stg4(ap + rowi[i] * F + kb * 16 + 4 * kg, ag[kb]);
+        for (int kb = 0; kb < FB; ++kb) stg4(af + kb * 256, ag[kb]);
+      } else {
+        float* ar = ap + rowi[i] * F + 4 * kg;
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) stg4(ar + kb * 16, ag[kb]);
+      }
     }
   }
   ts.mark(true);                                                 // end
@@ -534,6 +553,7 @@ struct FusedBwdArgs {
   float* gha;                                        // [R][2F]
   int n_graphs, N, L, S, edges_cap, n_edges;
   int compl_sums;                                    // see FusedFwdArgs
+  int frag_gha;                                      // gha fragment-major (written by k_mlp_train_wg, MlpArgs::frag_groups)
   int* err;
   long long* ts;
 };
@@ -572,13 +592,17 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   csr_issue(csr, a.row_ptr, a.col_idx, r_begin, nrows, x.g0, a.edges_cap, a.n_edges);
   f32x4 dg[NSA][FB];                     // dagg rows of the own slots on their way into the LDS tile
   f32x4 dhk[NSA][FB];                    // dh rows of the own slots: produced and consumed by this wave, never leave it
+  const bool frg = a.frag_gha != 0;
+  const int gst = frg ? 256 : 16;
 #pragma unroll
-  for (int i = 0; i < NS; ++i)
+  for (int i = 0; i < NS; ++i) {
+    const int64_t go = frg ? ((int64_t)(wv + FZ_WAVES * i) * gridDim.x + blockIdx.x) * (2 * FB * 256) + lane * 4 : rowi[i] * (2 * F) + 4 * kg;
 #pragma unroll
     for (int nt = 0; nt < FB; ++nt) {
-      dg[i][nt] = ldg4(a.gha + rowi[i] * (2 * F) + F + nt * 16 + 4 * kg);
-      dhk[i][nt] = ldg4(a.gha + rowi[i] * (2 * F) + nt * 16 + 4 * kg);
+      dg[i][nt] = ldg4(a.gha + go + (FB + nt) * gst);
+      dhk[i][nt] = ldg4(a.gha + go + nt * gst);
     }
+  }
   const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
   if (nedges > a.edges_cap || nedges < 0) {
     if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);

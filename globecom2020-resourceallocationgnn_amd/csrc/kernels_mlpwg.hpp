@@ -200,7 +200,9 @@ __device__ __forceinline__ void wg_write(const float* sA, const float* sB, const
   if ((int)threadIdx.x < n_real) dst[total + threadIdx.x] = sBias[threadIdx.x];
 }
 
-template <int F>
+// FRAG: h, agg and gha fragment-major (MlpArgs::frag_groups) -- a compile-time form: with the layout selected at run time
+// the strides are no longer immediates, every access gets its own 64-bit address and the kernel spills (120 us)
+template <int F, bool FRAG = false>
 __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
   using L = MlpLds<F>;
   using G = MlpWgLds<F>;
@@ -258,11 +260,13 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
     const int idx = min(t * 16 + j, a.n_idx - 1);
     const int64_t row = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
     in.row = row;
+    const int64_t ho = FRAG ? ((int64_t)slot * a.frag_groups + min(t, a.frag_groups - 1)) * (FB * 256) + lane * 4 : row * F + 4 * kg;
+    constexpr int hs = FRAG ? 256 : 16;
 #pragma unroll
-    for (int b = 0; b < FB; ++b) in.z0[b] = ld4(a.h + row * F + b * 16 + 4 * kg);
+    for (int b = 0; b < FB; ++b) in.z0[b] = ld4(a.h + ho + b * hs);
     in.z0[FB] = ld4(a.xe + row * XE + 4 * kg);
 #pragma unroll
-    for (int b = 0; b < FB; ++b) in.z0[FB + 1 + b] = ld4(a.agg + row * F + b * 16 + 4 * kg);
+    for (int b = 0; b < FB; ++b) in.z0[FB + 1 + b] = ld4(a.agg + ho + b * hs);
     in.y = ld4(a.y + row * a.C + cq);
   };
   // `in` holds tile t on entry and tile t_next on exit: the next tile's rows are requested when only Dense-0's weight
@@ -392,9 +396,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
 #pragma unroll
     for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     chain_bwd<5, 2 * FB, true, 12>(smem + L::W1, LD1, skip_xe, j, kg, d1, o, t8, [&]() { wg_n_operand<5>(sN, lane, b5); wg_k_operand(sZ0, lane, 0, aT[0]); });
+    const int64_t go = FRAG ? ((int64_t)slot * a.frag_groups + min(t, a.frag_groups - 1)) * (2 * FB * 256) + lane * 4 : row * (2 * F) + 4 * kg;
+    constexpr int gs = FRAG ? 256 : 16;
 #pragma unroll
     for (int nt = 0; nt < 2 * FB; ++nt)
-      if (valid) st4(a.gha + row * (2 * F) + nt * 16 + 4 * kg, o[nt]);
+      if (valid) st4(a.gha + go + nt * gs, o[nt]);
     mark();
     __builtin_amdgcn_sched_barrier(0);
     load_in(t_next, in);

@@ -60,6 +60,7 @@ struct v2x_model {
   float *z1 = nullptr, *z2 = nullptr, *z3 = nullptr, *q = nullptr;
   float *dq = nullptr, *dz1 = nullptr, *dz2 = nullptr, *dz3 = nullptr, *gha = nullptr, *rowloss = nullptr;
   std::vector<float*> dpre;     // one pre-activation gradient per GNN stage (read concurrently by k_wgrad)
+  bool frag_live = false;                // h_L, a_L (and then gha) of the last training forward are fragment-major (frag_layout)
   unsigned short* gate_bits = nullptr;   // ReLU' gates of the fused forward for the fused backward: [L][gate_stride]
   int64_t gate_stride = 0;               // ushorts per stage: N x ceil(B / 16) x 64 <= 4 R + 64 N
   hipStream_t side = nullptr;   // weight-gradient kernels run here, forked/joined around the data chain
@@ -202,6 +203,7 @@ void set_attrs_f() {
   allow_big_lds((const void*)k_mlp_bwd<F>);
   allow_big_lds((const void*)k_mlp_train<F>);
   allow_big_lds((const void*)k_mlp_train_wg<F>);
+  allow_big_lds((const void*)k_mlp_train_wg<F, true>);
   allow_big_lds((const void*)k_wgrad<F, 0>);
   allow_big_lds((const void*)k_wgrad<F, 1>);
   allow_big_lds((const void*)k_wgrad<F, 2>);
@@ -840,8 +842,8 @@ int launch_mlp_train_wg_f(v2x_model* m, hipStream_t st, const MlpArgs& a, int n_
     ld.n_slabs = sp.n_slabs;              // remembered for the slab reduction
     t.w.l[i] = MlpWgLayer{ld.off, ld.slot_stride, ld.n_out, ld.pad};
   }
-  auto k = k_mlp_train_wg<F>;
-  LAUNCH(m, "k_mlp_train_wg", k, dim3(sp.n_wgs), lds, st, t);
+  if (a.frag_groups > 0) { auto k = k_mlp_train_wg<F, true>; LAUNCH(m, "k_mlp_train_wg", k, dim3(sp.n_wgs), lds, st, t); }
+  else { auto k = k_mlp_train_wg<F>; LAUNCH(m, "k_mlp_train_wg", k, dim3(sp.n_wgs), lds, st, t); }
   return V2X_OK;
 }
 
@@ -1198,7 +1200,16 @@ int launch_pack(v2x_model* m, hipStream_t st) {
     if (_e != hipSuccess) FAIL(m, V2X_EHIP, "launch %s failed: %s", kname, hipGetErrorString(_e)); \
   } while (0)
 
-int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
+// Fragment-major hand-off between the fused graph-layer kernels and k_mlp_train_wg (MlpArgs::frag_groups): whole batch in
+// whole 16-graph groups, per-node weights (a tile of the MLP kernel is then a group of one node), at least one graph layer.
+bool mlp_wg_path(const v2x_model* m);
+bool frag_layout(const v2x_model* m, const DevBatch& d, Range r) {
+  static const int on = env_int("V2X_FRAG_HANDOFF", 1), per_stage = env_int("V2X_WG_PER_STAGE", 0);
+  return on && !per_stage && fused_path(m, d) && r.g0 == 0 && r.ng == d.B && mlp_wg_path(m) && m->S == m->N && m->L >= 1 &&
+         d.B % FZ_TG == 0;
+}
+
+int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_out = false) {
   // The copy follows the parameters by itself: Adam writes both (k_reduce_adam / pack_scatter), set / copy_weights
   // re-pack eagerly.  Only a caller that took the raw parameter pointer (v2x_param_ptr) forces a re-pack per forward.
   if (m->pk_stale) { CHK(launch_pack(m, st)); m->pk_stale = m->raw_params; }
@@ -1207,6 +1218,7 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   a.xe = d.xe; a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_fwd;
   for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.a[s] = m->a[s]; a.gate[s] = m->gate_bits + s * m->gate_stride; }
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
+  a.frag_out = frag_out ? 1 : 0;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   a.compl_sums = fused_compl(m, d) ? 1 : 0;
   const size_t lds = fused_lds(m, d, false, a.compl_sums != 0);
@@ -1235,6 +1247,7 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   for (int s = 0; s <= m->L; ++s) a.dpre[s] = m->dpre[s];
   for (int s = 0; s < m->L; ++s) a.gate[s] = m->gate_bits + s * m->gate_stride;
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
+  a.frag_gha = m->frag_live ? 1 : 0;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   a.compl_sums = fused_compl(m, d) ? 1 : 0;
   const size_t lds = fused_lds(m, d, true, a.compl_sums != 0);
@@ -1290,8 +1303,9 @@ int launch_small_forward(v2x_model* m, hipStream_t st, const DevBatch& d, float*
 int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool with_mlp = true) {
   const int F = m->F, L = m->L;
   const IdxMap x = idx_map(m, d, r);
+  m->frag_live = !with_mlp && frag_layout(m, d, r);
   if (fused_path(m, d) && r.g0 == 0 && r.ng == d.B) {
-    CHK(launch_fused_fwd(m, st, d));       // embed + L stages + L+1 aggregations: one launch
+    CHK(launch_fused_fwd(m, st, d, m->frag_live));       // embed + L stages + L+1 aggregations: one launch
   } else {
     if (use_dense_agg(d, F)) {
       AggDenseArgs q = agg_dense_args(d, r, m->N, F);
@@ -1340,6 +1354,8 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   a.y = y_dev;
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
   const bool mlp_wg = mlp_wg_path(m);      // the Dense weight gradients come out of the MLP launch itself
+  if (m->frag_live && !frag_layout(m, d, r)) FAIL(m, V2X_ESTATE, "backward: the saved forward is fragment-major, this backward cannot read it");
+  a.frag_groups = m->frag_live ? d.B / FZ_TG : 0;
   if (mlp_wg) CHK(launch_mlp_train_wg(m, st, a));
   else if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
   else CHK(launch_mlp(m, st, a, true));
@@ -1762,6 +1778,7 @@ int v2x_forward_backward_phase(v2x_model* m, const v2x_batch* b, const float* y,
       mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
       a.y = yd;
       a.inv_denom = 1.0f / loss_denominator(m, n_global);
+      a.frag_groups = m->frag_live ? d.B / FZ_TG : 0;
       if (mlp_wg_path(m)) {
         CHK(launch_mlp_train_wg(m, st, a));
       } else {

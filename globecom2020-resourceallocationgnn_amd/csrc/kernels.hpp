@@ -1443,6 +1443,11 @@ constexpr int WG_MAX_ROLES = 8;
 #ifndef V2X_WG_DEPTH_GNN
 #define V2X_WG_DEPTH_GNN 3
 #endif
+// with the embed gradient on board (one more operand per block, 11 blocks per wave) two register buffers beat three:
+// 42.3-43.5 us against 45.1 (depth 4: 45.9)
+#ifndef V2X_WG_DEPTH_MERGED
+#define V2X_WG_DEPTH_MERGED 2
+#endif
 struct WgradMulti { WgradArgs w[WG_MAX_ROLES]; };
 enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 3, WG_KIND_DENSE2 = 4, WG_KIND_DENSE3 = 5,
        WG_KIND_EMBED_NONBR = 6, WG_KIND_GNN_E1 = 7, WG_KIND_GNN_E2 = 8, WG_KIND_GNN_E4 = 9 };   // _En: + n tiles of the embed gradient
@@ -1461,12 +1466,12 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
   for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
   if constexpr (MODE != 1) {
     if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN>(a, smem, blockIdx.x, blockIdx.y); return; }
-    if (a.kind == WG_KIND_GNN_E1) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN, false, 1>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_GNN_E1) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 1>(a, smem, blockIdx.x, blockIdx.y); return; }
     if constexpr (F >= 32) {
-      if (a.kind == WG_KIND_GNN_E2) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN, false, 2>(a, smem, blockIdx.x, blockIdx.y); return; }
+      if (a.kind == WG_KIND_GNN_E2) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 2>(a, smem, blockIdx.x, blockIdx.y); return; }
     }
     if constexpr (F >= 64) {
-      if (a.kind == WG_KIND_GNN_E4) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN, false, 4>(a, smem, blockIdx.x, blockIdx.y); return; }
+      if (a.kind == WG_KIND_GNN_E4) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 4>(a, smem, blockIdx.x, blockIdx.y); return; }
     }
     if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
     if (a.kind == WG_KIND_EMBED_NONBR) { wgrad_body<XE, F, 0, F, 3, true>(a, smem, blockIdx.x, blockIdx.y); return; }

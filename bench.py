@@ -112,8 +112,9 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     table["k_wgrad_all"] = table["k_wgrad_gnn"] + table["k_wgrad_dense"]        # every layer's weight gradient, one launch
     # graph-major fused launches (csrc/kernels_fused.hpp): inputs once, every h_s / a_s (dpre_s) once -- the tensors
     # the weight-gradient launch and the decision MLP read; nothing else leaves the CU
-    table["k_gnn_fwd_fused"] = 4 * R * (Dn + De) + csr + 2 * (L + 1) * 4 * R * F
-    table["k_gnn_bwd_fused"] = 4 * R * 2 * F + L * 4 * R * F + csr + (L + 1) * 4 * R * F
+    # (the backward gates with the SIGN BITS of h_s the forward leaves behind, one bit per feature, not with the rows)
+    table["k_gnn_fwd_fused"] = 4 * R * (Dn + De) + csr + 2 * (L + 1) * 4 * R * F + L * R * F // 8
+    table["k_gnn_bwd_fused"] = 4 * R * 2 * F + L * R * F // 8 + csr + (L + 1) * 4 * R * F
     table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"] - 4 * R * C  # fwd + Huber + bwd fused: q is not re-read
     table["k_mlp_train_wg"] = table["k_mlp_train"]    # weight gradients from the values on chip: no further node-row bytes
     return table.get(name)

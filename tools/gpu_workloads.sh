@@ -1,5 +1,5 @@
 # the other workloads of profiles/: one JSON line each (no CPU leg, roofline section kept)
-O=gpurun_out/r2g; mkdir -p $O
+O=gpurun_out/r2j; mkdir -p $O
 B="python bench.py --no-cpu-baseline"
 $B --share-weights > $O/bench_shared.json 2>/dev/null
 $B --workload cfg4 > $O/bench_cfg4.json 2>/dev/null

@@ -1257,8 +1257,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
     for (; k + 2 < nb; k += 2) {
       load_full(wv + 4 * (k + 1), b1);
       mfma_block(b0); V2X_ILV;
+      mark();
       load_full(wv + 4 * (k + 2), b0);
       mfma_block(b1); V2X_ILV;
+      mark();
     }
     if (nb - k == 2) {                                             // peeled tail: 2 or 1 blocks left
       load_full(wv + 4 * (k + 1), b1); V2X_SB;

@@ -104,6 +104,7 @@ struct FusedFwdArgs {
   int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
   int n_edges;                                       // E of the whole batch
   int compl_sums;                                    // (informative; the COMPL kernel instance is what runs) dense graphs: Agg(h)[q] = colsum(h) - sum over the NON-neighbours of q
+  unsigned* nbmask;                                  // compl_sums: the rows' non-neighbour masks, [R] words, for the fused backward
   int frag_out;                                      // h_L and a_L fragment-major for k_mlp_train_wg (MlpArgs::frag_groups); L >= 1
   int* err;
   long long* ts;                                     // TS builds: [8 waves][64] 100 MHz time stamps of workgroup 7
@@ -299,6 +300,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
       if (r < nrows)
         for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) nb |= 1u << x.sCol[e];
       x.sC[r] = ~nb & valid;
+      if (a.nbmask && r < nrows) a.nbmask[r_begin + r] = ~nb & valid;
     }
     ts.mark();                                                   // (TS) masks built
   }
@@ -553,6 +555,7 @@ struct FusedBwdArgs {
   float* gha;                                        // [R][2F]
   int n_graphs, N, L, S, edges_cap, n_edges;
   int compl_sums;                                    // see FusedFwdArgs
+  const unsigned* nbmask;                            // compl_sums: non-neighbour masks left by the fused forward (FusedFwdArgs::nbmask)
   int frag_gha;                                      // gha fragment-major (written by k_mlp_train_wg, MlpArgs::frag_groups)
   int* err;
   long long* ts;
@@ -588,8 +591,12 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   };
   float* myrow = x.sD + kg * x.SUB + jc * ROWF;
   // ---- requests in the order of their urgency: CSR slice, the dagg_L / dh_L rows of the own slots
+  // (complement form: no CSR at all -- the forward left the rows' non-neighbour masks behind, one coalesced word per row
+  //  instead of the chain row_ptr -> col_idx slice -> LDS -> 18 LDS atomics per row that the start of this kernel waited for)
   FzCsrEarly csr;
-  csr_issue(csr, a.row_ptr, a.col_idx, r_begin, nrows, x.g0, a.edges_cap, a.n_edges);
+  unsigned nbv = 0u;
+  if constexpr (COMPL) nbv = a.nbmask[r_begin + min((int)threadIdx.x, nrows - 1)];
+  else csr_issue(csr, a.row_ptr, a.col_idx, r_begin, nrows, x.g0, a.edges_cap, a.n_edges);
   f32x4 dg[NSA][FB];                     // dagg rows of the own slots on their way into the LDS tile
   f32x4 dhk[NSA][FB];                    // dh rows of the own slots: produced and consumed by this wave, never leave it
   const bool frg = a.frag_gha != 0;
@@ -603,13 +610,17 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
       dhk[i][nt] = ldg4(a.gha + go + nt * gst);
     }
   }
-  const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
-  if (nedges > a.edges_cap || nedges < 0) {
-    if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
-    return;
+  if constexpr (COMPL) {
+    if ((int)threadIdx.x < FZ_TG * N) x.sRp[threadIdx.x] = (int)nbv;       // (the CSR offsets' place: unused in this form)
+  } else {
+    const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
+    if (nedges > a.edges_cap || nedges < 0) {
+      if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);
+      return;
+    }
+    for (int i = threadIdx.x; i < FZ_TG * N; i += FZ_THREADS) x.sM[i] = 0u;
+    csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
   }
-  for (int i = threadIdx.x; i < FZ_TG * N; i += FZ_THREADS) x.sM[i] = 0u;
-  csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
   constexpr bool compl_sums = COMPL;
   float* mysum = x.sS + ((wv * 4 + kg) * FZ_TG + jc) * ROWF;     // this wave's partial column sum of the dagg tile
   const float* tot = x.sT + (kg * FZ_TG + jc) * ROWF;            // column sums of the dagg tile
@@ -636,10 +647,20 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   park();
   fz_barrier();
   if (compl_sums) fz_reduce_sums<FB, ROWF>(x.sS, x.sT);
-  // transposed adjacency: bit q of sM[j*N + p] = edge p -> q (integer atomics: order-independent)
-  for (int r = threadIdx.x; r < nrows; r += FZ_THREADS) {
-    const int jj = r / N, q = r - jj * N;
-    for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) atomicOr(&x.sM[jj * N + x.sCol[e]], 1u << q);
+  // transposed adjacency: bit q of sM[j*N + p] = edge p -> q
+  if constexpr (COMPL) {                 // from the non-neighbour masks: p -> q exists iff bit p of row q's mask is clear
+    const unsigned vmask = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
+    for (int r = threadIdx.x; r < nrows; r += FZ_THREADS) {
+      const int jj = r / N, p = r - jj * N;
+      unsigned ns = 0u;
+      for (int q = 0; q < N; ++q) ns |= (((unsigned)x.sRp[jj * N + q] >> p) & 1u) << q;
+      x.sM[r] = ~ns & vmask;
+    }
+  } else {                               // integer atomics: order-independent
+    for (int r = threadIdx.x; r < nrows; r += FZ_THREADS) {
+      const int jj = r / N, q = r - jj * N;
+      for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) atomicOr(&x.sM[jj * N + x.sCol[e]], 1u << q);
+    }
   }
   fz_barrier();
   ts.mark();                                                     // 1: tile + masks ready

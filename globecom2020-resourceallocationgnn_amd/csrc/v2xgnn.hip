@@ -60,6 +60,7 @@ struct v2x_model {
   float *z1 = nullptr, *z2 = nullptr, *z3 = nullptr, *q = nullptr;
   float *dq = nullptr, *dz1 = nullptr, *dz2 = nullptr, *dz3 = nullptr, *gha = nullptr, *rowloss = nullptr;
   std::vector<float*> dpre;     // one pre-activation gradient per GNN stage (read concurrently by k_wgrad)
+  unsigned* nbmask = nullptr;            // [cap_rows] non-neighbour masks: fused forward -> fused backward (complement form)
   bool frag_live = false;                // h_L, a_L (and then gha) of the last training forward are fragment-major (frag_layout)
   unsigned short* gate_bits = nullptr;   // ReLU' gates of the fused forward for the fused backward: [L][gate_stride]
   int64_t gate_stride = 0;               // ushorts per stage: N x ceil(B / 16) x 64 <= 4 R + 64 N
@@ -271,6 +272,9 @@ int ensure_rows(v2x_model* m, int64_t R) {
   for (int s = 0; s <= m->L; ++s) CHK(re(m->dpre[s], F));
   if (m->gate_bits) HIPCHK(m, hipFree(m->gate_bits));
   m->gate_bits = nullptr;
+  if (m->nbmask) HIPCHK(m, hipFree(m->nbmask));
+  m->nbmask = nullptr;
+  HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->nbmask), (size_t)R * sizeof(unsigned)));
   m->gate_stride = 4 * R + 64 * (int64_t)m->N;
   HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->gate_bits), (size_t)((m->L + 1) * m->gate_stride) * sizeof(unsigned short)));
   m->cap_rows = R;
@@ -1219,6 +1223,7 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_
   for (int s = 0; s <= m->L; ++s) { a.h[s] = m->h[s]; a.a[s] = m->a[s]; a.gate[s] = m->gate_bits + s * m->gate_stride; }
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   a.frag_out = frag_out ? 1 : 0;
+  a.nbmask = m->nbmask;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   a.compl_sums = fused_compl(m, d) ? 1 : 0;
   const size_t lds = fused_lds(m, d, false, a.compl_sums != 0);
@@ -1248,6 +1253,7 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   for (int s = 0; s < m->L; ++s) a.gate[s] = m->gate_bits + s * m->gate_stride;
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   a.frag_gha = m->frag_live ? 1 : 0;
+  a.nbmask = m->nbmask;
   const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
   a.compl_sums = fused_compl(m, d) ? 1 : 0;
   const size_t lds = fused_lds(m, d, true, a.compl_sums != 0);
@@ -1610,6 +1616,7 @@ void v2x_destroy(v2x_model* m) {
                    m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part, m->pk_fwd, m->pk_bwd};
   for (float* p : m->dpre) if (p) hipFree(p);
   if (m->gate_bits) hipFree(m->gate_bits);
+  if (m->nbmask) hipFree(m->nbmask);
   for (auto& e : m->ev) if (e) hipEventDestroy(e);
   if (m->side) hipStreamDestroy(m->side);
   for (float* p : ptrs) if (p) hipFree(p);

@@ -76,6 +76,26 @@ def test_model_parity_over_shapes(N, F, L, shared, B, topo):
     pytest.fail("every draw failed: %s" % failures)
 
 
+GROUPS = [  # per-node weights, whole 16-graph groups, F <= 64, L >= 1: the training step hands h_L, a_L and gha over
+            # FRAGMENT-major (frag_layout in csrc/v2xgnn.hip); with the reference topology also the complement aggregation,
+            # whose backward takes its masks from the forward
+    (4, 16, 2, False, 32, True), (4, 16, 1, False, 16, False), (7, 32, 1, False, 16, False), (7, 32, 2, False, 48, True),
+    (20, 64, 2, False, 48, True), (20, 64, 1, False, 16, True), (20, 64, 4, False, 16, False), (20, 16, 3, False, 32, True),
+    (28, 32, 2, False, 16, True), (32, 16, 2, False, 16, False),
+]
+
+
+@pytest.mark.parametrize("N,F,L,shared,B,topo", GROUPS)
+def test_model_parity_whole_groups(N, F, L, shared, B, topo):
+    failures = []
+    for attempt in range(3):
+        bad = _check(N, F, L, shared, B, topo, seed=2000 * attempt + 7 * N + F + L + B)
+        if bad is None:
+            return
+        failures.append(bad)
+    pytest.fail("every draw failed: %s" % failures)
+
+
 SMALL = [  # N, F, L, shared, B, reference topology: forwards of at most 256 node rows run k_predict_small
     (1, 16, 1, False, 1, False), (2, 32, 2, False, 3, False), (4, 16, 2, False, 1, True), (4, 16, 2, True, 64, True),
     (7, 32, 3, False, 5, False), (20, 64, 2, False, 1, True), (20, 64, 2, False, 12, True), (20, 64, 4, True, 2, True),

@@ -415,7 +415,8 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
       for (int kb = 0; kb < FB; ++kb) stg4(ap + rowi[i] * F + kb * 16 + 4 * kg, ag[i][kb]);
     }
     ts.mark();                                                   // stage: gathers done
-    // (2) MFMA phase
+    // (2) MFMA phase.  (Not in turns as in the backward: a forward slot alone takes 3.0-3.3 us -- 1.5x the weights per
+    //     slot, and the h_s stores --, side by side the two waves of a SIMD finish sooner: 53.4 us against 58.5.)
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       const int k = wv + FZ_WAVES * i;
@@ -562,7 +563,7 @@ struct FusedBwdArgs {
 };
 
 struct FzCtxB {
-  float* sD; int* sRp; unsigned* sM; unsigned char* sCol; float* sS; float* sT;
+  float* sD; int* sRp; unsigned* sM; unsigned char* sCol; float* sS; float* sT; int* sFlag;
   int N, L, SUB, lane, wv, jc, kg, g0;
 };
 
@@ -593,6 +594,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   // ---- requests in the order of their urgency: CSR slice, the dagg_L / dh_L rows of the own slots
   // (complement form: no CSR at all -- the forward left the rows' non-neighbour masks behind, one coalesced word per row
   //  instead of the chain row_ptr -> col_idx slice -> LDS -> 18 LDS atomics per row that the start of this kernel waited for)
+  if (threadIdx.x < 4) x.sFlag[threadIdx.x] = 0;                 // (before the first barrier; stages count down from L >= 1)
   FzCsrEarly csr;
   unsigned nbv = 0u;
   if constexpr (COMPL) nbv = a.nbmask[r_begin + min((int)threadIdx.x, nrows - 1)];
@@ -732,6 +734,15 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
     }
     ts.mark();                                                   // stage: gathers done
     if (s == 0) break;
+#ifndef V2X_FZ_NO_TURNS
+    // The two waves of a SIMD take TURNS at the MFMA phase: issuing their MFMA runs side by side they finish 5 slots in
+    // 13 us, one after the other in 9.5 (a slot takes 1.9 us when its wave has the matrix pipe to itself, and the
+    // second wave's gathers overlap with the first one's MFMAs either way).  Wave w + 4 waits for wave w's flag.
+    if (wv >= 4) {
+      while (__hip_atomic_load(x.sFlag + (wv - 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != s) __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
     // (2) data gradients of the own slots: chunk sequence number n = i * NCH + c lives in ring buffer n % 3 and is
     //     requested two chunks ahead (inside this stage only)
 #pragma unroll
@@ -767,6 +778,9 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
       }
       ts.mark();                                                 // slot done
     }
+#ifndef V2X_FZ_NO_TURNS
+    if (wv < 4 && lane == 0) __hip_atomic_store(x.sFlag + wv, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     park_sums();
     fz_barrier();                       // all gathers from the dagg_s tile are done
     ts.mark();
@@ -791,6 +805,7 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_bwd_fused(FusedBwdArgs a)
   x.sRp = reinterpret_cast<int*>(x.sT + (COMPL ? FZ_TOT_ROWS * P::ROWF : 0));    // [16 N + 1]
   x.sM = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // [16 N] out-neighbour bit masks (N <= 32)
   x.sCol = reinterpret_cast<unsigned char*>(x.sM + FZ_TG * a.N);
+  x.sFlag = reinterpret_cast<int*>(x.sCol + (a.edges_cap + 15) / 16 * 16);   // [4] turn flags of the SIMDs' wave pairs
   x.lane = threadIdx.x & 63;
   x.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   x.kg = x.lane >> 4;

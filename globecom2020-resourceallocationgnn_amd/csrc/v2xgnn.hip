@@ -1160,7 +1160,7 @@ size_t fused_lds(const v2x_model* m, const DevBatch& d, bool bwd, bool compl_sum
   size_t b = 4 * rows * fused_rowf(m->F) * 4 + (rows + 1) * 4 + (size_t)FZ_TG * d.max_edges;
   b += rows * 4;                                       // bit masks: backward always, forward with compl_sums
   if (compl_sums) b += (size_t)(FZ_SUMS_ROWS + FZ_TOT_ROWS) * fused_rowf(m->F) * 4;
-  return (b + 15) / 16 * 16;
+  return (b + 15) / 16 * 16 + 64;                      // + the turn flags of the backward (FzCtxB::sFlag)
 }
 bool fused_path(const v2x_model* m, const DevBatch& d) {
   if (!m->pk_fwd || m->cfg.variable_graphs || d.goff || d.nbr || m->F > 64 || m->N > 32 || m->L > FZ_MAXL) return false;

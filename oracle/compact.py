@@ -185,6 +185,7 @@ def forward(spec: GnnSpec, params, x, e, M, nbr=None):
     if nbr is not None:
         pre = pre + _slot_mm(nbr, g0['W3'], None)
     h = [np.maximum(pre, 0)]                                    # :121 activation='relu'
+    relu_pre = [pre]             # pre-activations of every ReLU (tests: which gates sit at fp32 rounding distance of 0)
     a = [M @ h[0]]                                              # :152
     for s in range(1, L + 1):
         gs = params['gnn'][s]
@@ -192,14 +193,18 @@ def forward(spec: GnnSpec, params, x, e, M, nbr=None):
         pre = (_slot_mm(u, gs['W1'], None) + _slot_mm(e, gs['W2'], None)
                + _slot_mm(a[s - 1], gs['W3'], None) + _slot_bias(gs['b'], R))
         h.append(np.maximum(pre, 0) if s < L else pre)          # :154 relu ... :161 linear
+        if s < L:
+            relu_pre.append(pre)
         a.append(M @ h[s])                                      # :159 / :166
     z = [np.concatenate([x, h[L], a[L]], axis=1)]               # :168-175
     for i in range(4):
         d = params['dense'][i]
         pre = _slot_mm(z[i], d['W'], None) + _slot_bias(d['b'], R)
         z.append(np.maximum(pre, 0) if i < 3 else pre)          # :176-179
+        if i < 3:
+            relu_pre.append(pre)
     q = z[4]
-    cache = {'x': x, 'e': e, 'nbr': nbr, 'h': h, 'a': a, 'z': z, 'M': M}
+    cache = {'x': x, 'e': e, 'nbr': nbr, 'h': h, 'a': a, 'z': z, 'M': M, 'relu_pre': relu_pre}
     return q, cache
 
 
@@ -221,17 +226,21 @@ def huber_loss_and_grad(spec: GnnSpec, q, y, n_graphs_global=None):
     return loss, dq.astype(q.dtype)
 
 
-def backward(spec: GnnSpec, params, cache, dq):
-    """Hand-written reverse pass of `forward`; returns grads with the structure of params."""
+def backward(spec: GnnSpec, params, cache, dq, probe=None):
+    """Hand-written reverse pass of `forward`; returns grads with the structure of params.
+    probe: optional dict; receives 'pre_gate' = the gradient arriving at every ReLU BEFORE its gate is applied, in the
+    order of cache['relu_pre'] (tests use it to bound what a gate at fp32 rounding distance of 0 can change)."""
     L, F, Dn = spec.n_mp_layers, spec.feat_dim, spec.node_in
     S = spec.n_slots
     x, e, nbr, h, a, z, M = (cache[k] for k in ['x', 'e', 'nbr', 'h', 'a', 'z', 'M'])
     Mt = M.T.tocsr()
     grads = zeros_like_params(params)
+    pre_gate = [None] * (L + 3)
     g = dq
     for i in range(3, -1, -1):
         d = params['dense'][i]
         if i < 3:
+            pre_gate[L + i] = g
             g = g * (z[i + 1] > 0)
         grads['dense'][i]['W'] = _slot_wgrad(z[i], g, S)
         grads['dense'][i]['b'] = _slot_bgrad(g, S)
@@ -239,6 +248,8 @@ def backward(spec: GnnSpec, params, cache, dq):
     dh = g[:, Dn:Dn + F] + Mt @ g[:, Dn + F:]          # z0 = [x | h_L | a_L]
     for s in range(L, 0, -1):
         gs = params['gnn'][s]
+        if s < L:
+            pre_gate[s] = dh
         dpre = dh * (h[s] > 0) if s < L else dh
         u = np.concatenate([h[s - 1], x], axis=1)
         grads['gnn'][s]['W1'] = _slot_wgrad(u, dpre, S)
@@ -248,6 +259,9 @@ def backward(spec: GnnSpec, params, cache, dq):
         du = _slot_mm_t(dpre, gs['W1'])
         da = _slot_mm_t(dpre, gs['W3'])
         dh = du[:, :F] + Mt @ da
+    pre_gate[0] = dh
+    if probe is not None:
+        probe['pre_gate'] = pre_gate
     dpre = dh * (h[0] > 0)
     grads['gnn'][0]['W1'] = _slot_wgrad(x, dpre, S)
     grads['gnn'][0]['W2'] = _slot_wgrad(e, dpre, S)

@@ -3,7 +3,7 @@
 A few of the 504 shapes report a mismatch in a BIAS gradient of a layer summed over few rows: a ReLU pre-activation
 ~1e-6 of its layer's scale that fp32 and fp64 gate differently (checked on the dumped case: pre-activation 2.9e-6 at a
 typical magnitude of 35).  tests/sweep_replay_case.py replays the dumped case in a fresh process (bit-identical gradients);
-tests/test_gpu_shapes.py is the permanent subset with a retry on a fresh draw."""
+tests/test_gpu_shapes.py is the permanent subset (one seeded draw per shape, every draw counts)."""
 import itertools, sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

@@ -5,9 +5,10 @@ against the oracle.
   configs[3]  100 links x 256 features x 3 layers, 8192 / 8 = 1024 graphs per GPU    -> test_cfg3_*
   configs[4]  8-128 links per graph (CSR offsets), 16384 / 8 = 2048 graphs per GPU   -> test_cfg4_*
 
-The oracle needs minutes at these sizes, so the checks are size-independent properties of the path (the pattern of
-test_gpu_fullsize.py): the loss is the Huber mean of the engine's own forward output, the gradient is additive over
-shards taken with the global denominator (what the data-parallel all-reduce relies on), hipGraph replay == eager.
+Element-wise oracle parity at these sizes lives in test_gpu_fullsize.py (test_cfg3_share_vs_oracle,
+test_cfg4_share_vs_oracle); here are the size-independent properties of the path at the same sizes: the loss is the Huber
+mean of the engine's own forward output, the gradient is additive over shards taken with the global denominator (what the
+data-parallel all-reduce relies on), hipGraph replay == eager.
 """
 import os
 import random

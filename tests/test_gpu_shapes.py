@@ -3,10 +3,10 @@ shapes -- link counts 1..40 (1 and 2 links: graphs without edges), all feature w
 message-passing layers, per-node and shared weights, batches that are not multiples of any tile (1, 17, 130), the
 reference topology and random adjacencies.  `tests/sweep_shapes.py` runs the full 504-shape grid.
 
-A ReLU whose pre-activation is ~1e-6 of its layer's scale is gated differently by fp32 and fp64 arithmetic (one row's
-contribution appears / disappears from a bias gradient summed over few rows); that is conditioning, not parity, and it
-is tied to the random draw, so a shape is retried on a fresh draw before it counts as a failure (a kernel bug fails
-every draw)."""
+Every shape is ONE seeded draw and that draw counts.  A ReLU whose pre-activation lies within fp32 rounding of 0 is gated
+differently by fp32 and fp64 arithmetic (one row's contribution appears / disappears from a gradient summed over few
+rows): such units are found explicitly from the oracle's pre-activations and the oracle's reverse pass takes their gates
+the kernels' way (tests/util.py, assert_grads_match_oracle); nothing is redrawn, no tolerance is widened."""
 import os
 
 import numpy as np
@@ -15,7 +15,8 @@ import pytest
 import v2xgnn
 from v2xgnn import GnnSpec, PackedBatch, GnnEngine
 from oracle import compact as oc
-from util import ospec, f32_params, random_inputs, FWD_RTOL, FWD_ATOL, GRAD_RTOL, GRAD_ATOL_REL
+from util import (ospec, f32_params, random_inputs, oracle_step, assert_fwd_close, assert_close, assert_grads_match_oracle,
+                  FWD_RTOL, FWD_ATOL)
 
 pytestmark = pytest.mark.gpu
 
@@ -44,36 +45,21 @@ def _check(N, F, L, shared, B, topo, seed):
         del os.environ["V2X_SMALL_PREDICT"]
     eng.set_weights(oc.params_to_list(P))
     graph = ((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
-    M = oc.csr_to_matrix(*graph, dtype=np.float64)
-    os_ = ospec(spec)
-    q_ref, cache = oc.forward(os_, P, x.reshape(B * N, -1).astype(np.float64), e.reshape(B * N, -1).astype(np.float64), M)
     q = eng.forward(pb)
-    scale = max(1.0, np.abs(q_ref).max())
-    if not np.all(np.abs(q - q_ref) <= FWD_RTOL * np.abs(q_ref) + FWD_ATOL * scale):
-        return "forward"
-    y = (q_ref + rng.normal(0, 1.2, size=q_ref.shape)).astype(np.float32)
-    loss_ref, dq = oc.huber_loss_and_grad(os_, q.astype(np.float64), y.astype(np.float64))      # differentiate at the kernels' q
-    g_ref = oc.backward(os_, P, cache, dq)
+    # targets around the kernels' own q, so that both Huber branches occur whatever the scale of q; the loss is
+    # differentiated at that q (forward parity is asserted separately)
+    y = (q + rng.normal(0, 1.2, size=q.shape)).astype(np.float32)
+    step = oracle_step(spec, P, x.reshape(B * N, -1), e.reshape(B * N, -1), graph, y, q_at=q)
+    assert_fwd_close(q, step['q'], "forward")
     loss = eng.forward_backward(pb, y)
-    if not np.allclose(loss, loss_ref, rtol=2e-4, atol=1e-6):
-        return "loss"
-    got = v2xgnn.flat_to_keras_list(spec, eng.get_grad_flat())
-    for i, (a, b) in enumerate(zip(got, oc.params_to_list(g_ref))):
-        sc = float(np.abs(b).max()) or 1.0
-        if np.any(np.abs(a - b) > GRAD_RTOL * np.abs(b) + GRAD_ATOL_REL * sc):
-            return "gradient array %d" % i
-    return None
+    assert_close(loss, step['loss'], 2e-4, 1e-6, "per-output Huber loss")
+    assert_grads_match_oracle(v2xgnn.flat_to_keras_list(spec, eng.get_grad_flat()), P, step, "N=%d F=%d L=%d B=%d" % (N, F, L, B))
+    eng.close()
 
 
 @pytest.mark.parametrize("N,F,L,shared,B,topo", SHAPES)
 def test_model_parity_over_shapes(N, F, L, shared, B, topo):
-    failures = []
-    for attempt in range(3):
-        bad = _check(N, F, L, shared, B, topo, seed=1000 * attempt + 7 * N + F + L + B)
-        if bad is None:
-            return
-        failures.append(bad)
-    pytest.fail("every draw failed: %s" % failures)
+    _check(N, F, L, shared, B, topo, seed=7 * N + F + L + B)
 
 
 GROUPS = [  # per-node weights, whole 16-graph groups, F <= 64, L >= 1: the training step hands h_L, a_L and gha over
@@ -87,13 +73,7 @@ GROUPS = [  # per-node weights, whole 16-graph groups, F <= 64, L >= 1: the trai
 
 @pytest.mark.parametrize("N,F,L,shared,B,topo", GROUPS)
 def test_model_parity_whole_groups(N, F, L, shared, B, topo):
-    failures = []
-    for attempt in range(3):
-        bad = _check(N, F, L, shared, B, topo, seed=2000 * attempt + 7 * N + F + L + B)
-        if bad is None:
-            return
-        failures.append(bad)
-    pytest.fail("every draw failed: %s" % failures)
+    _check(N, F, L, shared, B, topo, seed=7 * N + F + L + B)
 
 
 SMALL = [  # N, F, L, shared, B, reference topology: forwards of at most 256 node rows run k_predict_small

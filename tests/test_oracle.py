@@ -218,3 +218,58 @@ def test_literal_formulation_fit_step_equals_the_compact_one(N, F, L, with_nbr):
         assert np.abs(lc - ll).max() < 1e-12
     for a, b in zip(oc.param_arrays(om.params), oc.param_arrays(Pl)):
         assert np.abs(a - b).max() < 1e-10
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_rounding_distance_relu_gates_are_identified_and_nothing_else_is_excused(shared):
+    """tests/util.assert_grads_match_oracle (how the GPU parity tests treat ReLUs whose pre-activation lies within fp32
+    rounding of 0): a gradient computed with some candidate gates taken the other way is accepted, the flipped gates are
+    identified exactly; a gradient that is wrong in any other way is still rejected."""
+    import copy
+    from util import assert_grads_match_oracle, ospec
+    N, F, L, B = 5, 16, 2, 40
+    spec = OSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=shared)
+    rng = np.random.default_rng(11)
+    P = oc.init_params(spec, rng, np.float64, random_bias=True)
+    x = rng.normal(0.8, 0.4, size=(B * N, 9))
+    e = rng.normal(0.9, 0.1, size=(B * N, 4))
+    graph = oc.adj_to_csr(oc.random_topology(rng, B, N))
+    M = oc.csr_to_matrix(*graph, dtype=np.float64)
+    q, cache = oc.forward(spec, P, x, e, M)
+    y = q + rng.normal(0, 1.2, size=q.shape)
+    _, dq = oc.huber_loss_and_grad(spec, q, y)
+    # candidates: one or two units per ReLU tensor (two in the same column of dense layer 0 when weights are shared)
+    units = [(0, 0 * N + 2, 3), (1, 1 * N + 1, 5), (2, 1 * N + 4, 70), (2, 7 * N + 4, 70), (3, 2 * N + 0, 11), (4, 3 * N + 3, 7),
+             (1, 9 * N + 1, 5), (0, 12 * N + 0, 13)]
+    cache = dict(cache)
+    cache['relu_pre'] = [p.copy() for p in cache['relu_pre']]
+    for t, r, f in units:
+        cache['relu_pre'][t][r, f] = 1e-9 * np.sign(cache['relu_pre'][t][r, f])         # at rounding distance of 0
+    probe = {}
+    ref = oc.backward(spec, P, cache, dq, probe=probe)
+    step = {'os': spec, 'grads': ref, 'cache': cache, 'dq': dq, 'pre_gate': probe['pre_gate']}
+    want = [units[0], units[2], units[3], units[5], units[6]]                           # the gates "the kernels" took the other way
+    c2 = copy.deepcopy(cache)
+    hold = [c2['h'][0], c2['h'][1], c2['z'][1], c2['z'][2], c2['z'][3]]
+    for t, r, f in want:
+        hold[t][r, f] = 0.0 if hold[t][r, f] > 0 else 1e-300
+    flipped = oc.backward(spec, P, c2, dq)
+    noise = lambda a: a * (1 + 1e-5 * rng.uniform(-1, 1, size=a.shape))                # fp32-like rounding noise
+    got = [noise(a) for a in oc.params_to_list(flipped)]
+    assert any(np.abs(a - b).max() > 1e-3 * np.abs(b).max() for a, b in zip(got, oc.params_to_list(ref)) if b.size and np.abs(b).max() > 0)
+    used, n_cand, n_flip = assert_grads_match_oracle(got, P, step, "flipped candidates")
+    assert n_cand >= len(units) and n_flip == len(want)          # (a few units of the draw are candidates by themselves)
+    for a, b in zip(oc.params_to_list(used), oc.params_to_list(flipped)):
+        assert np.array_equal(a, b)
+    # an untouched gradient needs no resolution at all
+    assert assert_grads_match_oracle([noise(a) for a in oc.params_to_list(ref)], P, step)[1:] == (0, 0)
+    # ... and errors that are not flipped candidate gates are rejected: a wrong scale of one array, a non-candidate gate
+    bad = [a.copy() for a in got]
+    bad[5] *= 1.01
+    with pytest.raises(AssertionError):
+        assert_grads_match_oracle(bad, P, step, "scaled array")
+    c3 = copy.deepcopy(c2)
+    r_nc, f_nc = np.argwhere(c3['h'][1] > 0.5)[0]
+    c3['h'][1][r_nc, f_nc] = 0.0                                                        # a healthy unit's gate closed
+    with pytest.raises(AssertionError):
+        assert_grads_match_oracle([noise(a) for a in oc.params_to_list(oc.backward(spec, P, c3, dq))], P, step, "non-candidate gate")

@@ -120,16 +120,32 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     return table.get(name)
 
 
+def lib_sha256():
+    """sha256 of the libv2xgnn.so this process loads (ties measurements kept under profiles/ to the binary they are of)."""
+    import hashlib
+    from v2xgnn.lib import library_path
+    try:
+        with open(library_path(), "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()
+    except OSError:
+        return None
+
+
 def hbm_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled
-    per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE); only valid for the default workload."""
+    per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE).  Counters cannot be read from inside the run, so the
+    figure is only reported when it was measured on THIS binary (profiles/hbm_traffic.json records the sha256 of the
+    libv2xgnn.so of its PMC passes) and for the default workload; otherwise null."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     default = (args.batch, args.nodes, args.feat, args.layers, args.share_weights, args.ragged) == (4096, 20, 64, 2, False, None)
     if not default or not os.path.exists(path):
         return None
     try:
         with open(path) as f:
-            return json.load(f).get("bytes_per_launch", {}).get(kernel)
+            rec = json.load(f)
+        if not rec.get("lib_sha256") or rec["lib_sha256"] != lib_sha256():
+            return None
+        return rec.get("bytes_per_launch", {}).get(kernel)
     except Exception:
         return None
 
@@ -203,11 +219,19 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
         xr, er = x.reshape(b * N, -1), e.reshape(b * N, -1)
         return lambda: om.train_step(xr, er, graph, y), b, min_steps, warm
 
+    def sharded_leg(b, workers):
+        """C2 on all cores: `workers` processes x 1 BLAS thread, contiguous shards of whole graphs, gradients summed, one
+        Adam update (oracle/parallel.py) -- the formulation the GPU path uses across GPUs."""
+        from oracle.parallel import ShardedOracle
+        x, e, adj, y = synth_batch(np.random.default_rng(1001), b, N)
+        so = ShardedOracle(dict(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=share), x, e, adj, y, workers)
+        return so
+
     plan = [("C0", "reference formulation (dense kron adjacency), N=4 F=16 L=2 B=512", lambda: literal_leg(4, 16, 512, 20, 3)),
             ("C1", "reference formulation (dense kron adjacency), N=20 F=64 L=2 B=256", lambda: literal_leg(20, 64, 256, 3, 1)),
             ("C2", "compact CSR formulation, N=%d F=%d L=%d B=%d, %s weights" % (N, F, L, B, "shared" if share else "per-node"),
              lambda: compact_leg(B, 5, 1))]
-    legs, per_leg = {}, budget_s / 6.0
+    legs, per_leg = {}, budget_s / 7.0
     for name, what, make in plan:
         for label, nthr in (("all_cores", all_thr), ("one_thread", 1)):
             with limit(nthr):
@@ -218,13 +242,30 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
             legs["%s_%s" % (name, label)] = {"graphs_per_s": round(b / sec, 1), "ms_per_step": round(1e3 * sec, 2), "steps": n,
                                              "batch": b, "threads": int(nthr),
                                              "what": what if b == (B if name == "C2" else b) else what + " (timed on a %d-graph sample)" % b}
-    # the headline CPU number is the better of the two thread settings of C2 (on a 128-thread host the per-slot
-    # matrix products are too small for the BLAS thread pool: one thread wins); `cores` = the threads of that run
-    main_leg = max(legs["C2_all_cores"], legs["C2_one_thread"], key=lambda l: l["graphs_per_s"])
+    # C2 on all cores for real: the BLAS thread pool cannot use them (the per-slot products are too small: the
+    # "all_cores" figure above is SLOWER than one thread on a 128-thread host), worker processes over graph shards can
+    host_cores = len(os.sched_getaffinity(0))
+    workers = max(1, min(host_cores, B // 64))
+    try:
+        so = sharded_leg(B, workers)
+        try:
+            sec, n = _timed_steps(so.step, per_leg, 5, 50, 1)
+        finally:
+            so.close()
+        legs["C2_sharded_processes"] = {"graphs_per_s": round(B / sec, 1), "ms_per_step": round(1e3 * sec, 2), "steps": n, "batch": B,
+                                        "threads": int(workers),
+                                        "what": "compact CSR formulation, N=%d F=%d L=%d B=%d, %s weights: %d worker processes x 1 BLAS "
+                                                "thread over contiguous graph shards, gradients summed, one Adam update"
+                                                % (N, F, L, B, "shared" if share else "per-node", workers)}
+    except Exception as exc:                       # no /dev/shm, no spawn: keep the other legs
+        legs["C2_sharded_processes"] = {"graphs_per_s": 0.0, "error": "%s: %s" % (type(exc).__name__, exc), "threads": int(workers),
+                                        "steps": 0, "batch": B}
+    # the headline CPU number is the best C2 figure; `cores` = the threads / processes of that run
+    main_leg = max(legs["C2_sharded_processes"], legs["C2_all_cores"], legs["C2_one_thread"], key=lambda l: l["graphs_per_s"])
     return {"value": main_leg["graphs_per_s"], "unit": "graph-instances/s", "cores": int(main_leg["threads"]), "kind": "port",
-            "cpu_model": cpu_model(), "host_cores": len(os.sched_getaffinity(0)),
+            "cpu_model": cpu_model(), "host_cores": host_cores,
             "sample": "median of %d fit steps of B=%d (N=%d,F=%d,L=%d,%s weights) after 1 warm-up, numpy fp32 CSR oracle "
-                      "(leg C2, %d thread(s)); a CPU restatement of the reference math, not Keras/TF1"
+                      "(leg C2, %d core(s)); a CPU restatement of the reference math, not Keras/TF1"
                       % (main_leg["steps"], main_leg["batch"], N, F, L, "shared" if share else "per-node", main_leg["threads"]),
             "legs": legs}
 
@@ -317,12 +358,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="graphs per GPU (weak scaling) / in total (strong scaling)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak: --batch graphs per GPU (global batch grows with --gpus); strong: --batch graphs in total, "
-                         "cut into contiguous shards of whole graphs (SURVEY.md 8 d1: global batch fixed)")
+    ap.add_argument("--batch", type=int, default=4096, help="graphs in total (strong scaling, the default) / per GPU (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default; SURVEY.md 8 d1: the metric's GLOBAL batch is fixed): --batch graphs in total, cut into "
+                         "contiguous shards of whole graphs, one per GPU; weak: --batch graphs per GPU (global batch grows with --gpus)")
+    ap.add_argument("--shard-of", type=int, default=1, metavar="G",
+                    help="single-GPU rehearsal of a G-GPU strong-scaling run: time shard 0 of the global batch cut into G shards "
+                         "(Huber mean over the global batch, no all-reduce); value = this shard's graphs / s")
     ap.add_argument("--envs", type=int, default=0, help="cfg0 / cfg2loop: number of simulators stepped as arrays (0 = the single one)")
-    ap.add_argument("--min-seconds", type=float, default=0.25,
+    ap.add_argument("--no-edge-gather", action="store_true",
+                    help="skip the second timed pass with the general edge-index aggregation (V2X_FUSED_COMPL=0) that is printed "
+                         "beside the headline when the headline itself aggregates through the complement")
+    ap.add_argument("--min-seconds", type=float, default=2.5,
                     help="the timed region is extended to at least this long (more steps than --steps if needed)")
     ap.add_argument("--nodes", type=int, default=20)
     ap.add_argument("--feat", type=int, default=64)
@@ -345,6 +392,8 @@ def main():
         args.nodes, args.feat, args.layers, args.batch = 100, 256, 3, (8192 if strong else 1024)
     elif args.workload == "cfg5":         # BASELINE configs[4]: batch 16384 on 8 GPUs = 2048 per GPU
         args.ragged, args.feat, args.layers, args.batch, args.share_weights = [8, 128], 64, 2, (16384 if strong else 2048), True
+    if args.shard_of > 1 and (not strong or args.gpus > 1):
+        raise SystemExit("--shard-of rehearses ONE shard of a strong-scaling run on one GPU")
     ragged = args.ragged is not None
     if ragged and not args.share_weights:
         raise SystemExit("--ragged needs --share-weights")
@@ -401,8 +450,9 @@ def main():
         pb = PackedBatch.from_dense(x, e, adj)
     n_global = B if strong else B * world         # graphs per step over all ranks (the metric's unit)
     n_rows_global = pb.n_rows
-    if strong and world > 1:
-        pb, (r0, r1) = pb.shard(rank, world, with_rows=True)
+    n_shards = args.shard_of if args.shard_of > 1 else world
+    if strong and n_shards > 1:
+        pb, (r0, r1) = pb.shard(rank, n_shards, with_rows=True)
         y = y[r0:r1]
         if ragged:
             sizes = np.diff(pb.graph_off)
@@ -462,7 +512,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / steps
-    value = n_global * steps / elapsed
+    n_counted = B_local if args.shard_of > 1 else n_global          # --shard-of: only this shard's graphs were processed
+    value = n_counted * steps / elapsed
+
+    # The kernels a step of this batch runs.  When the fused graph layers aggregate through the complement (the reference
+    # topology is complete-minus-two), the general edge-index gather / segment sum -- the form north_star names -- is timed
+    # too and printed beside the headline.
+    path = eng.path_info(db)
+    edge_gather = None
+    if (rank == 0 and world == 1 and path.get("aggregation") == "complement" and not args.no_edge_gather
+            and os.environ.get("V2X_FUSED_COMPL") is None):
+        os.environ["V2X_FUSED_COMPL"] = "0"
+        try:
+            eng2 = GnnEngine(spec, device=local, use_graph=not args.no_graph)
+        finally:
+            del os.environ["V2X_FUSED_COMPL"]
+        eng2.copy_weights_from(eng)
+        with torch.cuda.stream(stream):
+            for _ in range(max(args.warmup, 5)):
+                eng2.train_step(db, yd, n_global=n_denom, want_loss=False)
+            torch.cuda.synchronize()
+            n2 = max(50, min(steps, 400))
+            t2 = time.perf_counter()
+            for _ in range(n2):
+                eng2.train_step(db, yd, n_global=n_denom, want_loss=False)
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t2
+        edge_gather = {"aggregation": eng2.path_info(db).get("aggregation"), "value": round(n_counted * n2 / e2, 1),
+                       "ms_per_step": round(1e3 * e2 / n2, 4), "steps": n2}
+        eng2.close()
 
     # sanity: the timed steps really trained (finite loss, weights moved)
     loss = eng.forward_backward(db, yd, n_global=n_denom)
@@ -520,12 +598,18 @@ def main():
 
     if rank == 0:
         links = "%d-%d" % tuple(args.ragged) if ragged else str(N)
+        # BASELINE.json's metric string names ITS configuration -- the GLOBAL batch is 4096 whatever the number of GPUs
+        # (SURVEY.md 8 d1); anything else (weak scaling on several GPUs, one shard of a run, other sizes) gets its own label
         headline = (args.workload == "cfg2" and (N, F, L, ragged, args.share_weights) == (20, 64, 2, False, False)
-                    and (B if strong else B) == 4096)
-        # BASELINE.json's metric string names ITS configuration; any other workload gets a label of its own
-        metric = ("graph-instances/sec (fwd+bwd), 20-V2V-link graphs, batch 4096" if headline else
-                  "graph-instances/sec (fwd+bwd), %s-V2V-link graphs, feat_dim %d, %d layers, batch %d%s"
-                  % (links, F, L, B, "" if strong else " per GPU"))
+                    and n_global == 4096 and args.shard_of == 1)
+        if headline:
+            metric = "graph-instances/sec (fwd+bwd), 20-V2V-link graphs, batch 4096"
+        elif args.shard_of > 1:
+            metric = ("graph-instances/sec (fwd+bwd) of ONE shard (%d graphs) of a %d-GPU run at global batch %d, %s-V2V-link graphs, "
+                      "feat_dim %d, %d layers, no all-reduce" % (B_local, args.shard_of, B, links, F, L))
+        else:
+            metric = ("graph-instances/sec (fwd+bwd), %s-V2V-link graphs, feat_dim %d, %d layers, global batch %d (%s scaling, %d per GPU)"
+                      % (links, F, L, n_global, args.scaling, B_local))
         out = {"metric": metric,
                "value": round(value, 1), "unit": "graph-instances/s", "n_gpus": world, "steps": steps,
                "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -534,11 +618,14 @@ def main():
                "config": {"workload": "BASELINE.json configs[%d]: %s V2V links, feat_dim=%d, %d-layer GNN, %s, "
                                       "fit step = fwd+Huber+bwd+Adam%s"
                                       % ({"cfg2": 1, "cfg4": 3, "cfg5": 4}[args.workload], links, F, L,
-                                         ("global batch %d synthetic graphs cut into %d shard(s)" % (B, world)) if strong else
+                                         ("global batch %d synthetic graphs cut into %d shard(s)%s"
+                                          % (B, n_shards, ", shard 0 timed on one GPU" if args.shard_of > 1 else "")) if strong else
                                          ("batch %d synthetic graphs per GPU" % B),
                                          "+RCCL grad all-reduce" if world > 1 else ""),
                           "weights": "shared" if args.share_weights else "per-node (reference semantics)",
                           "global_batch": n_global, "graphs_per_gpu": B_local, "scaling": args.scaling, "n_params": eng.n_params,
+                          "aggregation": path.get("aggregation"), "kernel_path": path, "edge_gather": edge_gather,
+                          "lib_sha256": lib_sha256(),
                           "launch": "eager" if args.no_graph else "hipGraph replay",
                           "parallelism": "dp%d" % world},
                "roofline": roofline, "cpu_baseline": cpu}

@@ -94,7 +94,8 @@ struct v2x_model {
   // hipGraph cache
   // a captured step + the per-layer slab counts its weight-gradient launches write (host state that the launches
   // OUTSIDE the graph -- the Adam / slab-sum kernel of train_step -- depend on)
-  struct GraphEntry { hipGraphExec_t exec; std::vector<int> n_slabs; };
+  struct GraphEntry { hipGraphExec_t exec; std::vector<int> n_slabs; bool frag_live; };
+  int64_t ws_gen = 0;           // bumped whenever a workspace buffer is re-allocated (keys of graphs that bake in ANOTHER model's workspace)
   std::map<GraphKey, GraphEntry> graphs;
   bool capturing = false;
 };
@@ -126,6 +127,7 @@ namespace {
 void drop_graphs(v2x_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second.exec);
   m->graphs.clear();
+  m->ws_gen += 1;               // every caller is about to re-allocate (or has invalidated) something captured graphs point at
 }
 
 int ensure(v2x_model* m, DevBuf& b, size_t bytes) {
@@ -1440,6 +1442,7 @@ int run_maybe_graph(v2x_model* m, hipStream_t st, const GraphKey& key, Body body
     size_t i = 0;                                   // what the captured host code had left in the layer descriptors
     for (auto* v : {&m->gnn, &m->dense})
       for (LayerDesc& ld : *v) ld.n_slabs = it->second.n_slabs[i++];
+    m->frag_live = it->second.frag_live;            // ... and in the model (layout of the saved h_L / a_L / gha)
     HIPCHK(m, hipGraphLaunch(it->second.exec, st));
     return V2X_OK;
   }
@@ -1460,6 +1463,7 @@ int run_maybe_graph(v2x_model* m, hipStream_t st, const GraphKey& key, Body body
   if (m->graphs.size() >= 16) drop_graphs(m);
   v2x_model::GraphEntry entry;
   entry.exec = ge;
+  entry.frag_live = m->frag_live;
   for (auto* v : {&m->gnn, &m->dense})
     for (const LayerDesc& ld : *v) entry.n_slabs.push_back(ld.n_slabs);
   m->graphs[key] = entry;
@@ -1634,7 +1638,12 @@ void v2x_destroy(v2x_model* m) {
 
 int64_t v2x_param_count(const v2x_model* m) { return m ? m->P : 0; }
 float* v2x_param_ptr(v2x_model* m) {
-  if (m) m->pk_stale = m->raw_params = true;   // the caller may write the parameters behind the library's back from now on
+  if (m) {
+    // the caller may write the parameters behind the library's back from now on: every fused forward re-packs its
+    // fragment-major copy first -- a launch that graphs captured BEFORE this call do not contain, so they are dropped
+    if (!m->raw_params) drop_graphs(m);
+    m->pk_stale = m->raw_params = true;
+  }
   return m ? m->params : nullptr;
 }
 float* v2x_grad_ptr(v2x_model* m) { return m ? m->grads : nullptr; }
@@ -1862,7 +1871,8 @@ int v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, const
   GraphKey key = make_key(4, ds, y, n_graphs_global);
   key.ptrs[6] = dn.xe; key.ptrs[7] = dn.rp; key.ptrs[8] = dn.ci; key.ptrs[9] = action; key.ptrs[10] = reward;
   key.ptrs[11] = target->q;
-  key.scalar = gamma;
+  key.sizes[3] = (int)(target->ws_gen & 0x7fffffff);     // fixed-size graphs: max_nodes == N, the slot is free.  The graph bakes
+  key.scalar = gamma;                                    // in EVERY workspace pointer of the target (h, a, z, masks, ...), not q only
   CHK(run_maybe_graph(online, st, key, [&]() -> int {
     target->capturing = online->capturing;
     int rc = run_forward(target, st, dn, all, true);
@@ -2056,6 +2066,21 @@ int v2x_check_errors(v2x_model* m, void* stream) {
 }
 
 // ---------------------------------------------------------------------------- measurement
+int v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap) {
+  if (!m || !b || !out || cap < 16) FAIL(m, V2X_EINVAL, "path_info: bad argument");
+  DevBatch d;
+  memset(&d, 0, sizeof(d));
+  d.B = b->n_graphs; d.R = b->n_rows; d.E = b->n_edges; d.max_nodes = b->max_nodes; d.max_edges = b->max_edges;
+  d.goff = b->graph_off; d.nbr = b->nbr_init;
+  const bool fused = fused_path(m, d);
+  const char* agg = fused ? (fused_compl(m, d) ? "complement" : "edge-gather")
+                          : (use_dense_agg(d, m->F) ? "dense-mfma" : "edge-gather");
+  snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s", fused ? "fused" : "layerwise", agg,
+           mlp_wg_path(m) ? "train_wg" : (mlp_fused_training(m) ? "train" : "fwd+bwd"),
+           frag_layout(m, d, Range{0, d.B}) ? "fragment-major" : "row-major");
+  return V2X_OK;
+}
+
 int v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n) {
   if (!m || !out) FAIL(m, V2X_EINVAL, "null argument");
   if (!m->ts_buf) FAIL(m, V2X_ESTATE, "phase stamps need V2X_FUSED_TS=1 when the model is created");

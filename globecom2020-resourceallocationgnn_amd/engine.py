@@ -248,6 +248,14 @@ class GnnEngine(object):
         self._check(self._lib.v2x_apply_gradients(self._h, self._stream()))
 
     # ------------------------------------------------------------------ measurement
+    def path_info(self, batch):
+        """{'graph_layers': 'fused', 'aggregation': 'complement' | 'edge-gather' | 'dense-mfma', ...}: the kernels a fit step
+        of this batch runs (v2x_path_info)."""
+        buf = C.create_string_buffer(256)
+        s = _batch_struct(batch)
+        self._check(self._lib.v2x_path_info(self._h, C.byref(s), buf, 256))
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split())
+
     def profile(self, enable):
         self._check(self._lib.v2x_profile_enable(self._h, 1 if enable else 0))
 

@@ -209,6 +209,12 @@ int  v2x_check_errors(v2x_model* m, void* stream);
 /* When enabled, every kernel launch of this model is bracketed by HIP events on its stream
  * (eager, no graph); v2x_profile_read returns per-kernel-name call counts and total ms.    */
 int  v2x_profile_enable(v2x_model* m, int enable);
+/* Which kernels a fit step of `b` runs on this model, as text ("graph_layers=fused aggregation=complement mlp=train_wg
+ * handoff=fragment-major"): the aggregation is the general edge-index gather / segment sum of AggLayer.call
+ * (BS_brain.py:69-76) unless the batch is dense enough for one of its rewritings -- through the complement in the fused
+ * graph-layer kernels ("complement"), as an MFMA product with adjacency bit masks for large graphs ("dense-mfma").
+ * Only sizes and null-ness of the batch pointers are read.  bench.py prints it in `config.aggregation`.              */
+int  v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap);
 /* Models created with V2X_FUSED_TS=1 in the environment run a measurement build of the fused forward kernel in which
  * workgroup 7 writes 100 MHz time stamps at its phase boundaries: out[wave * 64 + mark], n <= 512 entries.            */
 int  v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n);

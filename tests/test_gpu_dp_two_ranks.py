@@ -123,12 +123,17 @@ def test_two_rank_dqn_loop_with_device_replay_on_the_engine():
         assert np.allclose(w, w1, rtol=1e-3, atol=2e-5)
 
 
-@pytest.mark.parametrize("scaling,batch,global_batch,per_gpu", [("weak", 512, 1024, 512), ("strong", 512, 512, 256)])
+BASELINE_METRIC = "graph-instances/sec (fwd+bwd), 20-V2V-link graphs, batch 4096"
+
+
+@pytest.mark.parametrize("scaling,batch,global_batch,per_gpu", [("weak", 512, 1024, 512), ("strong", 512, 512, 256),
+                                                                  (None, 4096, 4096, 2048), ("weak", 4096, 8192, 4096)])
 def test_bench_two_ranks_on_one_gpu(scaling, batch, global_batch, per_gpu):
     """bench.py launched exactly as the driver launches it for N = 2 (torch.distributed.run, one rank per process:
     barrier, max-over-ranks timing, whole-job value, rank-0 JSON line); the box has one GPU, so both ranks use cuda:0
     and the collective is gloo (V2X_BENCH_ONE_DEVICE / V2X_BENCH_BACKEND exist for this test only).  weak: --batch graphs
-    per GPU; strong: the global batch cut into two shards."""
+    per GPU; strong (the DEFAULT, which is what the driver's `bench.py --gpus N` gets): the global batch cut
+    into two shards.  BASELINE.json's metric string appears only when the GLOBAL batch is 4096 -- not for 4096 per GPU."""
     import json
     import subprocess
     import sys
@@ -136,7 +141,7 @@ def test_bench_two_ranks_on_one_gpu(scaling, batch, global_batch, per_gpu):
     env = dict(os.environ, V2X_BENCH_ONE_DEVICE="1", V2X_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29551", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--min-seconds", "0",
-           "--batch", str(batch), "--scaling", scaling, "--no-cpu-baseline", "--no-roofline"]
+           "--batch", str(batch), "--no-cpu-baseline", "--no-roofline"] + (["--scaling", scaling] if scaling else [])
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -144,5 +149,7 @@ def test_bench_two_ranks_on_one_gpu(scaling, batch, global_batch, per_gpu):
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == global_batch and res["config"]["parallelism"] == "dp2"
     assert res["config"]["graphs_per_gpu"] == per_gpu
-    assert res["value"] > 0 and res["scaling"] == scaling and res["steps"] == 5
+    assert res["value"] > 0 and res["scaling"] == (scaling or "strong") == res["config"]["scaling"] and res["steps"] == 5
+    assert (res["metric"] == BASELINE_METRIC) == (global_batch == 4096)
+    assert res["config"]["aggregation"] in ("complement", "edge-gather")
     assert abs(res["value"] - global_batch * 5 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-3

@@ -273,3 +273,26 @@ def test_rounding_distance_relu_gates_are_identified_and_nothing_else_is_excused
     c3['h'][1][r_nc, f_nc] = 0.0                                                        # a healthy unit's gate closed
     with pytest.raises(AssertionError):
         assert_grads_match_oracle([noise(a) for a in oc.params_to_list(oc.backward(spec, P, c3, dq))], P, step, "non-candidate gate")
+
+
+def test_sharded_oracle_step_equals_the_single_process_step():
+    """oracle/parallel.py (bench.py's all-cores CPU leg): 2 worker processes over graph shards, gradients summed, one Adam
+    update == OracleModel.train_step on the whole batch (up to the summation order of the gradient)."""
+    from oracle.parallel import ShardedOracle
+    import bench
+    N, F, B = 5, 16, 24
+    kw = dict(n_nodes=N, feat_dim=F, n_mp_layers=2, share_weights=False)
+    x, e, adj, y = bench.synth_batch(np.random.default_rng(3), B, N)
+    spec = OSpec(**kw)
+    om = oc.OracleModel(spec, oc.init_params(spec, np.random.default_rng(1001), np.float32), dtype=np.float32)
+    _, g_ref, _ = om.loss_and_grads(x.reshape(B * N, -1), e.reshape(B * N, -1), oc.adj_to_csr(adj), y)
+    so = ShardedOracle(kw, x, e, adj, y, workers=2, seed=1001)
+    try:
+        assert np.array_equal(so.flat, np.concatenate([a.ravel() for a in oc.param_arrays(om.params)]))
+        so.step()
+        g = so.slabs.sum(axis=0)
+        ref = np.concatenate([a.ravel() for a in oc.param_arrays(g_ref)])
+        assert np.allclose(g, ref, rtol=1e-4, atol=1e-6 * np.abs(ref).max())
+        assert so.opt.iterations == 1
+    finally:
+        so.close()

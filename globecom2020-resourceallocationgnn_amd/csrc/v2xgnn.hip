@@ -78,8 +78,8 @@ struct v2x_model {
   bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
   bool compl_sums = true;                       // V2X_FUSED_COMPL (read at create): dense graphs aggregate through the complement
   bool small_predict = true;                    // V2X_SMALL_PREDICT (read at create): few-graph forwards in one launch (kernels_small.hpp)
-  float* small_h = nullptr;                     // its exchange buffer [2][SMALL_ROWS][F]
-  unsigned* small_sync = nullptr;               // and per-graph barrier counters [SMALL_ROWS][2]
+  unsigned long long* small_h = nullptr;        // its exchange buffer [L + 1][SMALL_ROWS][F] tagged words
+  unsigned* small_sync = nullptr;               // and per-graph departure counters [SMALL_ROWS][2]
   char* pin_h = nullptr; char* pin_d = nullptr;  // pinned, device-mapped window for host-resident few-graph predicts: the
                                                 // kernel reads the batch and writes q THROUGH it (no copy launches)
   float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
@@ -1295,12 +1295,12 @@ int launch_small_forward(v2x_model* m, hipStream_t st, const DevBatch& d, float*
   for (int s = 0; s <= m->L; ++s) { a.gnn_off[s] = m->gnn[s].off; a.gnn_sstride[s] = m->gnn[s].slot_stride; }
   for (int i = 0; i < 4; ++i) { a.dense_off[i] = m->dense[i].off; a.dense_sstride[i] = m->dense[i].slot_stride; }
   a.hbuf = m->small_h; a.sync = m->small_sync; a.q = q_dst ? q_dst : m->q;
-  a.N = m->N; a.L = m->L; a.S = m->S; a.C = m->C; a.Dn = m->Dn; a.De = m->De; a.n_rows = d.R;
+  a.N = m->N; a.L = m->L; a.S = m->S; a.C = m->C; a.Dn = m->Dn; a.De = m->De; a.n_rows = d.R; a.slab_rows = SMALL_ROWS;
   const dim3 grid(m->N, d.B);
 #define V2X_SMALL(FF)                                                                                   \
   if (m->F == FF) {                                                                                     \
     auto k = k_predict_small<FF>;                                                                       \
-    LAUNCH(m, "k_predict_small", k, grid, 0, st, a);                                                    \
+    LAUNCH_T(m, "k_predict_small", k, grid, SM_BLOCK, 0, st, a);                                        \
     return V2X_OK;                                                                                      \
   }
   V2X_SMALL(16) V2X_SMALL(32) V2X_SMALL(64)
@@ -1569,10 +1569,11 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   m->compl_sums = env_int("V2X_FUSED_COMPL", 1) != 0;
   m->small_predict = env_int("V2X_SMALL_PREDICT", 1) != 0;
   if (m->small_predict && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
-    const size_t hb = (size_t)2 * SMALL_ROWS * m->F * sizeof(float), sb = (size_t)2 * SMALL_ROWS * sizeof(unsigned);
+    const size_t hb = (size_t)(m->L + 1) * SMALL_ROWS * m->F * sizeof(unsigned long long), sb = (size_t)2 * SMALL_ROWS * sizeof(unsigned);
     void *ph = nullptr, *ps = nullptr;
     if (hipMalloc(&ph, hb) != hipSuccess || hipMalloc(&ps, sb) != hipSuccess) return fail("allocation");
-    m->small_h = static_cast<float*>(ph);
+    m->small_h = static_cast<unsigned long long*>(ph);
+    if (hipMemset(ph, 0, hb)) return fail("memset");             // tag 0 = never written
     m->small_sync = static_cast<unsigned*>(ps);
     void *hh = nullptr, *hdv = nullptr;
     if (env_int("V2X_SMALL_PINNED", 1) != 0 && hipHostMalloc(&hh, PIN_BYTES, hipHostMallocMapped) == hipSuccess &&

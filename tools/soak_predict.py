@@ -1,5 +1,6 @@
-"""Soak of the one-launch predict (grid barriers between the layers): 30,000 forwards of 1..12 graphs interleaved with fit
-steps and weight copies on two models sharing the GPU; the barrier counters must come back to zero every time."""
+"""Soak of the one-launch predict (tagged-word exchange between the layers): 30,000 forwards of 1..12 graphs interleaved with
+fit steps and weight copies on two models sharing the GPU.  Between two weight changes every repeat of a forward must
+return the SAME BITS as the first one (fixed summation order): a stale row from an earlier launch or stage would show."""
 import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,14 +19,21 @@ xt, et, at = random_inputs(rng, 256, 20, ref_topology=True)
 train = a.to_device(PackedBatch.from_dense(xt, et, at))
 yt = torch.from_numpy(rng.normal(2.5, 1.0, size=(256 * 20, 4)).astype(np.float32)).cuda()
 t0 = time.perf_counter()
-ref = {B: None for B in batches}
+ref = {}
 for it in range(30000):
     B = 1 + it % 12
     eng = a if it % 3 else b
     q = eng.forward(batches[B])
     assert np.all(np.isfinite(q))
+    key = (id(eng), B)
+    if key in ref:
+        assert np.array_equal(q, ref[key]), ("predict changed without a weight change", it, B)
+    else:
+        ref[key] = q.copy()
     if it % 50 == 0:
         a.train_step(train, yt, want_loss=False)
+        ref = {k: v for k, v in ref.items() if k[0] != id(a)}
     if it % 500 == 0:
         b.copy_weights_from(a) if hasattr(b, "copy_weights_from") else b.set_weights(a.get_weights())
+        ref = {k: v for k, v in ref.items() if k[0] != id(b)}
 print("30000 predicts + 600 fit steps in %.1f s: %.1f us per predict on average" % (time.perf_counter() - t0, (time.perf_counter() - t0) / 30000 * 1e6))

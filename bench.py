@@ -117,6 +117,16 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     table["k_gnn_bwd_fused"] = 4 * R * 2 * F + L * R * F // 8 + csr + (L + 1) * 4 * R * F
     table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"] - 4 * R * C  # fwd + Huber + bwd fused: q is not re-read
     table["k_mlp_train_wg"] = table["k_mlp_train"]    # weight gradients from the values on chip: no further node-row bytes
+    table["k_adj_masks"] = csr + 2 * 4 * R * ((max(N, 1) + 31) // 32)          # CSR in, bit masks by source and by destination out
+    if F >= 128:        # wide-feature path (csrc/kernels_wide.hpp): Dense-0 and its gradients are launches of their own,
+        #                 Dense 1..3 stay register-chained ("tail" kernels), one weight-gradient launch per graph layer
+        table["k_dense0_fwd"] = 4 * R * (Dn + 2 * F) + 4 * R * 80
+        table["k_dense0_dgrad"] = 4 * R * 80 + 4 * R * 2 * F
+        table["k_wgrad_dense0"] = 4 * R * (Dn + 2 * F + 80)
+        table["k_mlp_fwd"] = 4 * R * 80 + 4 * R * (40 + 20 + C)
+        table["k_mlp_bwd"] = 4 * R * (80 + 40 + 20 + 2 * C) + 4 * R * (80 + 40 + 20 + C)
+        table["k_wgrad_dense"] = 4 * R * (80 + 40) + 4 * R * (40 + 20) + 4 * R * (20 + C)
+        table["k_wgrad_gnn"] = wg_gnn
     return table.get(name)
 
 
@@ -567,7 +577,7 @@ def main():
         # dominant kernel = most time per step among the modelled kernels; its roofline is the resource whose floor
         # (algorithmic bytes / 8 TB/s vs algorithmic flops / 157.3 TF) is the LARGER one
         def floors(k):
-            by = algorithmic_bytes(k, Bq, Nq, F, E, L) if F < 128 else None
+            by = algorithmic_bytes(k, Bq, Nq, F, E, L)
             fl = algorithmic_flops(k, n_rows_local, F, L)
             return by, fl
         modelled = [k for k in prof if any(v is not None for v in floors(k))]

@@ -299,6 +299,17 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
 //   B[k = p][j = q]       = Adj[p][q]    (bit q of mask[p];   transposed:  B[k = q][j = p] = bit q of mask[p])
 //   D[i][j]: lane holds out[row j][4 consecutive features] -> float4 epilogue (+add, ReLU' gate) and store.
 // 0/1 times h is exact, so the only difference to the gather form is the fp32 summation order.
+//
+// Round 3 -- per graph, through the complement when that is cheaper.  The reference's interference graph is complete
+// minus two (link q hears every link but itself and its own receiver's), so the N x N x F
+// product is spent adding 98 rows where  out[q] = S - sum_{p : Adj[p][q] = 0} h[p],  S = the column sum of the graph's
+// rows, needs two.  A workgroup knows its graph's edge count from row_ptr: with at most AD_COMPL_PER_ROW non-edges per
+// row on average it sums the columns once (fixed order), then walks the ZERO bits of each output row's mask (ascending)
+// -- LDS reads of ~4 N rows instead of N^2 / 4 MFMAs, which leaves the launch to its HBM traffic; any other graph takes
+// the MFMA product as before.  Exact for every adjacency; differs from the other forms by fp32 rounding only.  The
+// forward needs the masks by DESTINATION (bit p of adjT[q]), the transpose by source (bit q of adj[p]): k_adj_masks
+// writes both.
+constexpr int AD_COMPL_PER_ROW = 8;
 struct AggDenseArgs {
   const float* src; int src_stride;
   const float* add; int add_stride;
@@ -306,6 +317,7 @@ struct AggDenseArgs {
   float* out;
   const int32_t* graph_off; const int32_t* row_ptr; const int32_t* col_idx;
   unsigned* adj;                        // [R][mask_words]: bit q of adj[p] = edge p -> q (graph-local q), built by k_adj_masks
+  unsigned* adjT;                       // [R][mask_words]: bit p of adjT[q] = edge p -> q (same edges, by destination)
   int g_base, n_graphs, n_nodes, F;
   int n_fg;                             // 64-wide feature groups per graph (one workgroup each)
   int rows_cap, mask_words;             // rows_cap: max nodes rounded up to 16
@@ -317,7 +329,8 @@ struct AggDenseArgs {
 // of 4 bytes per edge.
 __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned* sM = reinterpret_cast<unsigned*>(smem);                         // [rows_cap][mask_words]
+  unsigned* sM = reinterpret_cast<unsigned*>(smem);                         // [rows_cap][mask_words] by source
+  unsigned* sD = sM + a.rows_cap * a.mask_words;                            // [rows_cap][mask_words] by destination
   const int tid = threadIdx.x;
   const int g = a.g_base + blockIdx.x;
   const int r_begin = a.graph_off ? a.graph_off[g] : g * a.n_nodes;
@@ -340,7 +353,25 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
     }
   }
   __syncthreads();
-  for (int i = tid; i < n * a.mask_words; i += 256) a.adj[(int64_t)r_begin * a.mask_words + i] = sM[i];
+  // by destination = the transpose of the bit matrix: lane p reads bit q of row p, a wave ballot is 64 bits of row q
+  {
+    const int lane = tid & 63, wv = tid >> 6, n_blk = (n + 63) >> 6;
+    for (int q = wv; q < n; q += 4)
+      for (int blk = 0; blk < n_blk; ++blk) {
+        const int pp = 64 * blk + lane;
+        const bool bit = pp < n && ((sM[pp * a.mask_words + (q >> 5)] >> (q & 31)) & 1u);
+        const unsigned long long bal = __ballot(bit);
+        if (lane == 0) {
+          sD[q * a.mask_words + 2 * blk] = (unsigned)bal;
+          if (2 * blk + 1 < a.mask_words) sD[q * a.mask_words + 2 * blk + 1] = (unsigned)(bal >> 32);
+        }
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < n * a.mask_words; i += 256) {
+    a.adj[(int64_t)r_begin * a.mask_words + i] = sM[i];
+    a.adjT[(int64_t)r_begin * a.mask_words + i] = sD[i];
+  }
 }
 
 constexpr int AD_LDT = 64 + 16;         // LDS row stride of the feature tile: the 4 k-groups of a wave hit disjoint banks
@@ -361,23 +392,66 @@ __global__ __launch_bounds__(256) void k_agg_dense(AggDenseArgs a) {
   const int n = (a.graph_off ? a.graph_off[g + 1] : r_begin + a.n_nodes) - r_begin;
   if (n > a.rows_cap || n < 1) { if (tid == 0 && a.err) atomicOr(a.err, 1); return; }
 
-  // stage the graph's [n][64] feature slice (4 loads in flight per thread) and its adjacency bit masks
+  // the graph's non-edges decide the form (uniform over the workgroup; the feature groups of a graph agree)
+  const int n_edges = a.row_ptr[r_begin + n] - a.row_ptr[r_begin];
+  const bool compl_form = n * n - n_edges <= AD_COMPL_PER_ROW * n;
+  // stage the graph's [n][64] feature slice (4 loads in flight per thread) and its adjacency bit masks: by source for the
+  // MFMA product and for the transposed complement walk, by destination for the forward complement walk
   const int n_mw = n * a.mask_words;
-  for (int i = tid; i < a.rows_cap * a.mask_words; i += 256) sM[i] = i < n_mw ? a.adj[(int64_t)r_begin * a.mask_words + i] : 0u;
-  for (int i0 = 0; i0 < n * 16; i0 += 1024) {
-    float4 v[4];
+  const unsigned* msrc = (compl_form && !TRANSPOSE) ? a.adjT : a.adj;
+  for (int i = tid; i < a.rows_cap * a.mask_words; i += 256) sM[i] = i < n_mw ? msrc[(int64_t)r_begin * a.mask_words + i] : 0u;
+  for (int i0 = 0; i0 < n * 16; i0 += 2048) {                              // 8 loads in flight per thread: 128 rows per pass
+    float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int i = min(i0 + u * 256 + tid, n * 16 - 1);
       v[u] = *reinterpret_cast<const float4*>(a.src + (int64_t)(r_begin + (i >> 4)) * a.src_stride + f0 + ((i & 15) << 2));
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * 256 + tid;
       if (i < n * 16) *reinterpret_cast<float4*>(sT + (i >> 4) * AD_LDT + ((i & 15) << 2)) = v[u];
     }
   }
   __syncthreads();
+
+  if (compl_form) {
+    // out[r] = S - sum over the zero bits p < n of row r's mask of tile[p]   (forward: r = destination, mask by
+    // destination; transpose: r = source, mask by source -- the same walk)
+    float* sP = reinterpret_cast<float*>(sM + a.rows_cap * a.mask_words);   // [16 row groups][64] partial column sums, then S at [0]
+    const int c = tid & 15, rg = tid >> 4;                                  // float4 column, row group
+    {
+      f32x4 ps = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int r = rg; r < n; r += 16) ps += *reinterpret_cast<const f32x4*>(sT + r * AD_LDT + 4 * c);
+      *reinterpret_cast<f32x4*>(sP + rg * 64 + 4 * c) = ps;
+    }
+    __syncthreads();
+    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 16; ++u) S += *reinterpret_cast<const f32x4*>(sP + u * 64 + 4 * c);     // fixed order, every thread the same
+    for (int r0 = 0; r0 < n; r0 += 16) {
+      const int r = r0 + rg;
+      if (r >= n) break;
+      const int64_t grow = r_begin + r;
+      const f32x4 addv = a.add ? ld4(a.add + grow * a.add_stride + f0 + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 gate = a.mask ? ld4(a.mask + grow * a.F + f0 + 4 * c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      f32x4 miss = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int w = 0; w < a.mask_words; ++w) {
+        const int left = n - 32 * w;                                        // valid bits of this word
+        if (left <= 0) break;
+        unsigned z = ~sM[r * a.mask_words + w] & (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
+        while (z) {
+          const int p = 32 * w + __builtin_ctz(z);
+          z &= z - 1;
+          miss += *reinterpret_cast<const f32x4*>(sT + p * AD_LDT + 4 * c);
+        }
+      }
+      f32x4 v = (S - miss) + addv;
+      v = gate4(v, gate);
+      st4(a.out + grow * a.F + f0 + 4 * c, v);
+    }
+    return;
+  }
 
   const int n_rt = (n + 15) >> 4;
   const int n_k4 = (n + 15) >> 4;                                           // groups of 4 k-steps (16 contraction rows)

@@ -475,7 +475,7 @@ bool use_dense_agg(const DevBatch& d, int F) {
   static const int dense_min_nodes = env_int("V2X_AGG_DENSE_MIN_NODES", 32);
   const size_t rows_cap = (d.max_nodes + 15) / 16 * 16, mw = (d.max_nodes + 31) / 32;
   return F >= 64 && d.max_nodes >= dense_min_nodes && (int64_t)d.max_edges * 4 >= (int64_t)d.max_nodes * d.max_nodes &&
-         rows_cap * AD_LDT * 4 + rows_cap * mw * 4 <= 160 * 1024;
+         rows_cap * AD_LDT * 4 + rows_cap * mw * 4 + 16 * 64 * 4 <= 160 * 1024;
 }
 
 AggDenseArgs agg_dense_args(const DevBatch& d, Range r, int N, int F) {
@@ -489,7 +489,7 @@ AggDenseArgs agg_dense_args(const DevBatch& d, Range r, int N, int F) {
 }
 
 int build_adj_masks(v2x_model* m, hipStream_t st, const AggDenseArgs& q) {
-  const size_t lds = (size_t)q.rows_cap * q.mask_words * 4;
+  const size_t lds = (size_t)2 * q.rows_cap * q.mask_words * 4 + (size_t)(q.rows_cap + 1) * 4;   // by source + by destination + row_ptr slice
   LAUNCH(m, "k_adj_masks", k_adj_masks, dim3(q.n_graphs), lds, st, q);
   return V2X_OK;
 }
@@ -511,9 +511,10 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, 
     q.err = flag_dev_of(m);
     if (m) {
       q.adj = (unsigned*)m->adj_mask.p;                 // built by run_forward for this batch
+      q.adjT = q.adj + (size_t)d.R * q.mask_words;
     } else {                                            // handle-less entry point: build into a scratch buffer
       static thread_local DevBuf scratch;
-      const size_t need = (size_t)d.R * q.mask_words * 4;
+      const size_t need = (size_t)2 * d.R * q.mask_words * 4;
       if (need > scratch.cap) {
         if (scratch.p) hipFree(scratch.p);
         scratch.p = nullptr; scratch.cap = 0;
@@ -521,9 +522,10 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, 
         scratch.cap = need;
       }
       q.adj = (unsigned*)scratch.p;
+      q.adjT = q.adj + (size_t)d.R * q.mask_words;
       CHK(build_adj_masks(m, st, q));
     }
-    const size_t lds = (size_t)q.rows_cap * AD_LDT * 4 + (size_t)q.rows_cap * q.mask_words * 4;
+    const size_t lds = (size_t)q.rows_cap * AD_LDT * 4 + (size_t)q.rows_cap * q.mask_words * 4 + 16 * 64 * 4;   // + partial column sums
     const dim3 grid((r.ng + 7) / 8 * 8 * q.n_fg);
     if (transpose) { auto k = k_agg_dense<true>; LAUNCH(m, "k_agg_bwd", k, grid, lds, st, q); }
     else { auto k = k_agg_dense<false>; LAUNCH(m, "k_agg_fwd", k, grid, lds, st, q); }
@@ -1318,6 +1320,7 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
     if (use_dense_agg(d, F)) {
       AggDenseArgs q = agg_dense_args(d, r, m->N, F);
       q.adj = (unsigned*)m->adj_mask.p;
+      q.adjT = q.adj + (size_t)d.R * q.mask_words;
       q.err = m->flag_dev;
       CHK(build_adj_masks(m, st, q));
     }
@@ -1493,7 +1496,7 @@ int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
 
 int presize(v2x_model* m, const DevBatch& d) {
   CHK(ensure_rows(m, d.R));
-  if (use_dense_agg(d, m->F)) CHK(ensure(m, m->adj_mask, (size_t)d.R * ((d.max_nodes + 31) / 32) * 4));
+  if (use_dense_agg(d, m->F)) CHK(ensure(m, m->adj_mask, (size_t)2 * d.R * ((d.max_nodes + 31) / 32) * 4));
   const IdxMap x = idx_map(m, d, Range{0, d.B});
   CHK(ensure_slabs(m, max_slabs(m, x.n_idx, x.grid_y)));
   return V2X_OK;
@@ -2075,7 +2078,7 @@ int v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap) {
   d.goff = b->graph_off; d.nbr = b->nbr_init;
   const bool fused = fused_path(m, d);
   const char* agg = fused ? (fused_compl(m, d) ? "complement" : "edge-gather")
-                          : (use_dense_agg(d, m->F) ? "dense-mfma" : "edge-gather");
+                          : (use_dense_agg(d, m->F) ? "dense(complement-or-mfma-per-graph)" : "edge-gather");
   snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s", fused ? "fused" : "layerwise", agg,
            mlp_wg_path(m) ? "train_wg" : (mlp_fused_training(m) ? "train" : "fwd+bwd"),
            frag_layout(m, d, Range{0, d.B}) ? "fragment-major" : "row-major");

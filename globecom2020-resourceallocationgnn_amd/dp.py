@@ -51,8 +51,13 @@ class DataParallelTrainer(object):
         return (self.overlap and hasattr(self.backend, "forward_backward_phase") and hasattr(local_batch, "device")
                 and getattr(self.backend.spec, "feat_dim", 0) <= 64)
 
-    def train_step(self, local_batch, local_y, n_graphs_global, want_loss=True):
+    def train_step(self, local_batch, local_y, n_graphs_global=None, want_loss=True, n_denominator=None):
         """forward+backward on the local shard, all-reduce the gradient, Adam on every rank.
+
+        n_denominator (n_graphs_global is its older name): what the GLOBAL Huber mean divides by besides the channel
+        count -- the number of graphs of the whole minibatch for fixed-size graphs (one mean per output, BS_brain.py:214),
+        the number of NODE ROWS of the whole minibatch for variable_graphs models (one mean over all rows): ragged shards
+        hold different numbers of rows, so the caller sums them over the ranks (bench.py does).
 
         With `overlap` and a device-resident batch the step is split (SURVEY.md 8 e3 "overlappable with the tail of
         backward"): the Dense-layer gradients are final as soon as the decision MLP has been differentiated, so their
@@ -60,6 +65,10 @@ class DataParallelTrainer(object):
         the graph layers are still in their backward pass; the graph-layer bucket follows, and ONE Adam launch runs
         after both.  Otherwise: one replayed graph for forward + backward + slab sums, ONE all-reduce of the flat
         gradient, Adam."""
+        if n_denominator is not None:
+            n_graphs_global = n_denominator
+        if n_graphs_global is None:
+            raise ValueError("train_step: the global Huber denominator (n_denominator) is required under data parallelism")
         reduce_now = self.world > 1 or self.force
         if reduce_now and self._overlapped(local_batch):
             if self._grad is None:

@@ -97,10 +97,15 @@ class Agent(object):
         engine = getattr(getattr(self.brain, 'model', None), 'engine', None)
         on_gpu = hasattr(engine, '_h') and self.num_Neighbor == 1
         self.device_replay = None
-        if device_replay is True or (device_replay == 'auto' and on_gpu):
+        # (the HBM-resident memory keeps a transition's adjacency as one 32-bit source mask per link: at most
+        #  DeviceReplay.MAX_LINKS links; larger scenarios keep the reference's host-side Memory under 'auto')
+        from .replay import DeviceReplay
+        if device_replay is True and self.num_D2D > DeviceReplay.MAX_LINKS:
+            raise ValueError("device_replay=True: at most %d links (got %d); use device_replay='auto' or False"
+                             % (DeviceReplay.MAX_LINKS, self.num_D2D))
+        if device_replay is True or (device_replay == 'auto' and on_gpu and self.num_D2D <= DeviceReplay.MAX_LINKS):
             if not on_gpu:
                 raise ValueError("device_replay needs a brain on the gfx950 engine")
-            from .replay import DeviceReplay
             self.device_replay = DeviceReplay(MEMORY_CAPACITY, self.num_D2D, device=engine.device)
 
     def _trainer(self):

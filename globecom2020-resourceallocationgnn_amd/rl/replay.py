@@ -25,6 +25,8 @@ from ..packing import adj_to_csr, pack_xe
 
 
 class DeviceReplay(object):
+    MAX_LINKS = 31          # one int32 source mask per link (bit p of mask[q]: p sends to q)
+
     def __init__(self, capacity, n_nodes, device=0):
         import torch
         self.torch = torch
@@ -66,7 +68,7 @@ class DeviceReplay(object):
     def add(self, x, e, adj, action, reward, x_next, e_next):
         """x, x_next [n, Dn]; e, e_next [n, De]; adj [n, n] (Adj[p, q] = 1: p sends to q); action [n]; reward scalar."""
         adj = np.asarray(adj)
-        if self.n > 31:
+        if self.n > self.MAX_LINKS:
             raise ValueError("DeviceReplay keeps the adjacency as one 32-bit source mask per link: at most 31 links")
         row_ptr, col, _ = adj_to_csr(adj[None])
         if self.n_edges is None:
@@ -84,7 +86,7 @@ class DeviceReplay(object):
         operations."""
         adj = np.asarray(adj)
         K, n = adj.shape[0], self.n
-        if n > 31:
+        if n > self.MAX_LINKS:
             raise ValueError("DeviceReplay keeps the adjacency as one 32-bit source mask per link: at most 31 links")
         if self.n_edges is None:
             self.n_edges = n * (n - 2)

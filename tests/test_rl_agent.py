@@ -225,3 +225,24 @@ def test_random_channels_consume_the_numpy_stream_like_the_reference_loop():
                 got = _random_channels(n, nn, C)
                 assert np.array_equal(ref.astype(int), got) and got.dtype.kind == 'i'
                 assert np.random.random() == after_ref
+
+
+def test_more_than_31_links_keep_the_host_replay_memory_under_auto():
+    """rl/replay.DeviceReplay stores a transition's adjacency as one int32 source mask per link; device_replay='auto' (the
+    default on a GPU brain) must therefore fall back to the reference's host-side Memory at 32 links instead of failing at
+    the first stored transition, and an explicit device_replay=True must say so at construction."""
+    import pytest
+    random.seed(3)
+    np.random.seed(3)
+    cfg = RL_Config()
+    cfg.set_train_value(16, 0.5, 8, 1, 0.1)
+    env = make_env()
+    env.new_random_game(32)
+    brain = RecordingBrain(32, 3, 1, 16, 1, 4)
+    brain.model = types.SimpleNamespace(engine=types.SimpleNamespace(_h=1, device=0))      # looks like the gfx950 engine
+    agent = Agent(32, env.n_RB, env.n_Neighbor, 16, env, cfg, brain=brain)
+    assert agent.device_replay is None
+    agent.generate_d2d_transition(3)                                  # stores through the host Memory
+    assert len(agent.memory.samples) == 3
+    with pytest.raises(ValueError, match="at most 31 links"):
+        Agent(32, env.n_RB, env.n_Neighbor, 16, env, cfg, brain=brain, device_replay=True)

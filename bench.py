@@ -117,7 +117,8 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     table["k_gnn_bwd_fused"] = 4 * R * 2 * F + L * R * F // 8 + csr + (L + 1) * 4 * R * F
     table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"] - 4 * R * C  # fwd + Huber + bwd fused: q is not re-read
     table["k_mlp_train_wg"] = table["k_mlp_train"]    # weight gradients from the values on chip: no further node-row bytes
-    table["k_adj_masks"] = csr + 2 * 4 * R * ((max(N, 1) + 31) // 32)          # CSR in, bit masks by source and by destination out
+    table["k_adj_masks"] = csr + 2 * 4 * R * ((min(max(N, 1), 128) + 31) // 32)   # CSR in, bit masks by source and by destination out
+    #                       (ragged batches are modelled as ONE graph of R rows: their masks are 4 words, graphs of <= 128 links)
     if F >= 128:        # wide-feature path (csrc/kernels_wide.hpp): Dense-0 and its gradients are launches of their own,
         #                 Dense 1..3 stay register-chained ("tail" kernels), one weight-gradient launch per graph layer
         table["k_dense0_fwd"] = 4 * R * (Dn + 2 * F) + 4 * R * 80

@@ -987,12 +987,15 @@ int wide_wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, con
 }
 
 // rows per workgroup of the graph layers' roles when the embed gradient rides on them: one workgroup per CU if that
-// leaves >= 256 rows each, else the default chunking (0)
+// leaves >= 64 rows each (one 16-row block per wave), else the default chunking (0).  (Until round 3 the bound was 256
+// rows: a 512- or 1024-graph share of a fixed global batch -- 8 / 4 GPUs -- then fell back to 896-row chunks, i.e. 40 / 80
+// workgroups walking 8 blocks per wave: 33.8 / 34.1 us per launch against 19.2 / 20.6 us with 128- / 192-row chunks.)
 int merged_wg_rows(const v2x_model* m, int n_idx, int n_slots) {
   static const int rows_env = env_int("V2X_WG_CHUNK_MERGED", 0);
   if (rows_env > 0) return rows_env;
   const int nc_fit = n_cus() / std::max(1, m->L * n_slots);
-  if (nc_fit >= 1 && n_idx / nc_fit >= 256) return ((n_idx + nc_fit - 1) / nc_fit + 63) / 64 * 64;
+  static const int min_rows = env_int("V2X_WG_MERGED_MIN_ROWS", 64);
+  if (nc_fit >= 1 && n_idx / nc_fit >= min_rows) return ((n_idx + nc_fit - 1) / nc_fit + 63) / 64 * 64;
   return 0;
 }
 

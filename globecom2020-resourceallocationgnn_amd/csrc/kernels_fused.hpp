@@ -158,7 +158,19 @@ struct FzStamp {
 // explicit GLOBAL accesses: pointers rebuilt from the kernarg segment are generic, and a FLAT store / load makes the
 // wait-count pass give up counting (vmcnt(0) in front of every dependent MFMA)
 typedef __attribute__((address_space(1))) f32x4* gvec_wp;
+// The rows these kernels store (h_s, a_s, dpre_s: 126 + 63 MB per step at the headline size) are read again one to three
+// launches later by the weight-gradient launch -- far more than the 32 MB of L2 holds -- so they are stored NON-TEMPORAL
+// (`global_store ... nt`): they do not displace the weight fragments and partial-sum slabs that ARE re-read from L2.
+// Measured A/B on one box (round 3): step 0.2541 -> 0.2502 ms (the slab sums + Adam 15.5 -> 13.8 us, backward - 0.8 us,
+// forward + 0.8 us); non-temporal LOADS of the same rows in k_wgrad: no gain (0.2505 vs 0.2508), not used.
+#ifndef V2X_NT_STORES
+#define V2X_NT_STORES 1
+#endif
+#if V2X_NT_STORES
+__device__ __forceinline__ void stg4(float* p, f32x4 v) { __builtin_nontemporal_store(v, (gvec_wp)p); }
+#else
 __device__ __forceinline__ void stg4(float* p, f32x4 v) { *(gvec_wp)p = v; }
+#endif
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *(gvec_p)p; }
 
 // ReLU' gates as bits: the backward needs h_s only to know where it is positive.  Reading the rows back costs it 21 MB per

@@ -67,7 +67,12 @@ class Agent(object):
                         ceil(50 / G) of the transitions of a train step and samples its B / G graphs of the minibatch
                         from its OWN memory (stratified sampling: the minibatch is the union of the ranks' draws); the
                         Huber mean is over all B graphs and the gradients are all-reduced, so the replicas stay
-                        bit-identical while the simulator work per rank drops by G."""
+                        bit-identical while the simulator work per rank drops by G.
+                        This is NOT the reference's schedule transition for transition: when G does not divide 50 the job
+                        collects ceil(50 / G) * G transitions per train step (56 at G = 8); the epsilon schedule and the
+                        500-transition target sync count the JOB's transitions, but MEMORY_CAPACITY is per rank (the
+                        job's replay memory is G times the reference's), and a rank only ever replays its own
+                        simulator's trajectories.  'replicated' is the mode that reproduces the single-process run."""
         self.epsilon = MAX_EPSILON
         self.num_step = 0
         self.num_CH = num_ch

@@ -1,4 +1,9 @@
-"""Ragged-batch sweep (variable graph sizes, shared weights) against the float64 oracle -- run on a GPU box."""
+"""Ragged-batch sweep (variable graph sizes 1..128, shared weights, dense reference-like or sparse random adjacency) against
+the float64 oracle -- run on a GPU box:  python tests/sweep_ragged.py [n_cases].  Judged like tests/test_gpu_shapes.py:
+plain tolerances, ReLU gates at rounding distance of 0 resolved explicitly (tests/util.py), nothing redrawn.  Random weights,
+up to 126-neighbour sums and three layers put |q| at 1e7-1e8 in some draws; a case that fails is re-run in plain float32
+numpy against the same float64 oracle, which tells an ill-conditioned draw (numpy fails it too: round 3 saw 1 of 400,
+3 of 3200 elements of one array at 1.4x the tolerance in numpy, 3.3x in the kernels) from a kernel problem."""
 import sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
@@ -6,7 +11,7 @@ import v2xgnn
 from v2xgnn import GnnSpec, PackedBatch, GnnEngine
 from oracle import compact as oc
 from oracle.spec import GnnSpec as OSpec
-from util import f32_params, FWD_RTOL, FWD_ATOL, GRAD_RTOL, GRAD_ATOL_REL
+from util import f32_params, oracle_step, assert_fwd_close, assert_grads_match_oracle
 
 rng = np.random.default_rng(11)
 bad = 0
@@ -40,27 +45,34 @@ for case in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
         P = f32_params(spec, rng)
         eng = GnnEngine(spec)
         eng.set_weights(oc.params_to_list(P))
-        M = oc.csr_to_matrix(offs, pb.row_ptr, pb.col_idx, np.float64)
-        q_ref, cache = oc.forward(osp, P, x.astype(np.float64), e.astype(np.float64), M)
         q = eng.forward(pb)
-        scale = max(1.0, np.abs(q_ref).max())
-        ok_f = np.all(np.abs(q - q_ref) <= FWD_RTOL * np.abs(q_ref) + FWD_ATOL * scale)
-        y = (q_ref + rng.normal(0, 1.2, size=q_ref.shape)).astype(np.float32)
-        err = q.astype(np.float64) - y
-        dq = np.clip(err, -1, 1) / (R * 4)
-        g_ref = oc.backward(osp, P, cache, dq)
-        eng.forward_backward(pb, y)
-        got = v2xgnn.flat_to_keras_list(spec, eng.get_grad_flat())
-        ok_g, detail = True, ''
-        for ai, (a, b) in enumerate(zip(got, oc.params_to_list(g_ref))):
-            sc = float(np.abs(b).max()) or 1.0
-            if np.any(np.abs(a - b) > GRAD_RTOL * np.abs(b) + GRAD_ATOL_REL * sc):
-                ok_g = False; detail = "arr#%d%s rel %.1e" % (ai, a.shape, float((np.abs(a - b) / sc).max()))
+        y = (q + rng.normal(0, 1.2, size=q.shape)).astype(np.float32)
+        step = oracle_step(spec, P, x, e, (offs, pb.row_ptr, pb.col_idx), y, q_at=q, n_denominator=R)
+        status = "ok"
+        try:
+            assert_fwd_close(q, step['q'], "forward")
+            loss = eng.forward_backward(pb, y)
+            assert np.allclose(loss, step['loss'], rtol=2e-4, atol=1e-7), (loss, step['loss'])
+            _, n_cand, n_flip = assert_grads_match_oracle(v2xgnn.flat_to_keras_list(spec, eng.get_grad_flat()), P, step, "gradients")
+            if n_flip:
+                status = "ok (%d of %d candidate ReLU gates taken the kernels' way)" % (n_flip, n_cand)
+        except AssertionError as exc:
+            status = "MISMATCH " + str(exc).splitlines()[0][:200]
+            # is it the draw?  the same step in plain float32 numpy (oracle/compact.py cast to fp32) against the float64 oracle
+            P32 = oc.cast_params(P, np.float32)
+            M32 = oc.csr_to_matrix(offs, pb.row_ptr, pb.col_idx, np.float32)
+            _, c32 = oc.forward(osp, P32, x, e, M32)
+            g32 = oc.params_to_list(oc.backward(osp, P32, c32, step['dq'].astype(np.float32)))
+            worst = 0.0
+            for a_, b_ in zip(g32, oc.params_to_list(step['grads'])):
+                sc = float(np.abs(b_).max()) or 1.0
+                worst = max(worst, float((np.abs(a_ - b_) / (5e-4 * np.abs(b_) + 2e-5 * sc)).max()))
+            status += " | float32 numpy vs float64 on the same draw: worst err/tol %.2f (%s)" % (
+                worst, "the DRAW is ill-conditioned for fp32" if worst > 1 else "fp32 numpy passes: look at the kernels")
         eng.close()
-        status = "ok" if ok_f and ok_g else "MISMATCH fwd=%s grad=%s %s" % (ok_f, ok_g, detail)
     except Exception as exc:                              # noqa
         status = "ERROR %s: %s" % (type(exc).__name__, str(exc)[:140])
-    if status != "ok":
+    if not status.startswith("ok"):
         bad += 1
     print("F=%3d L=%d graphs=%2d max=%3d dense=%d rows=%4d  %s" % (F, L, G, hi, dense, int(np.sum(sizes)), status), flush=True)
 print("bad cases:", bad)

@@ -1,24 +1,27 @@
-"""Randomised shape sweep of the whole model (forward, loss, gradients) against the float64 oracle -- run on a GPU box:
+"""Randomised shape sweep of the whole model (forward, per-output loss, every gradient array) against the float64 oracle --
+run on a GPU box:
     python tests/sweep_shapes.py [n_cases]
-A few of the 504 shapes report a mismatch in a BIAS gradient of a layer summed over few rows: a ReLU pre-activation
-~1e-6 of its layer's scale that fp32 and fp64 gate differently (checked on the dumped case: pre-activation 2.9e-6 at a
-typical magnitude of 35).  tests/sweep_replay_case.py replays the dumped case in a fresh process (bit-identical gradients);
-tests/test_gpu_shapes.py is the permanent subset (one seeded draw per shape, every draw counts)."""
-import itertools, sys
+Every case is one seeded draw, judged exactly as tests/test_gpu_shapes.py judges its permanent subset: plain rounding
+tolerances, ReLU gates at fp32 rounding distance of 0 identified explicitly and taken the kernels' way (tests/util.py),
+nothing redrawn.  The grid: 7 link counts x 4 feature widths x 3 depths x shared / per-node weights x 3 batch sizes = 504
+shapes, reference topology or a random adjacency."""
+import itertools, os, sys, traceback
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from v2xgnn import GnnSpec, PackedBatch, GnnEngine
 import v2xgnn
 from oracle import compact as oc
-from util import ospec, f32_params, random_inputs, FWD_RTOL, FWD_ATOL, GRAD_RTOL, GRAD_ATOL_REL
+from util import f32_params, random_inputs, oracle_step, assert_fwd_close, assert_close, assert_grads_match_oracle
 
 rng = np.random.default_rng(7)
 cases = list(itertools.product([1, 2, 3, 7, 20, 33, 40], [16, 32, 64, 128], [1, 2, 4], [False, True], [1, 17, 130]))
 rng.shuffle(cases)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-bad = 0
+bad = flips = 0
+os.environ["V2X_SMALL_PREDICT"] = "0"          # forward() on the training path's kernels (the loss is differentiated at its q)
 for (N, F, L, shared, B) in cases[:n]:
     spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=shared)
+    status = "ok"
     try:
         P = f32_params(spec, rng)
         topo = bool(rng.integers(0, 2)) and N > 2
@@ -27,42 +30,23 @@ for (N, F, L, shared, B) in cases[:n]:
         eng = GnnEngine(spec)
         eng.set_weights(oc.params_to_list(P))
         graph = ((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
-        M = oc.csr_to_matrix(*graph, dtype=np.float64)
-        os_ = ospec(spec)
-        xr, er = x.reshape(B * N, -1).astype(np.float64), e.reshape(B * N, -1).astype(np.float64)
-        q_ref, cache = oc.forward(os_, P, xr, er, M)
         q = eng.forward(pb)
-        scale = max(1.0, np.abs(q_ref).max())
-        ok_f = np.all(np.abs(q - q_ref) <= FWD_RTOL * np.abs(q_ref) + FWD_ATOL * scale)
-        y = (q_ref + rng.normal(0, 1.2, size=q_ref.shape)).astype(np.float32)
-        # the backward is checked for the SAME q the kernels differentiate (tests/test_gpu_model.py)
-        loss_ref, dq = oc.huber_loss_and_grad(os_, q.astype(np.float64), y.astype(np.float64))
-        g_ref = oc.backward(os_, P, cache, dq)
+        y = (q + rng.normal(0, 1.2, size=q.shape)).astype(np.float32)
+        step = oracle_step(spec, P, x.reshape(B * N, -1), e.reshape(B * N, -1), graph, y, q_at=q)
+        assert_fwd_close(q, step['q'], "forward")
         loss = eng.forward_backward(pb, y)
-        ok_l = np.allclose(loss, loss_ref, rtol=2e-4, atol=1e-6)
-        gflat = eng.get_grad_flat()
-        got = v2xgnn.flat_to_keras_list(spec, gflat)
-        ok_g, worst = True, 0.0
-        detail = ''
-        for ai, (a, b) in enumerate(zip(got, oc.params_to_list(g_ref))):
-            sc = float(np.abs(b).max()) or 1.0
-            err = np.abs(a - b) - (GRAD_RTOL * np.abs(b) + GRAD_ATOL_REL * sc)
-            worst = max(worst, float((np.abs(a - b) / sc).max()))
-            if np.any(err > 0):
-                ok_g = False
-                idx = np.unravel_index(np.argmax(err), a.shape)
-                detail = "arr#%d%s at %s got %.4e ref %.4e scale %.2e" % (ai, a.shape, idx, a[idx], b[idx], sc)
-        ok_g = ok_g and ok_l
+        assert_close(loss, step['loss'], 2e-4, 1e-6, "per-output Huber loss")
+        _, n_cand, n_flip = assert_grads_match_oracle(v2xgnn.flat_to_keras_list(spec, eng.get_grad_flat()), P, step, "gradients")
+        flips += n_flip
+        if n_flip:
+            status = "ok (%d of %d candidate ReLU gates taken the kernels' way)" % (n_flip, n_cand)
         eng.close()
-        if not (ok_f and ok_g) and not globals().get('_dumped'):
-            globals()['_dumped'] = True
-            np.savez('gpurun_out/fail_case.npz', N=N, F=F, L=L, shared=shared, B=B, x=x, e=e, adj=adj, y=y,
-                     w=np.concatenate([np.asarray(a, np.float64).ravel() for a in oc.params_to_list(P)]),
-                     g=gflat, q=q)
-        status = "ok" if (ok_f and ok_g) else "MISMATCH fwd=%s grad=%s loss=%s worst_rel=%.2e qscale=%.1e ref_topo=%s %s" % (ok_f, ok_g, ok_l, worst, scale, topo, detail)
+    except AssertionError as exc:
+        status = "MISMATCH ref_topo=%s: %s" % (topo, str(exc).splitlines()[0][:200])
     except Exception as exc:                      # noqa
-        status = "ERROR %s: %s" % (type(exc).__name__, str(exc)[:120])
-    if status != "ok":
+        status = "ERROR %s: %s" % (type(exc).__name__, str(exc)[:160])
+        traceback.print_exc()
+    if not status.startswith("ok"):
         bad += 1
     print("N=%2d F=%3d L=%d shared=%d B=%3d  %s" % (N, F, L, shared, B, status), flush=True)
-print("bad cases:", bad)
+print("cases: %d, bad: %d, ReLU gates resolved: %d" % (min(n, len(cases)), bad, flips))

@@ -89,7 +89,8 @@ def golden_feed(f, case):
 # the other way by fp32 arithmetic: the unit's whole gradient contribution appears / disappears, which no rounding
 # tolerance covers.  That is conditioning of the DRAW, not of the kernels.  Nothing is redrawn and no tolerance is
 # widened; instead the condition is made explicit:
-#   (a) the CANDIDATE units are found from the oracle's own pre-activations (|pre| <= 4e-6 * max|pre| of the layer, AMBIG_RTOLS);
+#   (a) the CANDIDATE units are found from the oracle's own pre-activations (|pre| <= 4e-6 x the sum of the magnitudes of
+#       the terms it adds up, sum_k |in_k| |W_kf| + |b_f|; AMBIG_RTOLS);
 #   (b) if the kernels' gradient differs from the oracle's, the candidates whose gate the kernels took the other way are
 #       identified from the residual in the unit's OWN weight column (flipping unit (row r, feature f) changes column f of
 #       its layer's weight gradient by exactly +-(pre-gate gradient) x (the layer's input row r), bias included): the
@@ -117,6 +118,10 @@ def _relu_layer_inputs(os_, cache, t):
                       ('W3', cache['a'][t - 1])], cache['h'][t]
 
 
+def _slot_bias_abs(b, R):
+    return np.abs(b[0])[None, :] if b.shape[0] == 1 else np.tile(np.abs(b), (R // b.shape[0], 1))
+
+
 def resolve_relu_gates(os_, P, cache, dq, got, ref, pre_gate, rtol=AMBIG_RTOLS[0]):
     """got / ref: gradients with the structure of the parameters (kernels / oracle).  -> (gradients of the oracle with the
     candidate gates the kernels took the other way flipped, number of candidate units, number flipped).
@@ -130,11 +135,16 @@ def resolve_relu_gates(os_, P, cache, dq, got, ref, pre_gate, rtol=AMBIG_RTOLS[0
     n_cand = n_flip = 0
     for t in range(len(cache['relu_pre']) - 1, -1, -1):
         pre = cache['relu_pre'][t]
-        rr, ff = np.nonzero(np.abs(pre) <= rtol * np.abs(pre).max())
+        kind, li, ins, post = _relu_layer_inputs(os_, c2, t)
+        # a pre-activation is uncertain relative to the size of the TERMS it sums (rows of a 126-link graph carry
+        # values 1e4 times those of a 2-link graph in the same ragged batch), not relative to the layer's largest value
+        mag = np.abs(_slot_bias_abs(P[kind][li]['b'], pre.shape[0]))
+        for name, a in ins:
+            mag = mag + oc._slot_mm(np.abs(a), np.abs(P[kind][li][name]))
+        rr, ff = np.nonzero(np.abs(pre) <= rtol * mag)
         n_cand += rr.size
         if rr.size == 0:
             continue
-        kind, li, ins, post = _relu_layer_inputs(os_, c2, t)
         slot = rr % S if S > 1 else np.zeros_like(rr)
         delta = np.where(post[rr, ff] > 0, -1.0, 1.0) * pre_gate[t][rr, ff]    # what flipping the unit adds to db[slot][f]
         key = slot * pre.shape[1] + ff

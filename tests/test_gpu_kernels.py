@@ -49,8 +49,11 @@ def _variable_batch(rng, sizes, F, density=0.4):
 
 @pytest.mark.parametrize("B,N,F,ref_topo", [(1, 4, 16, True), (7, 4, 16, False), (64, 20, 64, True),
                                             (5, 33, 64, False), (3, 100, 32, True), (130, 20, 64, False),
-                                            (2, 100, 256, True)])
+                                            (2, 100, 256, True), (3, 200, 64, True), (3, 200, 64, False),
+                                            (2, 129, 128, True)])
 def test_agg_fwd_bwd_fixed(B, N, F, ref_topo):
+    """(N >= 32 dense graphs run k_agg_dense: the reference topology through the complement -- column sum minus the
+    non-neighbour rows --, random adjacencies of density 0.5 as an MFMA product; 129 and 200 links: masks of 5 / 7 words)"""
     rng = np.random.default_rng(B * 1000 + N + F)
     _, _, adj = random_inputs(rng, B, N, ref_topology=ref_topo)
     row_ptr, col_idx, max_e = v2xgnn.adj_to_csr(adj)
@@ -90,6 +93,53 @@ def test_agg_variable_sizes():
     vlib.check(lib, lib.v2x_agg_bwd(C.byref(s), 0, F, hd.data_ptr(), out.data_ptr(), None))
     _sync()
     assert_close(out.cpu().numpy(), M.T @ h.astype(np.float64), 1e-5, 1e-5, "agg bwd ragged")
+
+
+def test_agg_mixed_forms_in_one_ragged_batch():
+    """k_agg_dense decides PER GRAPH between the complement walk (at most 8 non-edges per row: the reference topology, complete
+    graphs, a graph of one node) and the MFMA product (random adjacency of density 0.5, an edgeless graph) -- all in one batch."""
+    rng = np.random.default_rng(17)
+    sizes = [64, 40, 1, 128, 33, 2, 96, 50]
+    kinds = ['ref', 'rand', 'ref', 'ref', 'rand', 'ref', 'full', 'empty']
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    row_ptr, cols, max_e = [0], [], 0
+    for n, kind in zip(sizes, kinds):
+        if kind == 'ref':
+            adj = ~np.eye(n, dtype=bool)
+            for q in range(n):
+                if n > 1:
+                    adj[rng.choice([p for p in range(n) if p != q]), q] = False
+        elif kind == 'full':
+            adj = ~np.eye(n, dtype=bool)
+        elif kind == 'empty':
+            adj = np.zeros((n, n), bool)
+        else:
+            adj = rng.uniform(size=(n, n)) < 0.5
+        e_g = 0
+        for q in range(n):
+            src = np.nonzero(adj[:, q])[0]
+            cols.append(src)
+            row_ptr.append(row_ptr[-1] + len(src))
+            e_g += len(src)
+        max_e = max(max_e, e_g)
+    col_idx = np.concatenate(cols).astype(np.int32)
+    R, F = int(offs[-1]), 64
+    pb = PackedBatch(len(sizes), 0, np.zeros((R, 16), np.float32), np.array(row_ptr, np.int32), col_idx, max_e,
+                     graph_off=offs, max_nodes=max(sizes))
+    h = rng.normal(size=(R, F)).astype(np.float32)
+    M = oc.csr_to_matrix(pb.graph_off, pb.row_ptr, pb.col_idx, np.float64)
+    lib = vlib.load_library()
+    s = _batch_struct(DeviceBatch(pb, "cuda:0"))
+    import torch
+    db = DeviceBatch(pb, "cuda:0")
+    s = _batch_struct(db)
+    hd, out = _t(h), torch.empty((R, F), dtype=torch.float32, device="cuda:0")
+    vlib.check(lib, lib.v2x_agg_fwd(C.byref(s), 0, F, hd.data_ptr(), out.data_ptr(), None))
+    _sync()
+    assert_close(out.cpu().numpy(), M @ h.astype(np.float64), 1e-5, 2e-5, "agg fwd, mixed forms")
+    vlib.check(lib, lib.v2x_agg_bwd(C.byref(s), 0, F, hd.data_ptr(), out.data_ptr(), None))
+    _sync()
+    assert_close(out.cpu().numpy(), M.T @ h.astype(np.float64), 1e-5, 2e-5, "agg bwd (transpose), mixed forms")
 
 
 def test_agg_empty_graphs():

@@ -1,7 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for e in 0 1; do
-if [ $e = 1 ]; then export V2X_NO_PACK_SCATTER=1; fi
-rocprofv3 --kernel-trace --stats -d gpurun_out/tmpp$e -o stats -- python bench.py --no-cpu-baseline --no-roofline --no-edge-gather --min-seconds 0.3 > /dev/null 2>&1
-python tools/rocpd_summary.py $(ls gpurun_out/tmpp$e/*/*.db gpurun_out/tmpp$e/*.db 2>/dev/null | head -1) | grep -E "k_reduce_adam|k_mlp_train"
-done
-rm -rf gpurun_out/tmpp*
+for g in 8 4; do for e in 1 0; do V2X_MLP_WG=$e python bench.py --shard-of $g --no-cpu-baseline --no-edge-gather --min-seconds 0.5 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('MLP_WG=$e shard-of $g', d['ms_per_step'], {k:v['avg_us'] for k,v in d['kernels'].items()})"; done; done

@@ -142,11 +142,25 @@ def lib_sha256():
         return None
 
 
+def src_sha256():
+    """sha256 over the kernel and C-ABI sources the library is built from (hipcc output is not bit-reproducible: a rebuild of
+    the SAME sources has another sha256 and the same kernels)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "globecom2020-resourceallocationgnn_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(pkg, "*.hip")) + glob.glob(os.path.join(pkg, "*.hpp")) + [os.path.join(ROOT, "include", "v2xgnn.h")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def hbm_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled
     per the gfx950 note in MI355X_MICROARCH.md, + WRITE_SIZE).  Counters cannot be read from inside the run, so the
-    figure is only reported when it was measured on THIS binary (profiles/hbm_traffic.json records the sha256 of the
-    libv2xgnn.so of its PMC passes) and for the default workload; otherwise null."""
+    figure is only reported when it was measured on THIS binary, or on a build of the same kernel sources
+    (profiles/hbm_traffic.json records the sha256 of the libv2xgnn.so of its PMC passes and of the sources it was built
+    from), and for the default workload; otherwise null."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     default = (args.batch, args.nodes, args.feat, args.layers, args.share_weights, args.ragged) == (4096, 20, 64, 2, False, None)
     if not default or not os.path.exists(path):
@@ -154,7 +168,9 @@ def hbm_traffic(kernel, args):
     try:
         with open(path) as f:
             rec = json.load(f)
-        if not rec.get("lib_sha256") or rec["lib_sha256"] != lib_sha256():
+        same_binary = rec.get("lib_sha256") and rec["lib_sha256"] == lib_sha256()
+        same_sources = rec.get("src_sha256") and rec["src_sha256"] == src_sha256()
+        if not (same_binary or same_sources):
             return None
         return rec.get("bytes_per_launch", {}).get(kernel)
     except Exception:

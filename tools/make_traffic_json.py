@@ -40,7 +40,10 @@ def main(fetch_db, write_db):
     lib = os.environ.get("V2XGNN_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                     "globecom2020-resourceallocationgnn_amd", "libv2xgnn.so"))
     f, w = per_dispatch(fetch_db, "FETCH_SIZE"), per_dispatch(write_db, "WRITE_SIZE")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     out = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),     # bench.py reports these figures only for THIS binary
+           "src_sha256": bench.src_sha256(),                                     # ... or a rebuild of the same sources
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python bench.py --no-graph",
            "formula": "bytes = (2*FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024", "fetch_kb": f, "write_kb": w,
            "bytes_per_launch": {k: int((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024) for k in sorted(set(f) | set(w))}}

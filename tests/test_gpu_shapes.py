@@ -123,3 +123,46 @@ def test_small_predict_vs_oracle_and_training_path(N, F, L, shared, B, topo):
     assert np.all(np.abs(q2 - qp2) <= FWD_RTOL * np.abs(qp2) + FWD_ATOL * max(1.0, np.abs(qp2).max()))
     small.close()
     plain.close()
+
+
+def test_small_predict_soak_bitwise_repeatable_across_launches_models_and_batch_sizes():
+    """The one-launch predict exchanges rows as data-tagged words whose tag comes from a per-graph departure counter
+    (csrc/kernels_small.hpp): 3,000 predicts of 1..12 graphs on two models sharing the GPU, eager and as replayed hipGraphs,
+    interleaved with fit steps and weight copies.  Between two weight changes every repeat of a forward must return the
+    SAME BITS as the first one -- a row taken from an earlier launch or stage would show."""
+    import torch
+    N, F = 20, 64
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(0)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        a, b = GnnEngine(spec, use_graph=True), GnnEngine(spec)
+        w = oc.params_to_list(f32_params(spec, rng))
+        a.set_weights(w)
+        b.set_weights(w)
+        batches = {}
+        for B in range(1, 13):
+            x, e, adj = random_inputs(rng, B, N, ref_topology=True)
+            batches[B] = PackedBatch.from_dense(x, e, adj)
+        xt, et, at = random_inputs(rng, 64, N, ref_topology=True)
+        train = a.to_device(PackedBatch.from_dense(xt, et, at))
+        yt = torch.from_numpy(rng.normal(2.5, 1.0, size=(64 * N, 4)).astype(np.float32)).cuda()
+        ref = {}
+        for it in range(3000):
+            B = 1 + it % 12
+            eng = a if it % 3 else b
+            q = eng.forward(batches[B])
+            key = (id(eng), B)
+            if key in ref:
+                assert np.array_equal(q, ref[key]), ("predict changed without a weight change", it, B)
+            else:
+                assert np.all(np.isfinite(q))
+                ref[key] = q.copy()
+            if it % 50 == 0:
+                a.train_step(train, yt, want_loss=False)
+                ref = {k: v for k, v in ref.items() if k[0] != id(a)}
+            if it % 500 == 0:
+                b.copy_weights_from(a)
+                ref = {k: v for k, v in ref.items() if k[0] != id(b)}
+        torch.cuda.synchronize()
+        a.close()
+        b.close()

@@ -129,7 +129,6 @@ def test_agg_mixed_forms_in_one_ragged_batch():
     h = rng.normal(size=(R, F)).astype(np.float32)
     M = oc.csr_to_matrix(pb.graph_off, pb.row_ptr, pb.col_idx, np.float64)
     lib = vlib.load_library()
-    s = _batch_struct(DeviceBatch(pb, "cuda:0"))
     import torch
     db = DeviceBatch(pb, "cuda:0")
     s = _batch_struct(db)

@@ -336,20 +336,34 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
   const int r_begin = a.graph_off ? a.graph_off[g] : g * a.n_nodes;
   const int n = (a.graph_off ? a.graph_off[g + 1] : r_begin + a.n_nodes) - r_begin;
   if (n > a.rows_cap || n < 0) { if (tid == 0 && a.err) atomicOr(a.err, 1); return; }
+  int* sR = reinterpret_cast<int*>(sD + a.rows_cap * a.mask_words);         // [rows_cap + 1] the graph's slice of row_ptr
+  for (int i = tid; i <= n; i += 256) sR[i] = a.row_ptr[r_begin + i];
   for (int i = tid; i < n * a.mask_words; i += 256) sM[i] = 0u;
   __syncthreads();
-  for (int i = tid; i < n * 32; i += 256) {                                 // 32 threads per destination row
-    const int q = i >> 5, sl = i & 31;
-    const int e0 = a.row_ptr[r_begin + q] + sl, e1 = a.row_ptr[r_begin + q + 1];
-    int p[4];
+  // 32 threads per destination row, TWO passes of 8 rows at a time with all 8 col_idx loads of a thread in flight; the row
+  // bounds come from the LDS copy of row_ptr (round 2 read them from global memory in every pass: two dependent round
+  // trips per 8 rows, 32 in a row for a 128-link graph)
+  for (int i0 = tid; i0 < n * 32; i0 += 512) {
+    int p[2][4], q[2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) p[u] = e0 + 32 * u < e1 ? a.col_idx[e0 + 32 * u] : -1;   // 4 loads in flight
+    for (int h = 0; h < 2; ++h) {
+      const int i = i0 + 256 * h;
+      q[h] = min(i >> 5, n - 1);
+      const int e0 = sR[q[h]] + (i & 31), e1 = i < n * 32 ? sR[q[h] + 1] : 0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (p[u] >= 0 && p[u] < n) atomicOr(&sM[p[u] * a.mask_words + (q >> 5)], 1u << (q & 31));
-    for (int e = e0 + 128; e < e1; e += 32) {
-      const int pp = a.col_idx[e];
-      if (pp >= 0 && pp < n) atomicOr(&sM[pp * a.mask_words + (q >> 5)], 1u << (q & 31));
+      for (int u = 0; u < 4; ++u) p[h][u] = e0 + 32 * u < e1 ? a.col_idx[e0 + 32 * u] : -1;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (p[h][u] >= 0 && p[h][u] < n) atomicOr(&sM[p[h][u] * a.mask_words + (q[h] >> 5)], 1u << (q[h] & 31));
+      const int i = i0 + 256 * h;
+      if (i < n * 32)
+        for (int e = sR[q[h]] + (i & 31) + 128; e < sR[q[h] + 1]; e += 32) {
+          const int pp = a.col_idx[e];
+          if (pp >= 0 && pp < n) atomicOr(&sM[pp * a.mask_words + (q[h] >> 5)], 1u << (q[h] & 31));
+        }
     }
   }
   __syncthreads();
@@ -374,7 +388,13 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
   }
 }
 
-constexpr int AD_LDT = 64 + 16;         // LDS row stride of the feature tile: the 4 k-groups of a wave hit disjoint banks
+// LDS layout of the [rows][64] feature tile: NO padding, row r is rotated by 16 (r & 3) floats instead -- the four
+// k-groups of a wave (rows 4 s + kg of a k-step) then hit disjoint quarters of the 64 banks exactly as the 80-float row
+// stride of round 2 made them, float4 accesses stay aligned, and a graph of 100 / 128 links takes 34 / 39 KB instead of
+// 41 / 46: FOUR workgroups per CU instead of three.  These launches are latency chains per workgroup: the
+// fourth resident workgroup is worth 73.2 -> 59.3 / 96.8 -> 80.0 us at configs[3] and 30.7 -> 26.7 / 41.4 -> 36.8 us at configs[4].
+constexpr int AD_LDT = 64;
+__device__ __forceinline__ int ad_off(int row, int col) { return row * AD_LDT + ((col + ((row & 3) << 4)) & 63); }
 
 // grid = n_graphs * n_fg workgroups.  Workgroup ids are dealt round-robin to the 8 XCDs, so the n_fg feature
 // groups of one graph are given ids with the SAME id mod 8: they run on one XCD and share its L2.
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(256) void k_agg_dense(AggDenseArgs a) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * 256 + tid;
-      if (i < n * 16) *reinterpret_cast<float4*>(sT + (i >> 4) * AD_LDT + ((i & 15) << 2)) = v[u];
+      if (i < n * 16) *reinterpret_cast<float4*>(sT + ad_off(i >> 4, (i & 15) << 2)) = v[u];
     }
   }
   __syncthreads();
@@ -418,17 +438,24 @@ __global__ __launch_bounds__(256) void k_agg_dense(AggDenseArgs a) {
   if (compl_form) {
     // out[r] = S - sum over the zero bits p < n of row r's mask of tile[p]   (forward: r = destination, mask by
     // destination; transpose: r = source, mask by source -- the same walk)
-    float* sP = reinterpret_cast<float*>(sM + a.rows_cap * a.mask_words);   // [16 row groups][64] partial column sums, then S at [0]
-    const int c = tid & 15, rg = tid >> 4;                                  // float4 column, row group
+    float* sP = reinterpret_cast<float*>(sM + a.rows_cap * a.mask_words);   // [4 waves][64] partial column sums
+    const int c = tid & 15, rg = tid >> 4;                                  // float4 column, row group (4 per wave)
+    f32x4 S;
     {
       f32x4 ps = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int r = rg; r < n; r += 16) ps += *reinterpret_cast<const f32x4*>(sT + r * AD_LDT + 4 * c);
-      *reinterpret_cast<f32x4*>(sP + rg * 64 + 4 * c) = ps;
-    }
-    __syncthreads();
-    f32x4 S = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int r = rg; r < n; r += 16) ps += *reinterpret_cast<const f32x4*>(sT + ad_off(r, 4 * c));
+      // the wave's four row groups through lane exchanges, the four waves through 1 KB of LDS (16 partial rows there would
+      // cost the fifth resident workgroup at 100 links): ((g0 + g1) + (g2 + g3)) per wave, ((w0 + w1) + (w2 + w3)) -- fixed
 #pragma unroll
-    for (int u = 0; u < 16; ++u) S += *reinterpret_cast<const f32x4*>(sP + u * 64 + 4 * c);     // fixed order, every thread the same
+      for (int e = 0; e < 4; ++e) ps[e] += __shfl_xor(ps[e], 16, 64);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ps[e] += __shfl_xor(ps[e], 32, 64);
+      if ((lane >> 4) == 0) *reinterpret_cast<f32x4*>(sP + wv * 64 + 4 * c) = ps;
+      __syncthreads();
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(sP + 0 * 64 + 4 * c), w1 = *reinterpret_cast<const f32x4*>(sP + 1 * 64 + 4 * c);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(sP + 2 * 64 + 4 * c), w3 = *reinterpret_cast<const f32x4*>(sP + 3 * 64 + 4 * c);
+      S = (w0 + w1) + (w2 + w3);
+    }
     for (int r0 = 0; r0 < n; r0 += 16) {
       const int r = r0 + rg;
       if (r >= n) break;
@@ -443,7 +470,7 @@ __global__ __launch_bounds__(256) void k_agg_dense(AggDenseArgs a) {
         while (z) {
           const int p = 32 * w + __builtin_ctz(z);
           z &= z - 1;
-          miss += *reinterpret_cast<const f32x4*>(sT + p * AD_LDT + 4 * c);
+          miss += *reinterpret_cast<const f32x4*>(sT + ad_off(p, 4 * c));
         }
       }
       f32x4 v = (S - miss) + addv;
@@ -480,9 +507,8 @@ __global__ __launch_bounds__(256) void k_agg_dense(AggDenseArgs a) {
         if (!TRANSPOSE) w = sM[kk * a.mask_words + (row >> 5)] >> (row & 31);   // Adj[p = kk][q = row]
         else w = sM[row * a.mask_words + (kk >> 5)] >> (kk & 31);               // Adj[p = row][q = kk]
         bv[s] = (float)(w & 1u);
-        const float* tp = sT + kc * AD_LDT + j;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) av[s][nt] = tp[nt * 16];
+        for (int nt = 0; nt < 4; ++nt) av[s][nt] = sT[ad_off(kc, nt * 16 + j)];
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s)

@@ -475,7 +475,7 @@ bool use_dense_agg(const DevBatch& d, int F) {
   static const int dense_min_nodes = env_int("V2X_AGG_DENSE_MIN_NODES", 32);
   const size_t rows_cap = (d.max_nodes + 15) / 16 * 16, mw = (d.max_nodes + 31) / 32;
   return F >= 64 && d.max_nodes >= dense_min_nodes && (int64_t)d.max_edges * 4 >= (int64_t)d.max_nodes * d.max_nodes &&
-         rows_cap * AD_LDT * 4 + rows_cap * mw * 4 + 16 * 64 * 4 <= 160 * 1024;
+         rows_cap * AD_LDT * 4 + rows_cap * mw * 4 + 4 * 64 * 4 <= 160 * 1024;
 }
 
 AggDenseArgs agg_dense_args(const DevBatch& d, Range r, int N, int F) {
@@ -525,7 +525,7 @@ int launch_agg(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, int N, 
       q.adjT = q.adj + (size_t)d.R * q.mask_words;
       CHK(build_adj_masks(m, st, q));
     }
-    const size_t lds = (size_t)q.rows_cap * AD_LDT * 4 + (size_t)q.rows_cap * q.mask_words * 4 + 16 * 64 * 4;   // + partial column sums
+    const size_t lds = (size_t)q.rows_cap * AD_LDT * 4 + (size_t)q.rows_cap * q.mask_words * 4 + 4 * 64 * 4;   // + partial column sums
     const dim3 grid((r.ng + 7) / 8 * 8 * q.n_fg);
     if (transpose) { auto k = k_agg_dense<true>; LAUNCH(m, "k_agg_bwd", k, grid, lds, st, q); }
     else { auto k = k_agg_dense<false>; LAUNCH(m, "k_agg_fwd", k, grid, lds, st, q); }

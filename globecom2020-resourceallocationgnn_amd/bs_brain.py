@@ -9,7 +9,7 @@ can use this class unchanged:  `self.brain = BS(num_d2d, 3, 1, num_feedback, num
 import numpy as np
 
 from .engine import GnnEngine
-from .packing import PackedBatch, feed_to_arrays, keras_list_shapes
+from .packing import PackedBatch, AdjacencyCache, feed_to_arrays, feed_to_packed, keras_list_shapes
 from .spec import GnnSpec
 
 
@@ -39,7 +39,7 @@ class GnnQModel(object):
 
     def __init__(self, spec: GnnSpec, device=0, seed=None, use_graph=False, validate_adjacency=True,
                  lr=1e-3, beta_1=0.5, beta_2=0.999, epsilon=1e-7, data_parallel=False, process_group=None, engine=None,
-                 model_index=0):
+                 model_index=0, adjacency_cache=None):
         """data_parallel: every fit step shards the minibatch over the ranks of `process_group` (default group) and
         all-reduces the gradient (v2xgnn.dp); all ranks must call fit with the SAME full minibatch.
         engine: an object with GnnEngine's interface (the CPU tests inject one); default: the gfx950 engine,
@@ -56,6 +56,9 @@ class GnnQModel(object):
             self.trainer = DataParallelTrainer(self.engine, process_group=process_group,
                                                force=os.environ.get("V2X_FORCE_DP") == "1")
         self.validate_adjacency = validate_adjacency
+        # which Adjacency_Matrix objects already passed the Kronecker check (shared by the two models of a BS: one
+        # replay hands the same array to predict and to fit, BS_brain.py:603 -> :652, :716)
+        self.adjacency_cache = adjacency_cache if adjacency_cache is not None else AdjacencyCache()
         N = spec.n_nodes
         self.input_names = []
         for k in range(1, N + 1):                            # order of Model(inputs=[...]) BS_brain.py:203-207
@@ -75,9 +78,15 @@ class GnnQModel(object):
         raise ValueError("Error when checking model %s: expected a dict or list of arrays" % what)
 
     def _pack(self, x):
+        """numpy definition of the payload -> arrays step (minibatched fits; the tests' reference for _pack_batch)"""
         feed = self._named(x, self.input_names, "input")
         xs, es, nbr, adj = feed_to_arrays(self.spec, feed, self.validate_adjacency)
         return xs, es, nbr, adj
+
+    def _pack_batch(self, x):
+        """dict payload -> PackedBatch in one pass of compiled host code (v2x_pack_feed)"""
+        feed = self._named(x, self.input_names, "input")
+        return feed_to_packed(self.spec, feed, self.validate_adjacency, self.adjacency_cache)
 
     def _targets(self, y, B):
         yd = self._named(y, self.output_names, "target")
@@ -109,18 +118,26 @@ class GnnQModel(object):
     def predict(self, x, batch_size=None, verbose=0):
         """-> list of N fresh, writable float32 arrays [B, C] (the caller mutates them in place,
         BS_brain.py:684-692)."""
-        xs, es, nbr, adj = self._pack(x)
-        B, N, Cc = xs.shape[0], self.spec.n_nodes, self.spec.n_channels
-        q = self.engine.forward(PackedBatch.from_dense(xs, es, adj, nbr)).reshape(B, N, Cc)
+        pb = self._pack_batch(x)
+        B, N, Cc = pb.n_graphs, self.spec.n_nodes, self.spec.n_channels
+        q = self.engine.forward(pb).reshape(B, N, Cc)
         return [np.ascontiguousarray(q[:, k, :]) for k in range(N)]
 
     def fit(self, x, y, batch_size=None, epochs=1, verbose=0, shuffle=True):
         """Model.fit: `epochs` passes of minibatch Adam steps.  The reference always calls it with
         batch_size == len(x), i.e. exactly one step (BS_brain.py:218-223)."""
-        xs, es, nbr, adj = self._pack(x)
-        B, N = xs.shape[0], self.spec.n_nodes
-        yt = self._targets(y, B)
+        N = self.spec.n_nodes
         batch_size = int(batch_size or 32)       # Keras default
+        feed = self._named(x, self.input_names, "input")
+        first = feed.get(self.input_names[0])
+        one_batch = first is not None and np.ndim(first) == 2 and batch_size >= np.shape(first)[0]
+        if one_batch:                            # the reference's call: the whole data set is one minibatch
+            whole = self._pack_batch(feed)
+            B = whole.n_graphs
+        else:
+            xs, es, nbr, adj = self._pack(feed)
+            B = xs.shape[0]
+        yt = self._targets(y, B)
         hist = History()
         keys = ['loss'] + [n + '_loss' for n in self.output_names]
         for k in keys:
@@ -132,14 +149,14 @@ class GnnQModel(object):
             tot = np.zeros(N, np.float64)
             for s in range(0, B, batch_size):
                 sel = idx[s:s + batch_size]
-                if len(sel) == B:
+                if one_batch:
                     # whole data set in one minibatch: sample order inside the batch only changes
                     # the fp32 summation order, so skip the gather
-                    bx, be, bn, ba, by = xs, es, nbr, adj, yt
+                    pb, by = whole, yt
                 else:
                     bx, be, ba, by = xs[sel], es[sel], adj[sel], yt[sel]
                     bn = None if nbr is None else nbr[sel]
-                pb = PackedBatch.from_dense(bx, be, ba, bn)
+                    pb = PackedBatch.from_dense(bx, be, ba, bn)
                 loss = self._train_step(pb, by.reshape(-1, self.spec.n_channels))
                 tot += np.asarray(loss, np.float64) * len(sel)
             tot /= B
@@ -273,6 +290,7 @@ class BS(object):
         ss = np.random.SeedSequence(seed).spawn(2)
         self._seeds = [int(s.generate_state(1)[0]) for s in ss]
         self._n_models = 0
+        self._adj_cache = AdjacencyCache()
         self.model = self._create_model()
         self.target_model = self._create_model()
 
@@ -282,7 +300,8 @@ class BS(object):
         index = self._n_models
         self._n_models += 1
         return GnnQModel(self._spec, device=self._device, seed=seed, use_graph=self._use_graph,
-                         data_parallel=self._dp, process_group=self._group, engine=engine, model_index=index)
+                         data_parallel=self._dp, process_group=self._group, engine=engine, model_index=index,
+                         adjacency_cache=self._adj_cache)
 
     def train_dnn(self, data_train, labels, batch_size):
         epochs = 1

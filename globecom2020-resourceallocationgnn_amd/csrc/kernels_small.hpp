@@ -37,7 +37,8 @@ struct SmallFwdArgs {
   int64_t gnn_off[FZ_MAXL + 1], gnn_sstride[FZ_MAXL + 1];      // flat-parameter offset of stage s (slot 0), slot stride
   int64_t dense_off[4], dense_sstride[4];
   unsigned long long* hbuf;                                    // [L + 1][SMALL rows][F] tagged words {value, tag}: the stage outputs
-  unsigned* sync;                                              // [n_graphs][2]: departures of all launches so far, unused
+  unsigned long long* sync;                                    // [n_graphs]: departures of all launches so far (64-bit: never wraps)
+  int* err;                                                    // contract-violation / exchange-timeout flag word (check_flag)
   int slab_rows;                                               // rows of one stage slab
   float* q;                                                    // [n_rows][C]
   int N, L, S, C, Dn, De, n_rows;
@@ -45,6 +46,13 @@ struct SmallFwdArgs {
 
 constexpr int SM_THREADS = 256;
 constexpr int SM_BLOCK = SM_THREADS;
+// Error bits of the flag word (host side: check_flag).  A poll that does not see its tags after SM_POLL_CAP rounds -- every
+// round is at least one trip through memory, ~1 us: a quarter of a second, where a healthy hand-over takes ~2 us -- gives up,
+// raises SM_ERR_TIMEOUT and lets the workgroup run to its end on whatever it read: the launch always terminates, the
+// departure counter stays a multiple of N, the results are reported invalid (V2X_ESTATE) and the host re-arms the exchange.
+constexpr int SM_ERR_SOURCE = 4 << 4;                    // a source id outside its graph (same bit as k_validate_batch)
+constexpr int SM_ERR_TIMEOUT = 1 << 8;
+constexpr int SM_POLL_CAP = 1 << 18;
 
 // One layer's matrix-vector product, split so that the weights travel while the workgroup waits for something else (the
 // grid barrier, the previous layer's reduction): `request` = all of this thread's rows (<= RMAX; clamped addresses
@@ -108,14 +116,22 @@ __global__ __launch_bounds__(SM_BLOCK) void k_predict_small(SmallFwdArgs a) {
   const int row = g * N + q, slot = a.S == 1 ? 0 : q, tid = threadIdx.x;
   const bool xw_wave = tid < 128;                        // waves 0 and 1 also run the exchange: in-neighbours 0..15 / 16..31
   const int xl = tid & 63, xh = tid >> 6;                // lane = feature, half
-  unsigned* departures = a.sync + 2 * g;
+  unsigned long long* departures = a.sync + g;
   typedef const __attribute__((address_space(1))) float* gfp;
 
   // ---- requests that depend on nothing: the node's features, its CSR row, the embed weights
-  const unsigned epoch8 = 16u * (__hip_atomic_load(departures, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned)N);
-  const int e0 = a.row_ptr[row], deg = min(a.row_ptr[row + 1] - e0, 32);
+  // (the quotient of a 64-bit count: a 32-bit one would jump at its wrap in the middle of a launch whenever N is not a power
+  //  of two -- after 2^32 / N predicts per graph slot; the tag keeps its low 28 bits, which wrap together for all workgroups)
+  const unsigned epoch8 = 16u * (unsigned)((__hip_atomic_load(departures, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned long long)N) & 0x0fffffffull);
+  const int e0 = a.row_ptr[row], deg = max(0, min(a.row_ptr[row + 1] - e0, 32));
   if (tid < XE) sx[tid] = a.xe[(int64_t)row * XE + tid];
-  if (tid < deg) sNb[tid] = a.col_idx[e0 + tid];
+  if (tid < deg) {
+    // device-resident batches do not pass the host-side contract check: a source outside [0, N) would make this node poll a
+    // row of ANOTHER graph (whose tags never become this graph's) -- clamp it and report it instead
+    const int c = a.col_idx[e0 + tid];
+    if ((c < 0 || c >= N) && a.err) atomicOr(a.err, SM_ERR_SOURCE);
+    sNb[tid] = min(max(c, 0), N - 1);
+  }
   Gemv<NPF, (XE + KGF - 1) / KGF> g0;
   // stage 0: rows 0..xr-1 = [x | e], rows xr..xr+F-1 = neighbour init (zero input in the reference: skipped), then bias
   const float* W0 = a.params + a.gnn_off[0] + slot * a.gnn_sstride[0];
@@ -156,13 +172,15 @@ __global__ __launch_bounds__(SM_BLOCK) void k_predict_small(SmallFwdArgs a) {
       const unsigned long long* base = slab + (int64_t)g * N * F + xl;
       unsigned long long t[16];
       bool ok;
+      int rounds = 0;
       do {
 #pragma unroll
         for (int e = 0; e < 16; ++e) t[e] = ld_tagged(base + (int64_t)sNb[min(16 * xh + e, deg - 1)] * F);
         ok = true;
 #pragma unroll
         for (int e = 0; e < 16; ++e) ok = ok && (unsigned)(t[e] >> 32) == tag;
-      } while (!ok);
+      } while (!ok && ++rounds < SM_POLL_CAP);
+      if (!ok && xl == 0 && a.err) atomicOr(a.err, SM_ERR_TIMEOUT);      // bounded: see SM_POLL_CAP
 #pragma unroll
       for (int e = 0; e < 16; ++e)
         if (16 * xh + e < deg) acc += __uint_as_float((unsigned)t[e]);
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_predict_small(SmallFwdArgs a) {
     if (tid < C) a.q[(int64_t)row * C + tid] = o;
   }
   // ---- leave: one more departure (the next launch's epoch); nobody waits for the add
-  if (tid == 0) __hip_atomic_fetch_add(departures, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_fetch_add(departures, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace v2x

@@ -306,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
 // rows, needs two.  A workgroup knows its graph's edge count from row_ptr: with at most AD_COMPL_PER_ROW non-edges per
 // row on average it sums the columns once (fixed order), then walks the ZERO bits of each output row's mask (ascending)
 // -- LDS reads of ~4 N rows instead of N^2 / 4 MFMAs, which leaves the launch to its HBM traffic; any other graph takes
-// the MFMA product as before.  Exact for every adjacency; differs from the other forms by fp32 rounding only.  The
+// the MFMA product as before.  Valid for every adjacency (rows with fewer edges than non-edges are summed directly: decided
+// per row); differs from the other forms by fp32 rounding only.  The
 // forward needs the masks by DESTINATION (bit p of adjT[q]), the transpose by source (bit q of adj[p]): k_adj_masks
 // writes both.
 constexpr int AD_COMPL_PER_ROW = 8;
@@ -462,18 +463,29 @@ __global__ __launch_bounds__(256) void k_agg_dense(AggDenseArgs a) {
       const int64_t grow = r_begin + r;
       const f32x4 addv = a.add ? ld4(a.add + grow * a.add_stride + f0 + 4 * c) : (f32x4){0.f, 0.f, 0.f, 0.f};
       const f32x4 gate = a.mask ? ld4(a.mask + grow * a.F + f0 + 4 * c) : (f32x4){1.f, 1.f, 1.f, 1.f};
+      // Per row: through the complement only when the row HAS fewer non-edges than edges; a row with few (or no) in-neighbours
+      // inside an otherwise dense graph -- every graph of <= 8 links takes this form -- sums its edges directly, so that
+      // its result carries the rounding of its own terms, not of the whole column sum (an isolated node gets an exact 0).
+      int ones = 0;
+      for (int w = 0; w < a.mask_words; ++w) {
+        const int left = n - 32 * w;
+        if (left <= 0) break;
+        ones += __builtin_popcount(sM[r * a.mask_words + w] & (left >= 32 ? 0xffffffffu : ((1u << left) - 1u)));
+      }
+      const bool direct = 2 * ones < n;
       f32x4 miss = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int w = 0; w < a.mask_words; ++w) {
         const int left = n - 32 * w;                                        // valid bits of this word
         if (left <= 0) break;
-        unsigned z = ~sM[r * a.mask_words + w] & (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
+        const unsigned m = sM[r * a.mask_words + w];
+        unsigned z = (direct ? m : ~m) & (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
         while (z) {
           const int p = 32 * w + __builtin_ctz(z);
           z &= z - 1;
           miss += *reinterpret_cast<const f32x4*>(sT + ad_off(p, 4 * c));
         }
       }
-      f32x4 v = (S - miss) + addv;
+      f32x4 v = (direct ? miss : S - miss) + addv;
       v = gate4(v, gate);
       st4(a.out + grow * a.F + f0 + 4 * c, v);
     }

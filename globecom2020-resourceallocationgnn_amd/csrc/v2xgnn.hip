@@ -7,6 +7,7 @@
 #include "kernels_fused.hpp"
 #include "kernels_mlpwg.hpp"
 #include "kernels_small.hpp"
+#include "host_pack.hpp"
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -42,6 +43,7 @@ struct ProfRec { int id; hipEvent_t ev0, ev1; };
 
 struct GraphKey {
   int kind; const void* ptrs[12]; int sizes[6]; double scalar;
+  int64_t gen;          // workspace generation of ANOTHER model whose buffers the graph bakes in (v2x_dqn_step: the target)
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
@@ -79,7 +81,7 @@ struct v2x_model {
   bool compl_sums = true;                       // V2X_FUSED_COMPL (read at create): dense graphs aggregate through the complement
   bool small_predict = true;                    // V2X_SMALL_PREDICT (read at create): few-graph forwards in one launch (kernels_small.hpp)
   unsigned long long* small_h = nullptr;        // its exchange buffer [L + 1][SMALL_ROWS][F] tagged words
-  unsigned* small_sync = nullptr;               // and per-graph departure counters [SMALL_ROWS][2]
+  unsigned long long* small_sync = nullptr;     // and per-graph departure counters [SMALL_ROWS] (64-bit)
   char* pin_h = nullptr; char* pin_d = nullptr;  // pinned, device-mapped window for host-resident few-graph predicts: the
                                                 // kernel reads the batch and writes q THROUGH it (no copy launches)
   float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
@@ -343,6 +345,15 @@ FlagWord* global_flag() {            // the per-kernel entry points that take no
 }
 int* flag_dev_of(v2x_model* m) { return m ? m->flag_dev : global_flag()->dev; }
 
+// the one-launch predict's exchange buffer and departure counters back to their initial state (synchronous)
+int reset_exchange(v2x_model* m) {
+  if (!m->small_h) return V2X_OK;
+  HIPCHK(m, hipDeviceSynchronize());
+  HIPCHK(m, hipMemset(m->small_h, 0, (size_t)(m->L + 1) * 256 * m->F * sizeof(unsigned long long)));     // tag 0 = never written
+  HIPCHK(m, hipMemset(m->small_sync, 0, (size_t)256 * sizeof(unsigned long long)));
+  return V2X_OK;
+}
+
 // to be called after the stream was synchronised: reports and clears what the kernels raised
 int check_flag(v2x_model* m) {
   volatile int* p = m ? m->flag_host : global_flag()->host;
@@ -350,6 +361,15 @@ int check_flag(v2x_model* m) {
   const int v = *p;
   if (!v) return V2X_OK;
   *p = 0;
+  if (v & SM_ERR_TIMEOUT) {
+    // k_predict_small gave up waiting for a neighbour row (kernels_small.hpp, SM_POLL_CAP): the exchange state is not the one
+    // the launch expected -- an earlier launch of this model died half-way (departure counters between two multiples of N),
+    // or the caller corrupted it.  Re-arm it, so that the NEXT predict works, and report this one.
+    if (m) reset_exchange(m);
+    FAIL(m, V2X_ESTATE, "predict: the one-launch kernel timed out waiting for a neighbour's row (exchange buffer out of step: an "
+                        "earlier launch was aborted?); the exchange was reset, this call's q is invalid%s",
+         (v & SM_ERR_SOURCE) ? "; the batch also holds a source id outside its graph" : "");
+  }
   if (v & 1) FAIL(m, V2X_EINVAL, "batch: a graph has more rows / edges than max_nodes / max_edges allow (LDS tile guard); results are invalid");
   FAIL(m, V2X_EINVAL, "batch violates the layout contract:%s%s%s%s", (v >> 4) & 1 ? " graph sizes vs max_nodes / graph_off;" : "",
        (v >> 4) & 2 ? " row_ptr not monotone / edge counts vs max_edges;" : "", (v >> 4) & 4 ? " source id outside its graph;" : "",
@@ -402,6 +422,8 @@ int resolve_batch(v2x_model* m, const v2x_batch* b, DevBatch* d, hipStream_t st)
     FAIL(m, V2X_EINVAL, "batch: n_rows (%d) != n_graphs*n_nodes (%d*%d)", b->n_rows, b->n_graphs, m->N);
   if (m->cfg.variable_graphs && !b->graph_off) FAIL(m, V2X_EINVAL, "batch: variable_graphs needs graph_off");
   if (b->max_nodes <= 0 || b->max_edges < 0) FAIL(m, V2X_EINVAL, "batch: max_nodes/max_edges not set");
+  if (!m->cfg.variable_graphs && b->max_nodes != m->N)      // max_nodes selects kernels and sizes LDS tiles: one meaning only
+    FAIL(m, V2X_EINVAL, "batch: max_nodes (%d) must equal n_nodes (%d) for a fixed-size model", b->max_nodes, m->N);
   d->B = b->n_graphs; d->R = b->n_rows; d->E = b->n_edges;
   d->max_nodes = b->max_nodes; d->max_edges = b->max_edges;
   if (b->on_device) {
@@ -1299,7 +1321,7 @@ int launch_small_forward(v2x_model* m, hipStream_t st, const DevBatch& d, float*
   a.xe = d.xe; a.row_ptr = d.rp; a.col_idx = d.ci; a.params = m->params;
   for (int s = 0; s <= m->L; ++s) { a.gnn_off[s] = m->gnn[s].off; a.gnn_sstride[s] = m->gnn[s].slot_stride; }
   for (int i = 0; i < 4; ++i) { a.dense_off[i] = m->dense[i].off; a.dense_sstride[i] = m->dense[i].slot_stride; }
-  a.hbuf = m->small_h; a.sync = m->small_sync; a.q = q_dst ? q_dst : m->q;
+  a.hbuf = m->small_h; a.sync = m->small_sync; a.err = m->flag_dev; a.q = q_dst ? q_dst : m->q;
   a.N = m->N; a.L = m->L; a.S = m->S; a.C = m->C; a.Dn = m->Dn; a.De = m->De; a.n_rows = d.R; a.slab_rows = SMALL_ROWS;
   const dim3 grid(m->N, d.B);
 #define V2X_SMALL(FF)                                                                                   \
@@ -1580,7 +1602,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     if (hipMalloc(&ph, hb) != hipSuccess || hipMalloc(&ps, sb) != hipSuccess) return fail("allocation");
     m->small_h = static_cast<unsigned long long*>(ph);
     if (hipMemset(ph, 0, hb)) return fail("memset");             // tag 0 = never written
-    m->small_sync = static_cast<unsigned*>(ps);
+    m->small_sync = static_cast<unsigned long long*>(ps);
     void *hh = nullptr, *hdv = nullptr;
     if (env_int("V2X_SMALL_PINNED", 1) != 0 && hipHostMalloc(&hh, PIN_BYTES, hipHostMallocMapped) == hipSuccess &&
         hipHostGetDevicePointer(&hdv, hh, 0) == hipSuccess) {
@@ -1878,8 +1900,8 @@ int v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, const
   GraphKey key = make_key(4, ds, y, n_graphs_global);
   key.ptrs[6] = dn.xe; key.ptrs[7] = dn.rp; key.ptrs[8] = dn.ci; key.ptrs[9] = action; key.ptrs[10] = reward;
   key.ptrs[11] = target->q;
-  key.sizes[3] = (int)(target->ws_gen & 0x7fffffff);     // fixed-size graphs: max_nodes == N, the slot is free.  The graph bakes
-  key.scalar = gamma;                                    // in EVERY workspace pointer of the target (h, a, z, masks, ...), not q only
+  key.gen = target->ws_gen;                              // the graph bakes in EVERY workspace pointer of the target (h, a, z,
+  key.scalar = gamma;                                    // masks, ...), not q only
   CHK(run_maybe_graph(online, st, key, [&]() -> int {
     target->capturing = online->capturing;
     int rc = run_forward(target, st, dn, all, true);
@@ -2050,6 +2072,27 @@ int v2x_dqn_targets(const float* q, const float* q_next, const int32_t* action, 
   return V2X_OK;
 }
 
+// ---------------------------------------------------------------------------- dict payload -> packed host batch
+int v2x_pack_feed(const v2x_feed* f, int check_kron, float* xe_out, int32_t* row_ptr_out, int32_t* col_idx_out,
+                  float* nbr_out, int32_t* info_out) {
+  v2x_model* nullm = nullptr;
+  if (!f || !xe_out || !row_ptr_out || !col_idx_out || !info_out || !f->node || !f->edge || !f->is_f64 || !f->adjacency)
+    FAIL(nullm, V2X_EINVAL, "pack_feed: null argument");
+  if (f->n_graphs <= 0 || f->n_nodes <= 0 || f->feat_dim <= 0 || f->node_in <= 0 || f->edge_in < 0 ||
+      f->node_in + f->edge_in > XE)
+    FAIL(nullm, V2X_EINVAL, "pack_feed: bad sizes (node_in + edge_in must fit the %d-wide packed row)", XE);
+  if ((int64_t)f->n_graphs * f->n_nodes * f->n_nodes > INT32_MAX) FAIL(nullm, V2X_EINVAL, "pack_feed: batch too large");
+  for (int k = 0; k < f->n_nodes; ++k)
+    if (!f->node[k] || !f->edge[k] || (f->nbr && !f->nbr[k])) FAIL(nullm, V2X_EINVAL, "pack_feed: null input array");
+  v2x_host::FeedView v{f->n_graphs, f->n_nodes, f->feat_dim, f->node_in, f->edge_in, f->node, f->edge, f->nbr, f->is_f64, f->adjacency};
+  int bad = -1;
+  const int rc = v2x_host::pack_feed(v, check_kron != 0, xe_out, row_ptr_out, col_idx_out, nbr_out, info_out, &bad);
+  if (rc == v2x_host::PACK_NOT_01)
+    FAIL(nullm, V2X_EINVAL, "adjacency entries must be 0 or 1 (the engine aggregates unweighted edges); sample %d", bad);
+  if (rc == v2x_host::PACK_NOT_KRON) FAIL(nullm, V2X_EINVAL, "Adjacency_Matrix is not kron(Adj, I_F) (sample %d)", bad);
+  return V2X_OK;
+}
+
 // ---------------------------------------------------------------------------- contract checks
 int v2x_validate_batch(v2x_model* m, const v2x_batch* b, int32_t n_nodes, void* stream) {
   if (!b || b->n_graphs <= 0 || b->n_rows <= 0 || !b->row_ptr || (b->n_edges > 0 && !b->col_idx) || b->max_nodes <= 0 ||
@@ -2066,6 +2109,14 @@ int v2x_validate_batch(v2x_model* m, const v2x_batch* b, int32_t n_nodes, void* 
   HIPCHK(m, hipStreamSynchronize(st));
   return check_flag(m);
 }
+
+int v2x_reset_exchange(v2x_model* m) {
+  if (!m) FAIL(m, V2X_EINVAL, "null model");
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  return reset_exchange(m);
+}
+
+void* v2x_debug_exchange_counters(v2x_model* m) { return m ? (void*)m->small_sync : nullptr; }
 
 int v2x_check_errors(v2x_model* m, void* stream) {
   HIPCHK(m, hipStreamSynchronize((hipStream_t)stream));

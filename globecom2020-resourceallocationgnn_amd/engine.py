@@ -244,12 +244,16 @@ class GnnEngine(object):
         promised (its outputs are then invalid)."""
         self._check(self._lib.v2x_check_errors(self._h, self._stream()))
 
+    def reset_exchange(self):
+        """Re-arm the one-launch predict's exchange buffer (v2x_reset_exchange); a predict that times out does it by itself."""
+        self._check(self._lib.v2x_reset_exchange(self._h))
+
     def apply_gradients(self):
         self._check(self._lib.v2x_apply_gradients(self._h, self._stream()))
 
     # ------------------------------------------------------------------ measurement
     def path_info(self, batch):
-        """{'graph_layers': 'fused', 'aggregation': 'complement' | 'edge-gather' | 'dense-mfma', ...}: the kernels a fit step
+        """{'graph_layers': 'fused', 'aggregation': 'complement' | 'edge-gather' | 'dense(complement-or-mfma-per-graph)', ...}: the kernels a fit step
         of this batch runs (v2x_path_info)."""
         buf = C.create_string_buffer(256)
         s = _batch_struct(batch)

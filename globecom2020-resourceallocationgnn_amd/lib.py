@@ -30,6 +30,12 @@ class Batch(C.Structure):
                 ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p)]
 
 
+class Feed(C.Structure):
+    _fields_ = [("n_graphs", C.c_int32), ("n_nodes", C.c_int32), ("feat_dim", C.c_int32), ("node_in", C.c_int32),
+                ("edge_in", C.c_int32), ("node", C.POINTER(C.c_void_p)), ("edge", C.POINTER(C.c_void_p)),
+                ("nbr", C.POINTER(C.c_void_p)), ("is_f64", C.POINTER(C.c_uint8)), ("adjacency", C.c_void_p)]
+
+
 # every symbol include/v2xgnn.h declares: (name, restype, argtypes)
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SYMBOLS = [
@@ -61,8 +67,11 @@ SYMBOLS = [
     ("v2x_gather_rows", C.c_int, [_P, _P, _P, _L, _L, _P]),
     ("v2x_dqn_targets", C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("v2x_dqn_step", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_int32, _P, _P, C.c_int, _P]),
+    ("v2x_pack_feed", C.c_int, [C.POINTER(Feed), C.c_int, _P, _P, _P, _P, _P]),
     ("v2x_validate_batch", C.c_int, [_P, C.POINTER(Batch), _I, _P]),
     ("v2x_check_errors", C.c_int, [_P, _P]),
+    ("v2x_reset_exchange", C.c_int, [_P]),
+    ("v2x_debug_exchange_counters", _P, [_P]),
     ("v2x_debug_phase_stamps", C.c_int, [_P, _P, C.c_int]),
     ("v2x_profile_enable", C.c_int, [_P, C.c_int]),
     ("v2x_path_info", C.c_int, [_P, _P, C.c_char_p, C.c_int]),

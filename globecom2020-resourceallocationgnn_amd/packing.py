@@ -95,6 +95,19 @@ class PackedBatch(object):
         self.max_nodes = int(max_nodes) if max_nodes is not None else real_nodes
         self.max_edges = int(max_edges) if max_edges is not None else real_edges
 
+    @classmethod
+    def trusted(cls, n_graphs, n_nodes, xe, row_ptr, col_idx, max_edges, nbr=None):
+        """Fixed-size batch whose arrays were just produced by the library's own packer (v2x_pack_feed): contiguous,
+        typed and consistent by construction, so the numpy-side checks of __init__ are skipped (the C ABI re-checks
+        every host batch anyway)."""
+        self = cls.__new__(cls)
+        self.n_graphs, self.n_nodes = int(n_graphs), int(n_nodes)
+        self.xe, self.row_ptr, self.col_idx, self.nbr, self.graph_off = xe, row_ptr, col_idx, nbr, None
+        self.n_rows = xe.shape[0]
+        self.n_edges = int(col_idx.shape[0])
+        self.max_nodes, self.max_edges = int(n_nodes), int(max_edges)
+        return self
+
     def graph_bounds(self):
         """First node row of every graph, plus n_rows: [B+1] int64."""
         if self.graph_off is not None:
@@ -216,6 +229,107 @@ def feed_to_arrays(spec: GnnSpec, feed, validate_adjacency=True):
         nbr = None            # the reference always feeds zeros (BS_brain.py:478-490): skip that GEMM
     adj = kron_to_adj(A, F, validate=validate_adjacency)
     return x, e, nbr, adj
+
+
+class AdjacencyCache(object):
+    """Which `Adjacency_Matrix` array OBJECTS have passed the full Kronecker-structure check.  One replay of the
+    reference hands the same array object to predict and then to fit (BS_brain.py:603 -> :652, :716); re-reading its
+    16.8 MB (4 links x 16 features x 512 samples) to re-prove what the first call proved is the largest single cost of
+    the dict boundary.  An entry is a weak reference to the array plus its address / shape / dtype and a copy of the
+    strided sample A[:, ::F, ::F] -- the only entries the engine ever uses; a later call with the same live object and an
+    identical sample skips the scan of the other entries (they cannot have changed the result, only the verdict of the
+    check).  Any difference re-validates."""
+
+    def __init__(self, capacity=4):
+        self.capacity = capacity
+        self._entries = {}
+
+    def hit(self, A, F):
+        ent = self._entries.get(id(A))
+        if ent is None:
+            return False
+        ref, addr, shape, dtype, sample = ent
+        if ref() is not A or addr != A.ctypes.data or shape != A.shape or dtype != A.dtype:
+            del self._entries[id(A)]
+            return False
+        return bool(np.array_equal(A[:, ::F, ::F], sample))
+
+    def remember(self, A, F):
+        import weakref
+        try:
+            ref = weakref.ref(A)
+        except TypeError:
+            return
+        if len(self._entries) >= self.capacity:
+            self._entries.pop(next(iter(self._entries)))
+        self._entries[id(A)] = (ref, A.ctypes.data, A.shape, A.dtype, A[:, ::F, ::F].copy())
+
+
+_F32, _F64 = np.dtype(np.float32), np.dtype(np.float64)
+
+
+def _native_array(a):
+    """C-contiguous float32 / float64 view of an input array (anything else is converted to float64 like np.asarray
+    followed by Keras' own standardisation would)."""
+    a = np.asarray(a)
+    if (a.dtype != _F64 and a.dtype != _F32) or not a.flags.c_contiguous:
+        a = np.ascontiguousarray(a, np.float64)
+    return a
+
+
+def feed_to_packed(spec: GnnSpec, feed, validate_adjacency=True, cache=None):
+    """Reference dict payload -> PackedBatch in one pass of compiled host code (v2x_pack_feed, csrc/host_pack.hpp).
+    Same contract and error behaviour as feed_to_arrays + PackedBatch.from_dense (the numpy definition the tests compare
+    it against); `cache`: an AdjacencyCache shared by the models of one BS."""
+    import ctypes as C
+    from . import lib as _lib
+    lib = _lib.load_library()
+    N, F, Dn, De = spec.n_nodes, spec.feat_dim, spec.node_in, spec.edge_in
+    arrs = [None] * (3 * N)
+    B = None
+    for k in range(N):
+        for j, (kind, width) in enumerate((('Node', Dn), ('Edge', De), ('Neighbor', F))):
+            name = 'D%d_%s_Input' % (k + 1, kind)
+            if name not in feed:
+                raise ValueError('No data provided for "%s". Need data for each key' % name)
+            arr = _native_array(feed[name])
+            if arr.ndim != 2 or arr.shape[1] != width:
+                raise ValueError('Error when checking input: expected %s to have shape (%d,) but got array '
+                                 'with shape %r' % (name, width, arr.shape[1:]))
+            if B is None:
+                B = arr.shape[0]
+            elif arr.shape[0] != B:
+                raise ValueError('All input arrays should have the same number of samples')
+            arrs[j * N + k] = arr
+    if 'Adjacency_Matrix' not in feed:
+        raise ValueError('No data provided for "Adjacency_Matrix". Need data for each key')
+    A0 = feed['Adjacency_Matrix']
+    A = _native_array(A0)
+    if A.shape != (B, N * F, N * F):
+        raise ValueError('Error when checking input: expected Adjacency_Matrix to have shape (%d, %d) but got '
+                         'array with shape %r' % (N * F, N * F, A.shape[1:]))
+    if B == 0:
+        raise ValueError('empty batch')
+    check = bool(validate_adjacency)
+    cached = check and cache is not None and A is A0 and cache.hit(A, F)
+    ptrs = (C.c_void_p * (3 * N))(*[a.ctypes.data for a in arrs])
+    flags = (C.c_uint8 * (3 * N + 1))(*([a.dtype == _F64 for a in arrs] + [A.dtype == _F64]))
+    base = C.cast(ptrs, C.POINTER(C.c_void_p))
+    step = C.sizeof(C.c_void_p)
+    at = lambda i: C.cast(C.addressof(ptrs) + i * step, C.POINTER(C.c_void_p))
+    f = _lib.Feed(B, N, F, Dn, De, base, at(N), at(2 * N), flags, A.ctypes.data)
+    R = B * N
+    xe = np.empty((R, XE_WIDTH), np.float32)
+    row_ptr = np.empty(R + 1, np.int32)
+    col_idx = np.empty(R * N, np.int32)
+    nbr = np.empty((R, F), np.float32)
+    info = np.zeros(3, np.int32)
+    rc = lib.v2x_pack_feed(C.byref(f), int(check and not cached), xe.ctypes.data, row_ptr.ctypes.data, col_idx.ctypes.data,
+                           nbr.ctypes.data, info.ctypes.data)
+    _lib.check(lib, rc, None)
+    if check and not cached and cache is not None and A is A0:
+        cache.remember(A, F)
+    return PackedBatch.trusted(B, N, xe, row_ptr, col_idx[:int(info[0])], int(info[1]), nbr if info[2] else None)
 
 
 # ------------------------------------------------------------------------------ weights

@@ -195,6 +195,27 @@ int  v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, cons
                   const int32_t* action, const double* reward, double gamma, int32_t n_graphs_global,
                   float* y_out, float* loss_out, int loss_on_device, void* stream);
 
+/* ---- the dict payload of the reference -> a packed host batch ---------------------------------
+ * Model.predict / Model.fit of the reference take, per call, 3 N arrays 'D{k}_Node_Input' [B][Dn], 'D{k}_Edge_Input'
+ * [B][De], 'D{k}_Neighbor_Input' [B][F] and the dense 'Adjacency_Matrix' [B][N F][N F] = kron(Adj, I_F)
+ * (BS_brain.py:492-504, :603, :642-651, :704-716).  v2x_pack_feed turns that payload into the arrays of a host v2x_batch
+ * in one pass of compiled host code (csrc/host_pack.hpp; no GPU involved): xe_out [B N][16], row_ptr_out [B N + 1],
+ * col_idx_out [capacity B N N], nbr_out [B N][F] (written only when some Neighbor_Input entry is non-zero -- the
+ * reference always feeds zeros, :478-490), info_out = {n_edges, max_edges, neighbour input non-zero}.
+ * Every array is C-contiguous float32 or float64 (is_f64[3 N + 1]: node[0..N), edge[0..N), nbr[0..N), adjacency).
+ * check_kron != 0: V2X_EINVAL unless the adjacency is exactly kron(Adj, I_F); entries other than 0 / 1 are always
+ * V2X_EINVAL (the engine aggregates unweighted edges).  Error text: v2x_last_error(NULL).                              */
+typedef struct v2x_feed {
+  int32_t n_graphs, n_nodes, feat_dim, node_in, edge_in;
+  const void* const* node;        /* [n_nodes] pointers */
+  const void* const* edge;        /* [n_nodes] pointers */
+  const void* const* nbr;         /* [n_nodes] pointers, or NULL */
+  const uint8_t* is_f64;          /* [3 * n_nodes + 1] */
+  const void* adjacency;
+} v2x_feed;
+int  v2x_pack_feed(const v2x_feed* feed, int check_kron, float* xe_out, int32_t* row_ptr_out, int32_t* col_idx_out,
+                   float* nbr_out, int32_t* info_out);
+
 /* ---- contract checks -------------------------------------------------------------------
  * The kernels size their LDS tiles from max_nodes / max_edges and rely on the CSR contract above (sources inside
  * their graph, strictly ascending => no duplicates).  HOST batches are checked on every call before anything is copied
@@ -204,6 +225,13 @@ int  v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, cons
  * that synchronises with the host (host-side q / loss outputs) or by v2x_check_errors.                              */
 int  v2x_validate_batch(v2x_model* m, const v2x_batch* b, int32_t n_nodes, void* stream);
 int  v2x_check_errors(v2x_model* m, void* stream);
+/* The one-launch rollout predict (csrc/kernels_small.hpp) hands node rows between its workgroups through an exchange buffer
+ * whose only state across launches is a per-graph departure count.  A launch that was aborted half-way leaves that state out
+ * of step; the next predict then does not hang: its polls are bounded, it raises a flag and the synchronising call returns
+ * V2X_ESTATE after re-arming the exchange by itself.  v2x_reset_exchange does the same re-arming on request (synchronises
+ * the device).  v2x_debug_exchange_counters: [dev] pointer to the 256 64-bit departure counters (tests corrupt one on purpose). */
+int  v2x_reset_exchange(v2x_model* m);
+void* v2x_debug_exchange_counters(v2x_model* m);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* When enabled, every kernel launch of this model is bracketed by HIP events on its stream
@@ -212,7 +240,8 @@ int  v2x_profile_enable(v2x_model* m, int enable);
 /* Which kernels a fit step of `b` runs on this model, as text ("graph_layers=fused aggregation=complement mlp=train_wg
  * handoff=fragment-major"): the aggregation is the general edge-index gather / segment sum of AggLayer.call
  * (BS_brain.py:69-76) unless the batch is dense enough for one of its rewritings -- through the complement in the fused
- * graph-layer kernels ("complement"), as an MFMA product with adjacency bit masks for large graphs ("dense-mfma").
+ * graph-layer kernels ("complement"), per graph through the complement or as an MFMA product with adjacency bit masks for large dense graphs
+ * ("dense(complement-or-mfma-per-graph)").
  * Only sizes and null-ness of the batch pointers are read.  bench.py prints it in `config.aggregation`.              */
 int  v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap);
 /* Models created with V2X_FUSED_TS=1 in the environment run a measurement build of the fused forward kernel in which

@@ -85,6 +85,12 @@ class ShardedOracle(object):
         self.opt = KerasAdam()
         ctx = mp.get_context("spawn")              # not fork: the parent may hold an initialised HIP runtime
         self.conns, self.procs = [], []
+        # one BLAS thread per worker, also when threadpoolctl is missing: the spawned interpreters read these when they
+        # import numpy (`workers` x the full BLAS pool would understate the all-cores leg)
+        import os
+        saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+        for k in saved:
+            os.environ[k] = "1"
         B, N = x.shape[0], x.shape[1]
         for r in range(workers):
             g0, g1 = r * B // workers, (r + 1) * B // workers
@@ -96,6 +102,11 @@ class ShardedOracle(object):
             p.start()
             self.conns.append(a)
             self.procs.append(p)
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         try:
             self._expect("ready", 120.0)
         except Exception:

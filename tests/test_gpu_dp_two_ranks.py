@@ -141,7 +141,7 @@ def test_bench_two_ranks_on_one_gpu(scaling, batch, global_batch, per_gpu):
     env = dict(os.environ, V2X_BENCH_ONE_DEVICE="1", V2X_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29551", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--min-seconds", "0",
-           "--batch", str(batch), "--no-cpu-baseline", "--no-roofline"] + (["--scaling", scaling] if scaling else [])
+           "--batch", str(batch), "--no-cpu-baseline", "--no-roofline", "--no-weak-pass"] + (["--scaling", scaling] if scaling else [])
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -153,3 +153,28 @@ def test_bench_two_ranks_on_one_gpu(scaling, batch, global_batch, per_gpu):
     assert (res["metric"] == BASELINE_METRIC) == (global_batch == 4096)
     assert res["config"]["aggregation"] in ("complement", "edge-gather")
     assert abs(res["value"] - global_batch * 5 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-3
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py re-executes itself through
+    torch.distributed.run with two ranks (both on the box's one GPU here, gloo collective), and the one line carries BOTH
+    regimes -- the strong-scaling value of the metric (global batch fixed) and a second timed pass at --batch graphs per GPU
+    (config.weak) -- plus the ranks the process group really had."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(V2X_BENCH_ONE_DEVICE="1", V2X_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--min-seconds", "0",
+           "--batch", "512", "--no-roofline"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["ranks_seen"] == 2 and res["config"]["collective_backend"] == "gloo"
+    assert res["scaling"] == "strong" and res["config"]["global_batch"] == 512 and res["config"]["graphs_per_gpu"] == 256
+    weak = res["config"]["weak"]
+    assert weak["graphs_per_gpu"] == 512 and weak["global_batch"] == 1024 and weak["value"] > 0
+    assert res["aggregation"] == "edge-gather" and res["fast_path"]["aggregation"] == "complement" and res["fast_path"]["value"] > 0

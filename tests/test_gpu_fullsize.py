@@ -13,7 +13,7 @@ import v2xgnn
 from v2xgnn import GnnSpec, PackedBatch, GnnEngine
 from oracle import compact as oc
 from oracle.keras_semantics import KerasAdam
-from util import assert_close, assert_grad_close, assert_fwd_close, assert_grads_match_oracle, f32_params, oracle_step
+from util import MAX_GATE_FLIPS, assert_close, assert_grad_close, assert_fwd_close, assert_grads_match_oracle, f32_params, oracle_step
 
 pytestmark = pytest.mark.gpu
 N, F, B = 20, 64, 4096
@@ -31,14 +31,18 @@ def setup():
     return spec, w, x, e, adj, y
 
 
-def _training_engine(spec):
+def _training_engine(spec, edge_gather=False):
     """forward() on the training path's kernels: the loss is differentiated at the q of `forward` (the few-graph predict
-    kernel has its own summation order and its own tests)."""
+    kernel has its own summation order and its own tests).  edge_gather: the fused graph layers aggregate with the general
+    edge-index gather / segment sum (V2X_FUSED_COMPL=0, read at create) instead of through the complement."""
     os.environ["V2X_SMALL_PREDICT"] = "0"
+    if edge_gather:
+        os.environ["V2X_FUSED_COMPL"] = "0"
     try:
         return GnnEngine(spec)
     finally:
         del os.environ["V2X_SMALL_PREDICT"]
+        os.environ.pop("V2X_FUSED_COMPL", None)
 
 
 def _parity_with_oracle(spec, P, pb, x, e, graph, what, adam=True, engine=None):
@@ -60,6 +64,8 @@ def _parity_with_oracle(spec, P, pb, x, e, graph, what, adam=True, engine=None):
     g_ref, n_cand, n_flip = assert_grads_match_oracle(got, P, ref, what)
     print("%s: every gradient element within tolerance of the oracle's (%d ReLU gates at rounding distance of 0 taken the "
           "kernels' way, of %d candidates)" % (what, n_flip, n_cand))
+    assert n_flip <= MAX_GATE_FLIPS, (what, "the checker resolved %d ReLU gates the kernels' way (of %d candidates): too many "
+                                            "to be rounding at the gate" % (n_flip, n_cand))
     if adam:
         eng.apply_gradients()
         params = oc.cast_params(P, np.float64)
@@ -77,10 +83,13 @@ def _parity_with_oracle(spec, P, pb, x, e, graph, what, adam=True, engine=None):
     eng.close()
 
 
+@pytest.mark.parametrize("aggregation", ["edge-gather", "complement"])
 @pytest.mark.parametrize("shared", [False, True])
-def test_cfg2_full_size_vs_oracle(shared):
+def test_cfg2_full_size_vs_oracle(shared, aggregation):
     """BASELINE configs[1] in full: B = 4096 graphs of 20 links, F = 64, L = 2 -- the 256 lock-stepped fused workgroups,
-    the 11 x 24-tile shares of k_mlp_train_wg, the 6 x 704-row chunks and 11-slab sums of k_wgrad / k_reduce_adam."""
+    the 11 x 24-tile shares of k_mlp_train_wg, the 6 x 704-row chunks and 11-slab sums of k_wgrad / k_reduce_adam -- with
+    BOTH aggregation forms of the fused graph layers: the general edge-index gather / segment sum north_star names (the
+    form bench.py's `value` runs) and the complement rewriting (the default for these complete-minus-two graphs)."""
     import bench
     rng = np.random.default_rng(2025 + shared)
     x, e, adj, _ = bench.synth_batch(rng, B, N)
@@ -88,8 +97,11 @@ def test_cfg2_full_size_vs_oracle(shared):
     P = f32_params(spec, rng)
     pb = PackedBatch.from_dense(x, e, adj)
     graph = ((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
+    eng = _training_engine(spec, edge_gather=aggregation == "edge-gather")
+    info = eng.path_info(pb)
+    assert info["graph_layers"] == "fused" and info["aggregation"] == aggregation, info
     _parity_with_oracle(spec, P, pb, x.reshape(B * N, -1), e.reshape(B * N, -1), graph,
-                        "configs[1] B=4096 %s" % ("shared" if shared else "per-node"))
+                        "configs[1] B=4096 %s, %s" % ("shared" if shared else "per-node", aggregation), engine=eng)
 
 
 def test_cfg3_share_vs_oracle():

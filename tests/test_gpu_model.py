@@ -319,7 +319,7 @@ def test_rccl_path_single_rank(tmp_path):
     env = dict(os.environ, V2X_FORCE_DP="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--min-seconds", "0",
-           "--batch", "256", "--no-cpu-baseline", "--no-roofline"]
+           "--batch", "256", "--no-cpu-baseline", "--no-roofline", "--no-dropin", "--no-other-workloads"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]

@@ -166,3 +166,75 @@ def test_small_predict_soak_bitwise_repeatable_across_launches_models_and_batch_
         torch.cuda.synchronize()
         a.close()
         b.close()
+
+
+def _exchange_counters(eng, n):
+    """torch view (no copy) of the first n 64-bit departure counters of the one-launch predict's exchange."""
+    import torch
+    ptr = int(eng._lib.v2x_debug_exchange_counters(eng._h))
+
+    class _H(object):
+        pass
+    h = _H()
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 2, "strides": None}
+    return torch.as_tensor(h, device="cuda:%d" % eng.device)
+
+
+def test_small_predict_out_of_step_exchange_times_out_instead_of_hanging():
+    """VERDICT r03 item 8 / ADVICE: the tagged-word polls of k_predict_small were unbounded.  Here the departure counter of a
+    graph is bumped by a multiple of N from another stream WHILE predicts run, so workgroups of one launch read different
+    epochs and wait for tags nobody writes.  The launch must terminate (bounded polls), the call must report V2X_ESTATE, the
+    library must re-arm the exchange by itself, and the next predicts must be right again.  Also: a device batch with a source
+    id outside its graph is reported (V2X_EINVAL) instead of polling a foreign row, and v2x_reset_exchange works on request."""
+    import time
+    import torch
+    import v2xgnn
+    N, F, B = 20, 64, 4
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(3)
+    eng = GnnEngine(spec)
+    eng.set_weights(oc.params_to_list(f32_params(spec, rng)))
+    x, e, adj = random_inputs(rng, B, N, ref_topology=True)
+    pb = PackedBatch.from_dense(x, e, adj)
+    q0 = eng.forward(pb)
+    assert eng.path_info(pb)["graph_layers"] == "fused"
+    cnt = _exchange_counters(eng, 256)
+    torch.cuda.synchronize()
+    assert int(cnt[0].item()) == N and int(cnt[B - 1].item()) == N and int(cnt[B].item()) == 0     # one launch: N departures per graph
+    side = torch.cuda.Stream()
+    seen = 0
+    t_max = 0.0
+    for attempt in range(60):
+        with torch.cuda.stream(side):
+            for _ in range(300):                      # ~1.5 ms of back-to-back bumps: whole epochs, mid-launch
+                cnt[:B].add_(7 * N)
+        t0 = time.perf_counter()
+        try:
+            q = eng.forward(pb)
+            assert q.shape == q0.shape
+        except v2xgnn.lib.V2XError as exc:
+            assert "timed out" in str(exc)
+            seen += 1
+        t_max = max(t_max, time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        if seen >= 2:
+            break
+    assert seen >= 1, "60 predicts raced against 18,000 counter bumps and none saw an out-of-step exchange"
+    assert t_max < 20.0, "a timed-out predict took %.1f s" % t_max
+    torch.cuda.synchronize()
+    # the library re-armed the exchange when it reported the time-out: predicts are right again, bit for bit
+    for _ in range(5):
+        assert np.array_equal(eng.forward(pb), q0)
+    eng.reset_exchange()
+    torch.cuda.synchronize()
+    assert int(cnt[0].item()) == 0
+    assert np.array_equal(eng.forward(pb), q0)
+    # a device batch with a source id outside its graph: reported, no hang
+    db = eng.to_device(pb)
+    db.col_idx[5] = N + 3
+    out = eng.forward(db)
+    with pytest.raises(ValueError, match="source id outside its graph"):
+        eng.check_errors()
+    assert out.shape == (B * N, 4)
+    assert np.array_equal(eng.forward(pb), q0)
+    eng.close()

@@ -308,3 +308,131 @@ def test_packed_batch_rejects_understated_tile_sizes_and_broken_csr():
     bad = pb.col_idx.copy(); bad[pb.row_ptr[r] + 1] = bad[pb.row_ptr[r]]
     with pytest.raises(ValueError, match="ascending"):
         PackedBatch(3, 5, pb.xe, pb.row_ptr, bad).validate()
+
+
+# ------------------------------------------------------------------------------ drop-in boundary: compiled packer
+def _ref_payload(rng, B, N, F, p_edge=0.6, nbr=False, dtype=np.float64):
+    adj = (rng.random((B, N, N)) < p_edge).astype(np.float64)
+    feed = {}
+    for k in range(N):
+        feed['D%d_Node_Input' % (k + 1)] = rng.normal(size=(B, 9)).astype(dtype)
+        feed['D%d_Edge_Input' % (k + 1)] = rng.normal(size=(B, 4)).astype(dtype)
+        feed['D%d_Neighbor_Input' % (k + 1)] = (rng.normal(size=(B, F)) if nbr else np.zeros((B, F))).astype(dtype)
+    feed['Adjacency_Matrix'] = np.kron(adj, np.eye(F)).astype(dtype)
+    return feed, adj
+
+
+@pytest.mark.parametrize("B,N,F,dtype,nbr", [(1, 4, 16, np.float64, False), (37, 4, 16, np.float64, False),
+                                              (5, 4, 16, np.float32, True), (3, 20, 64, np.float64, False),
+                                              (600, 4, 16, np.float64, True)])
+def test_native_packer_equals_the_numpy_definition(B, N, F, dtype, nbr):
+    """v2x_pack_feed (csrc/host_pack.hpp: the reference's dict payload -> packed batch in one pass of compiled host code) against
+    packing.feed_to_arrays + PackedBatch.from_dense, the numpy definition: identical xe rows, CSR, max_edges, neighbour input."""
+    from v2xgnn.packing import feed_to_packed, feed_to_arrays
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    feed, adj = _ref_payload(np.random.default_rng(B + N), B, N, F, nbr=nbr, dtype=dtype)
+    x, e, nb, a = feed_to_arrays(spec, feed, True)
+    ref = PackedBatch.from_dense(x, e, a, nb)
+    for validate in (True, False):
+        got = feed_to_packed(spec, feed, validate)
+        for f in ('xe', 'row_ptr', 'col_idx'):
+            assert np.array_equal(getattr(ref, f), getattr(got, f)), f
+        assert (got.n_graphs, got.n_nodes, got.n_rows, got.n_edges, got.max_nodes, got.max_edges) == \
+               (ref.n_graphs, ref.n_nodes, ref.n_rows, ref.n_edges, ref.max_nodes, ref.max_edges)
+        assert (got.nbr is None) == (ref.nbr is None) and (ref.nbr is None or np.array_equal(got.nbr, ref.nbr))
+        got.validate()
+    # non-contiguous / integer inputs are standardised like np.asarray would
+    feed2 = dict(feed)
+    feed2['D1_Node_Input'] = np.asfortranarray(feed['D1_Node_Input'])
+    feed2['Adjacency_Matrix'] = feed['Adjacency_Matrix'].astype(np.int64)
+    assert np.array_equal(feed_to_packed(spec, feed2, True).col_idx, ref.col_idx)
+
+
+def test_native_packer_rejects_what_the_numpy_definition_rejects():
+    from v2xgnn.packing import feed_to_packed
+    spec = GnnSpec()
+    B, N, F = 70, 4, 16
+    feed, adj = _ref_payload(np.random.default_rng(5), B, N, F)
+    NF = N * F
+
+    def bad_adj(mutate):
+        A = feed['Adjacency_Matrix'].copy()
+        mutate(A)
+        return dict(feed, Adjacency_Matrix=A)
+    cases = {
+        "off-diagonal entry inside a block": lambda A: A.__setitem__((69, 0, 5), 1.0),
+        "off-diagonal entry, last row": lambda A: A.__setitem__((33, NF - 1, 0), 1e-300),
+        "diagonal of a block not constant": lambda A: A.__setitem__((12, 1 * F + 3, 2 * F + 3), 1.0 - A[12, 1 * F + 3, 2 * F + 3]),
+        "NaN off the diagonals": lambda A: A.__setitem__((0, 2, 9), np.nan),
+        "weighted edge": lambda A: A.__setitem__((4, slice(None), slice(None)), 2.0 * A[4]),
+    }
+    for name, mut in cases.items():
+        with pytest.raises(ValueError):
+            feed_to_packed(spec, bad_adj(mut), True)
+        with pytest.raises(ValueError):                      # the numpy definition agrees
+            x, e, nb, a = v2xgnn.feed_to_arrays(spec, bad_adj(mut), True)
+            PackedBatch.from_dense(x, e, a, nb)
+    # a negative zero off the diagonals IS kron(Adj, I_F) (numpy: -0.0 == 0)
+    ok = bad_adj(lambda A: A.__setitem__((3, 0, 5), -0.0))
+    assert np.array_equal(feed_to_packed(spec, ok, True).col_idx, feed_to_packed(spec, feed, True).col_idx)
+    for mutate in ('drop', 'shape', 'adjshape', 'samples'):
+        bad = dict(feed)
+        if mutate == 'drop':
+            del bad['D3_Neighbor_Input']
+        elif mutate == 'shape':
+            bad['D1_Edge_Input'] = np.zeros((B, 5))
+        elif mutate == 'samples':
+            bad['D2_Node_Input'] = np.zeros((B + 1, 9))
+        else:
+            bad['Adjacency_Matrix'] = np.zeros((B, 32, 32))
+        with pytest.raises(ValueError):
+            feed_to_packed(spec, bad, True)
+
+
+def test_adjacency_cache_skips_only_what_it_has_seen():
+    """One replay of the reference hands the same Adjacency_Matrix object to predict and to fit (BS_brain.py:603 -> :652, :716):
+    the second call skips the Kronecker scan, but only for the same live object with an unchanged strided sample."""
+    from v2xgnn.packing import feed_to_packed, AdjacencyCache
+    spec = GnnSpec()
+    feed, adj = _ref_payload(np.random.default_rng(6), 16, 4, 16)
+    cache = AdjacencyCache()
+    A = feed['Adjacency_Matrix']
+    assert not cache.hit(A, 16)
+    ref = feed_to_packed(spec, feed, True, cache)
+    assert cache.hit(A, 16)
+    assert np.array_equal(feed_to_packed(spec, dict(feed), True, cache).col_idx, ref.col_idx)
+    # an equal COPY is another object: not a hit
+    assert not cache.hit(A.copy(), 16)
+    # the engine-visible entries changed in place: not a hit, and the new adjacency is what gets packed
+    A[2, 0 * 16:1 * 16, 1 * 16:2 * 16] = (1.0 - A[2, 0, 16]) * np.eye(16)
+    assert not cache.hit(A, 16)
+    got = feed_to_packed(spec, feed, True, cache)
+    x, e, nb, a = v2xgnn.feed_to_arrays(spec, feed, True)
+    assert np.array_equal(got.col_idx, PackedBatch.from_dense(x, e, a, nb).col_idx)
+    # a broken structure in a NEW object is still caught with the cache in place
+    B2 = A.copy()
+    B2[1, 0, 7] = 1.0
+    with pytest.raises(ValueError):
+        feed_to_packed(spec, dict(feed, Adjacency_Matrix=B2), True, cache)
+    # the cache holds weak references only
+    import gc
+    n0 = len(cache._entries)
+    del A, feed, got
+    gc.collect()
+    assert all(ent[0]() is None for ent in cache._entries.values()) or len(cache._entries) <= n0
+
+
+def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it must start its ranks itself (it used to
+    SystemExit).  Without a GPU each rank stops at the engine's no-CPU-fallback check -- AFTER the launch: both ranks report
+    it, and the exit code is the launcher's."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert out.stderr.count("bench.py needs a GPU") >= 2, out.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in out.stderr

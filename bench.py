@@ -85,7 +85,8 @@ def algorithmic_flops(name, R, F, L, C=4, Dn=9, De=4):
     table["k_gnn_fwd_fused"] = embed + L * gnn                        # embed + L stages (graph-major fused launch)
     table["k_gnn_bwd_fused"] = L * table["k_node_dgrad"]              # L data gradients
     if F >= 128:
-        table["k_wgrad_gnn"] = gnn                       # wide path: one launch per stage
+        table["k_wgrad_gnn"] = gnn                       # wide path: one launch per stage ...
+        table["k_wgrad_wide_all"] = L * gnn + embed + dense0     # ... or all graph layers + Dense-0 as roles of one grid
     return table.get(name)
 
 
@@ -128,6 +129,7 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
         table["k_mlp_bwd"] = 4 * R * (80 + 40 + 20 + 2 * C) + 4 * R * (80 + 40 + 20 + C)
         table["k_wgrad_dense"] = 4 * R * (80 + 40) + 4 * R * (40 + 20) + 4 * R * (20 + C)
         table["k_wgrad_gnn"] = wg_gnn
+        table["k_wgrad_wide_all"] = L * wg_gnn + wg_embed + table["k_wgrad_dense0"]
     return table.get(name)
 
 

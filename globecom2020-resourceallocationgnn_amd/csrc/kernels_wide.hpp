@@ -31,37 +31,51 @@ struct WideGemmArgs {
   int n_idx, row_stride, base_mul, idx_base;
 };
 
-constexpr int WD_TM = 128, WD_KC = 16, WD_LDB = WD_KC + 4;
+constexpr int WD_TM = 128, WD_KC = 16;
 
-// NT = output tile width in 16-column MFMA tiles (5: Dense-0's 80 outputs, 8: F = 128, 16: 256 columns).  The tile
-// spans the layer's WHOLE output width where it can: a 64-column tile made every activation row travel through
-// L2/HBM once per 64 output columns (4x at F = 256, 1.3 GB per launch at 100 links x 1024 graphs -- that traffic,
-// not the MFMA pipe, set the 278 us), and 16-column tiles x 16 give 128 MFMAs per wave between barriers instead of 32.
-template <bool TRANS, int NT>
+// NT = output tile width in 16-column MFMA tiles (4: 64 columns; 5: Dense-0's 80 outputs as one strip), RT = 16-row tiles per
+// wave (workgroup tile = 64 RT rows), KC = K depth of an LDS chunk (16 or 32: MFMAs between two workgroup barriers =
+// 2 KC / 16 x RT x NT per wave).  Measured at configs[3]'s share: 64-column tiles at 2 workgroups per CU beat
+// whole-width tiles (L2 absorbs the operand re-reads, occupancy matters more).
+template <bool TRANS, int NT, int RT = 2, int KC = WD_KC>
 __global__ __launch_bounds__(256, 2) void k_wide_gemm(WideGemmArgs a) {
+  constexpr int TM = 64 * RT, LDB = KC + 4;
   constexpr int TN = 16 * NT, LDA = TN + 4;
-  constexpr int PA = (64 * NT + 255) / 256;                      // float4 passes of the weight chunk [16][TN]
-  __shared__ __attribute__((aligned(16))) float sA[2][WD_KC * LDA];      // weights  [k][n]
-  __shared__ __attribute__((aligned(16))) float sB[2][WD_TM * WD_LDB];   // activations [row][k]
-  const int slot = blockIdx.z, m0 = blockIdx.x * WD_TM, n0 = blockIdx.y * TN;
+  constexpr int PA = (KC * NT + 63) / 64;                        // float4 passes of the weight chunk [KC][TN]
+  constexpr int NA = KC * NT * 4;                                // float4 elements of the weight chunk
+  constexpr int PB = TM * KC / 1024;                             // float4 passes of the activation chunk [TM][KC]
+  constexpr int CPR = KC / 4;                                    // float4 per activation row of the chunk
+  __shared__ __attribute__((aligned(16))) float sA[2][KC * LDA];         // weights  [k][n]
+  __shared__ __attribute__((aligned(16))) float sB[2][TM * LDB];         // activations [row][k]
+  const int slot = blockIdx.z, m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
   const float* Wg = a.W + slot * a.slot_stride;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, kg = lane >> 4;
 
-  // global -> register staging roles
-  const int rB = tid >> 2, cB = (tid & 3) << 2;                 // activation rows rB and rB + 64, 4 k-columns
-  const int64_t rowg0 = (int64_t)(a.idx_base + min(m0 + rB, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
-  const int64_t rowg1 = (int64_t)(a.idx_base + min(m0 + rB + 64, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
+  // global -> register staging roles: pass p covers activation rows (tid + 256 p) / CPR, 4 k-columns each
+  int64_t rowg[PB];
+#pragma unroll
+  for (int p = 0; p < PB; ++p)
+    rowg[p] = (int64_t)(a.idx_base + min(m0 + (tid + 256 * p) / CPR, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
+  const int cB = (tid % CPR) << 2;
 
-  const int n_chunks = a.k_total / WD_KC;
-  auto gload = [&](int kc, float4 (&va)[PA], float4& vb0, float4& vb1) {
-    int kcol = kc * WD_KC;
+  const int n_chunks = (a.k_total + KC - 1) / KC;
+  auto gload = [&](int kc, float4 (&va)[PA], float4 (&vb)[PB]) {
+    // a thread's 4 k-columns never straddle two segments (widths are multiples of 16), a KC = 32 chunk may: the segment is
+    // resolved per thread; columns past the end of the contraction (k_total is a multiple of 16, not of 32) are zeroed
+    int kcol = kc * KC + cB;
+    const bool kin = kcol < a.k_total;
+    if (!kin) kcol = 0;
     const float* p = a.seg[0].ptr; int st = a.seg[0].stride;
     if (a.n_seg > 1 && kcol >= a.seg[0].width) {
       kcol -= a.seg[0].width; p = a.seg[1].ptr; st = a.seg[1].stride;
       if (a.n_seg > 2 && kcol >= a.seg[1].width) { kcol -= a.seg[1].width; p = a.seg[2].ptr; st = a.seg[2].stride; }
     }
-    vb0 = *reinterpret_cast<const float4*>(p + rowg0 * st + kcol + cB);
-    vb1 = *reinterpret_cast<const float4*>(p + rowg1 * st + kcol + cB);
+    const float mkb = kin ? 1.f : 0.f;
+#pragma unroll
+    for (int q = 0; q < PB; ++q) {
+      const float4 t = *reinterpret_cast<const float4*>(p + rowg[q] * st + kcol);
+      vb[q] = KC == WD_KC ? t : make_float4(t.x * mkb, t.y * mkb, t.z * mkb, t.w * mkb);
+    }
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int i = tid + 256 * q;
@@ -69,78 +83,83 @@ __global__ __launch_bounds__(256, 2) void k_wide_gemm(WideGemmArgs a) {
       int64_t off;
       if (!TRANS) {                        // k row i / (4 NT), 4 output columns
         const int ka = i / (4 * NT), col = n0 + ((i % (4 * NT)) << 2);
-        const int rr = real_row(a.pad, kc * WD_KC + min(ka, WD_KC - 1));
-        ok = i < 64 * NT && col < a.n_real && rr >= 0;
+        const int kk = kc * KC + min(ka, KC - 1);
+        const int rr = kk < a.k_total ? real_row(a.pad, kk) : -1;
+        ok = i < NA && col < a.n_real && rr >= 0;
         off = (int64_t)rr * a.n_real + col;
-      } else {                             // output column i >> 2, 4 k values
-        const int nT = n0 + (i >> 2), ka = (i & 3) << 2;
-        ok = i < 64 * NT && nT < a.n_out;
-        off = (int64_t)(nT < a.split ? nT : nT + a.skip) * a.n_real + kc * WD_KC + ka;
+      } else {                             // output column i / (KC / 4), 4 k values
+        const int nT = n0 + i / CPR, ka = (i % CPR) << 2;
+        ok = i < NA && nT < a.n_out && kc * KC + ka < a.k_total;
+        off = (int64_t)(nT < a.split ? nT : nT + a.skip) * a.n_real + kc * KC + ka;
       }
       const float4 t = *reinterpret_cast<const float4*>(Wg + (ok ? off : 0));
       const float mk = ok ? 1.f : 0.f;
       va[q] = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
     }
   };
-  auto lstore = [&](int buf, const float4 (&va)[PA], const float4& vb0, const float4& vb1) {
-    *reinterpret_cast<float4*>(&sB[buf][rB * WD_LDB + cB]) = vb0;
-    *reinterpret_cast<float4*>(&sB[buf][(rB + 64) * WD_LDB + cB]) = vb1;
+  auto lstore = [&](int buf, const float4 (&va)[PA], const float4 (&vb)[PB]) {
+#pragma unroll
+    for (int q = 0; q < PB; ++q)
+      *reinterpret_cast<float4*>(&sB[buf][((tid + 256 * q) / CPR) * LDB + cB]) = vb[q];
 #pragma unroll
     for (int q = 0; q < PA; ++q) {
       const int i = tid + 256 * q;
-      if (i >= 64 * NT) continue;
+      if (i >= NA) continue;
       if (!TRANS) {
         *reinterpret_cast<float4*>(&sA[buf][(i / (4 * NT)) * LDA + ((i % (4 * NT)) << 2)]) = va[q];
       } else {
-        const int na = i >> 2, ka = (i & 3) << 2;
+        const int na = i / CPR, ka = (i % CPR) << 2;
         sA[buf][(ka + 0) * LDA + na] = va[q].x; sA[buf][(ka + 1) * LDA + na] = va[q].y;
         sA[buf][(ka + 2) * LDA + na] = va[q].z; sA[buf][(ka + 3) * LDA + na] = va[q].w;
       }
     }
   };
 
-  f32x4 acc[2][NT];
+  f32x4 acc[RT][NT];
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
+  for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 va[PA], vb0, vb1;
-  gload(0, va, vb0, vb1);
-  lstore(0, va, vb0, vb1);
+  float4 va[PA], vb[PB];
+  gload(0, va, vb);
+  lstore(0, va, vb);
   __syncthreads();
 #pragma unroll 1
   for (int kc = 0; kc < n_chunks; ++kc) {
     const int buf = kc & 1;
     // unconditional (clamped) prefetch: a load under `if` makes hipcc wait for it at the join, i.e. BEFORE the
     // MFMAs it is supposed to overlap; the last iteration re-loads its own chunk into the idle buffer
-    gload(min(kc + 1, n_chunks - 1), va, vb0, vb1);
+    gload(min(kc + 1, n_chunks - 1), va, vb);
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 b[2];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) b[rt] = ld4(&sB[buf][(32 * wv + 16 * rt + j) * WD_LDB + 4 * kg]);
+    for (int g = 0; g < KC / 16; ++g) {
+      f32x4 b[RT];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      float w[NT];
+      for (int rt = 0; rt < RT; ++rt) b[rt] = ld4(&sB[buf][(16 * RT * wv + 16 * rt + j) * LDB + 16 * g + 4 * kg]);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) w[nt] = sA[buf][(4 * kg + s) * LDA + nt * 16 + j];
+      for (int s = 0; s < 4; ++s) {
+        float w[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) w[nt] = sA[buf][(16 * g + 4 * kg + s) * LDA + nt * 16 + j];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) acc[rt][nt] = V2X_MFMA(w[nt], b[rt][s], acc[rt][nt]);
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = V2X_MFMA(w[nt], b[rt][s], acc[rt][nt]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    lstore(buf ^ 1, va, vb0, vb1);
+    lstore(buf ^ 1, va, vb);
     __syncthreads();
   }
 
-  // epilogue: lane holds out[row 32*wv + 16*rt + j][n0 + nt*16 + 4*kg .. +3]
+  // epilogue: lane holds out[row 16*RT*wv + 16*rt + j][n0 + nt*16 + 4*kg .. +3]
   const float* bias = Wg + (int64_t)a.pad.k_real * a.n_real;
 #pragma unroll
-  for (int rt = 0; rt < 2; ++rt) {
-    const int idx = m0 + 32 * wv + 16 * rt + j;
+  for (int rt = 0; rt < RT; ++rt) {
+    const int idx = m0 + 16 * RT * wv + 16 * rt + j;
     if (idx >= a.n_idx) continue;
-    const int64_t rowg = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
+    const int64_t rowo = (int64_t)(a.idx_base + idx) * a.row_stride + slot * a.base_mul;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int col = n0 + nt * 16 + 4 * kg;
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_wide_gemm(WideGemmArgs a) {
       f32x4 v = acc[rt][nt];
       if (!TRANS && a.has_bias) v = v + ld4(bias + col);
       if (!TRANS && a.relu) v = relu4(v);
-      st4(a.out + rowg * a.out_stride + col, v);
+      st4(a.out + rowo * a.out_stride + col, v);
     }
   }
 }
@@ -157,6 +176,10 @@ __global__ __launch_bounds__(256, 2) void k_wide_gemm(WideGemmArgs a) {
 struct WideWgradArgs {
   WideSeg seg[3]; int n_seg;             // K operand; a 64-wide K tile never straddles two segments
   int seg_kpad[3];                       // padded K row where each segment starts
+  // optional 16-wide segment (the packed [x | e] rows) that rides on the workgroup of K tile 0 instead of owning a K tile:
+  // as a tile of its own it cost a full KW x TN tile's MFMAs for 16 / KW useful rows -- one fifth of a GNN stage's launch
+  // at F = 256 (round 3 tried to skip its zero strips inside the loop: the branch cost more than it saved)
+  WideSeg xseg; int xseg_kpad;
   const float* dpre; int d_stride; int n_real;
   RowPad pad;
   float* slab; int64_t slab_stride;      // slab[split][P]
@@ -170,17 +193,28 @@ struct WideWgradArgs {
 // in 16-column tiles (5: Dense-0, 8: F = 128, 16: 256 columns).  Whole-width output tiles for the same reason as in
 // k_wide_gemm: with 64 x 64 tiles every input tile was fetched once per 64 output columns and every dpre tile once
 // per 64 input features -- 1.9 GB per launch at 100 links x 1024 graphs x 256 features.
-template <int KW, int NT>
-__global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
-  constexpr int WW_TR = NT >= 16 ? 16 : 32;                      // rows per chunk (LDS budget: 2 workgroups per CU)
-  constexpr int KS = KW / 64, LDX = KW + 4, XP = KW * WW_TR / 1024;   // strips per wave, LDS stride, float4 passes of the X tile
-  constexpr int TN = 16 * NT, LDD = TN + 4, DP = (WW_TR * TN / 4 + 255) / 256;   // dpre tile [WW_TR][TN]
-  __shared__ __attribute__((aligned(16))) float sX[2][WW_TR * LDX];
-  __shared__ __attribute__((aligned(16))) float sD[2][WW_TR * LDD];
-  const int slot = blockIdx.z / a.n_split, sp = blockIdx.z - slot * a.n_split;
+// FOLD: this workgroup also accumulates the 16 rows of a.xseg against the dpre tile it stages anyway; wave w owns output
+// tiles w, w + 4, ... of that strip (+ 12.5 % MFMAs for one workgroup in KT instead of a whole extra workgroup).
+template <int KW, int NT> struct WideWgradLds {
+  static constexpr int WW_TR = NT >= 16 ? 16 : 32;               // rows per chunk (LDS budget: 2 workgroups per CU)
+  static constexpr int LDX = KW + 4, LDD = 16 * NT + 4, LDE = 20;
+  static constexpr int X = 2 * WW_TR * LDX, D = 2 * WW_TR * LDD, E = 2 * WW_TR * LDE;
+};
+
+template <int KW, int NT, bool FOLD>
+__device__ __forceinline__ void wide_wgrad_body(const WideWgradArgs& a, float* sXp, float* sDp, float* sEp, int bx, int by, int bz) {
+  typedef WideWgradLds<KW, NT> Lds;
+  constexpr int WW_TR = Lds::WW_TR;
+  constexpr int KS = KW / 64, LDX = Lds::LDX, XP = KW * WW_TR / 1024;   // strips per wave, LDS stride, float4 passes of the X tile
+  constexpr int TN = 16 * NT, LDD = Lds::LDD, DP = (WW_TR * TN / 4 + 255) / 256;   // dpre tile [WW_TR][TN]
+  constexpr int LDE = Lds::LDE, NE = (NT + 3) / 4;              // folded strip: [WW_TR][16] tile, output tiles per wave
+  float (*sX)[WW_TR * LDX] = reinterpret_cast<float (*)[WW_TR * LDX]>(sXp);
+  float (*sD)[WW_TR * LDD] = reinterpret_cast<float (*)[WW_TR * LDD]>(sDp);
+  float (*sE)[WW_TR * LDE] = reinterpret_cast<float (*)[WW_TR * LDE]>(sEp);
+  const int slot = bz / a.n_split, sp = bz - slot * a.n_split;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, kg = lane >> 4;
   // K tile -> (segment, column offset, valid width)
-  int kt = blockIdx.x;
+  int kt = bx;
   const float* xp = a.seg[0].ptr; int xst = a.seg[0].stride, xw = a.seg[0].width, kpad0 = a.seg_kpad[0];
   {
     const int t0 = (a.seg[0].width + KW - 1) / KW;
@@ -192,11 +226,11 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
   }
   const int kcol0 = kt * KW, kw = min(KW, xw - kcol0);
   kpad0 += kcol0;
-  const int n0 = blockIdx.y * TN;
+  const int n0 = by * TN;
   const int i_begin = sp * a.rows_per_split, i_end = min(i_begin + a.rows_per_split, a.n_idx);
   const int n_chunks = (max(i_end - i_begin, 0) + WW_TR - 1) / WW_TR;
 
-  auto gload = [&](int c, float4 (&vx)[XP], float4 (&vd)[DP]) {
+  auto gload = [&](int c, float4 (&vx)[XP], float4 (&vd)[DP], float4& ve) {
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       const int i = tid + 256 * p, r = i / (KW / 4), cx = (i % (KW / 4)) << 2;
@@ -217,8 +251,13 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
       const float md = okd ? 1.f : 0.f;
       vd[p] = make_float4(d.x * md, d.y * md, d.z * md, d.w * md);
     }
+    if (FOLD) {                                       // the [x | e] rows of the chunk: thread (row tid / 4, 4 columns); others repeat
+      const int r = min(tid >> 2, WW_TR - 1), idx = i_begin + c * WW_TR + r;
+      const int64_t rowg = (int64_t)(a.idx_base + min(idx, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
+      ve = *reinterpret_cast<const float4*>(a.xseg.ptr + rowg * a.xseg.stride + ((tid & 3) << 2));
+    }
   };
-  auto lstore = [&](int buf, const float4 (&vx)[XP], const float4 (&vd)[DP]) {
+  auto lstore = [&](int buf, const float4 (&vx)[XP], const float4 (&vd)[DP], const float4& ve) {
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
       const int i = tid + 256 * p, r = i / (KW / 4), cx = (i % (KW / 4)) << 2;
@@ -229,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
       const int i = tid + 256 * p;
       if (i < WW_TR * TN / 4) *reinterpret_cast<float4*>(&sD[buf][(i / (TN / 4)) * LDD + ((i % (TN / 4)) << 2)]) = vd[p];
     }
+    if (FOLD && tid < 4 * WW_TR) *reinterpret_cast<float4*>(&sE[buf][(tid >> 2) * LDE + ((tid & 3) << 2)]) = ve;
   };
 
   f32x4 acc[KS][NT];
@@ -236,16 +276,19 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[ks][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 accE[NE];
+#pragma unroll
+  for (int t = 0; t < NE; ++t) accE[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;                                             // column n0 + tid of the kt == 0 tile
-  const bool do_bias = blockIdx.x == 0 && tid < TN;
+  const bool do_bias = bx == 0 && tid < TN;
 
-  float4 vx[XP], vd[DP];
-  if (n_chunks > 0) { gload(0, vx, vd); lstore(0, vx, vd); }
+  float4 vx[XP], vd[DP], ve = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n_chunks > 0) { gload(0, vx, vd, ve); lstore(0, vx, vd, ve); }
   __syncthreads();
 #pragma unroll 1
   for (int c = 0; c < n_chunks; ++c) {
     const int buf = c & 1;
-    gload(min(c + 1, n_chunks - 1), vx, vd);          // unconditional, clamped (see k_wide_gemm)
+    gload(min(c + 1, n_chunks - 1), vx, vd, ve);      // unconditional, clamped (see k_wide_gemm)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < WW_TR / 4; ++s) {
@@ -258,13 +301,21 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) acc[ks][nt] = V2X_MFMA(xa[ks], db[nt], acc[ks][nt]);
+      if (FOLD) {
+        const float xe = sE[buf][(4 * s + kg) * LDE + j];
+#pragma unroll
+        for (int t = 0; t < NE; ++t) {                // this wave's tiles of the folded strip: operands re-read from LDS
+          const float de = sD[buf][(4 * s + kg) * LDD + min(wv + 4 * t, NT - 1) * 16 + j];      // (db[] cannot be indexed by wv)
+          accE[t] = V2X_MFMA(xe, de, accE[t]);
+        }
+      }
     }
     if (do_bias) {
 #pragma unroll
       for (int r = 0; r < WW_TR; ++r) bsum += sD[buf][r * LDD + tid];
     }
     __builtin_amdgcn_sched_barrier(0);
-    lstore(buf ^ 1, vx, vd);
+    lstore(buf ^ 1, vx, vd, ve);
     __syncthreads();
   }
 
@@ -283,7 +334,76 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
         if (col < a.n_real) dst[(int64_t)rr * a.n_real + col] = acc[ks][nt][r];
       }
     }
+  if (FOLD) {                                         // ... and dW[xseg_kpad + 4*kg + r][n0 + (wv + 4 t)*16 + j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = real_row(a.pad, a.xseg_kpad + 4 * kg + r);
+      if (rr < 0) continue;
+#pragma unroll
+      for (int t = 0; t < NE; ++t) {
+        const int col = n0 + (wv + 4 * t) * 16 + j;
+        if (wv + 4 * t < NT && col < a.n_real) dst[(int64_t)rr * a.n_real + col] = accE[t][r];
+      }
+    }
+  }
   if (do_bias && n0 + tid < a.n_real) dst[(int64_t)a.pad.k_real * a.n_real + n0 + tid] = bsum;
+}
+
+template <int KW, int NT>
+__global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
+  typedef WideWgradLds<KW, NT> Lds;
+  __shared__ __attribute__((aligned(16))) float sX[Lds::X];
+  __shared__ __attribute__((aligned(16))) float sD[Lds::D];
+  __shared__ __attribute__((aligned(16))) float sE[Lds::E];
+  if (a.xseg.ptr && blockIdx.x == 0) wide_wgrad_body<KW, NT, true>(a, sX, sD, sE, blockIdx.x, blockIdx.y, blockIdx.z);
+  else wide_wgrad_body<KW, NT, false>(a, sX, sD, sE, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Several layers' weight gradients as ONE grid (single-GPU training: nothing waits for a single layer's gradient).  With
+// per-node weights a layer is [K tiles x slots] workgroups of a quarter million MFMA cycles each and a launch holds about two
+// of them per CU: 500 workgroups on 256 CUs, every launch as long as its fullest CU -- and the launches of L stages, Dense-0
+// and the embed layer each pay that rounding on their own.  As roles of one grid (heaviest first; a 1-D grid cut by
+// `start`) the chip is handed 5-6 workgroups per CU to balance: configs[3] share 3 x 298 + 114 + 59 us -> see DESIGN.md 3b.
+constexpr int WWM_ROLES = 6;
+enum { WWM_128x16 = 0, WWM_128x8 = 1, WWM_128x5 = 2, WWM_64x4 = 3 };
+struct WideWgradMulti {
+  WideWgradArgs w[WWM_ROLES];
+  int start[WWM_ROLES + 1];              // first workgroup of every role (+ the grid size)
+  int kt[WWM_ROLES], nt[WWM_ROLES], kind[WWM_ROLES];
+  int n_roles;
+};
+template <int A, int B> struct CMax { static constexpr int v = A > B ? A : B; };
+
+__global__ __launch_bounds__(256, 2) void k_wide_wgrad_multi(WideWgradMulti mu) {
+  constexpr int SX = CMax<CMax<WideWgradLds<128, 16>::X, WideWgradLds<128, 8>::X>::v, CMax<WideWgradLds<128, 5>::X, WideWgradLds<64, 4>::X>::v>::v;
+  constexpr int SD = CMax<CMax<WideWgradLds<128, 16>::D, WideWgradLds<128, 8>::D>::v, CMax<WideWgradLds<128, 5>::D, WideWgradLds<64, 4>::D>::v>::v;
+  constexpr int SE = WideWgradLds<128, 5>::E;
+  __shared__ __attribute__((aligned(16))) float sX[SX];
+  __shared__ __attribute__((aligned(16))) float sD[SD];
+  __shared__ __attribute__((aligned(16))) float sE[SE];
+  // role descriptors through the kernarg segment pointer (a by-value array indexed at run time would be copied to scratch)
+  typedef const __attribute__((address_space(4))) unsigned* CWords;
+  static_assert(sizeof(WideWgradArgs) % 4 == 0, "WideWgradArgs must be dword sized");
+  constexpr int NW = sizeof(WideWgradArgs) / 4;
+  CWords base = (CWords)__builtin_amdgcn_kernarg_segment_ptr();
+  CWords tail = base + WWM_ROLES * NW;                            // start[WWM_ROLES + 1], kt[], nt[], kind[], n_roles
+  const int b = blockIdx.x;
+  int r = 0;
+#pragma unroll
+  for (int i = 1; i < WWM_ROLES; ++i) r += (b >= (int)tail[i] && i < (int)tail[WWM_ROLES + 1 + 3 * WWM_ROLES]) ? 1 : 0;
+  const int local = b - (int)tail[r];
+  const int kt = (int)tail[WWM_ROLES + 1 + r], nt = (int)tail[WWM_ROLES + 1 + WWM_ROLES + r], kind = (int)tail[WWM_ROLES + 1 + 2 * WWM_ROLES + r];
+  const int bx = local % kt, by = (local / kt) % nt, bz = local / (kt * nt);
+  WideWgradArgs a;
+  unsigned* dstw = reinterpret_cast<unsigned*>(&a);
+  CWords srcw = base + r * NW;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
+  const bool fold = a.xseg.ptr && bx == 0;
+  if (kind == WWM_128x16) { if (fold) wide_wgrad_body<128, 16, true>(a, sX, sD, sE, bx, by, bz); else wide_wgrad_body<128, 16, false>(a, sX, sD, sE, bx, by, bz); }
+  else if (kind == WWM_128x8) { if (fold) wide_wgrad_body<128, 8, true>(a, sX, sD, sE, bx, by, bz); else wide_wgrad_body<128, 8, false>(a, sX, sD, sE, bx, by, bz); }
+  else if (kind == WWM_128x5) { if (fold) wide_wgrad_body<128, 5, true>(a, sX, sD, sE, bx, by, bz); else wide_wgrad_body<128, 5, false>(a, sX, sD, sE, bx, by, bz); }
+  else wide_wgrad_body<64, 4, false>(a, sX, sD, sE, bx, by, bz);
 }
 
 

@@ -47,6 +47,8 @@ struct GraphKey {
   bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
 };
 
+struct WideWgradPlan { WideWgradArgs a; int kt, nt, ntw, sp; };     // one layer's wide weight gradient: arguments + tiling
+
 }  // namespace
 
 struct v2x_model {
@@ -100,6 +102,11 @@ struct v2x_model {
   int64_t ws_gen = 0;           // bumped whenever a workspace buffer is re-allocated (keys of graphs that bake in ANOTHER model's workspace)
   std::map<GraphKey, GraphEntry> graphs;
   bool capturing = false;
+  // wide path, single-GPU training: the layers' weight gradients are collected and launched as ONE grid (wide_wgrad_flush)
+  bool wide_merge_now = false;                  // inside a backward pass that merges
+  bool bucketed = false;                        // data parallelism wants each layer's gradient as soon as it is final
+  std::vector<WideWgradPlan> wide_roles_buf;
+  std::vector<WideWgradPlan>* wide_roles = nullptr;      // non-null: wide_wgrad collects instead of launching
 };
 
 namespace {
@@ -624,13 +631,20 @@ int wide_nt(int n_out) { return n_out <= 80 ? 5 : 4; }
 
 int launch_wide_gemm(v2x_model* m, hipStream_t st, WideGemmArgs& a, int grid_z, bool trans, const char* name) {
   const int nt = wide_nt(a.n_out);
-  const dim3 grid((a.n_idx + WD_TM - 1) / WD_TM, (a.n_out + 16 * nt - 1) / (16 * nt), grid_z);
-#define V2X_WIDE_GEMM(T, NTV) { auto k = k_wide_gemm<T, NTV>; LAUNCH(m, name, k, grid, 0, st, a); return V2X_OK; }
+  // tile variants (V2X_WIDE_RT = 16-row tiles per wave: 2 or 4; V2X_WIDE_KC = K depth of an LDS chunk: 16 or 32)
+  static const int rt_env = env_int("V2X_WIDE_RT", 2), kc_env = env_int("V2X_WIDE_KC", 16);
+  const int rt = (nt == 4 && rt_env == 4) ? 4 : 2, kc = kc_env == 32 ? 32 : 16;
+  const dim3 grid((a.n_idx + 64 * rt - 1) / (64 * rt), (a.n_out + 16 * nt - 1) / (16 * nt), grid_z);
+#define V2X_WIDE_GEMM(T, NTV, RTV, KCV) { auto k = k_wide_gemm<T, NTV, RTV, KCV>; LAUNCH(m, name, k, grid, 0, st, a); return V2X_OK; }
   if (!trans) {
-    if (nt == 5) V2X_WIDE_GEMM(false, 5)
-    V2X_WIDE_GEMM(false, 4)
+    if (nt == 5) { if (kc == 32) V2X_WIDE_GEMM(false, 5, 2, 32) V2X_WIDE_GEMM(false, 5, 2, 16) }
+    if (rt == 4) V2X_WIDE_GEMM(false, 4, 4, 16)          // (RT = 4 with KC = 32 would need 91 KB of LDS)
+    if (kc == 32) V2X_WIDE_GEMM(false, 4, 2, 32)
+    V2X_WIDE_GEMM(false, 4, 2, 16)
   }
-  V2X_WIDE_GEMM(true, 4)
+  if (rt == 4) V2X_WIDE_GEMM(true, 4, 4, 16)
+  if (kc == 32) V2X_WIDE_GEMM(true, 4, 2, 32)
+  V2X_WIDE_GEMM(true, 4, 2, 16)
 #undef V2X_WIDE_GEMM
 }
 
@@ -670,18 +684,28 @@ int wide_splits(int n_idx, int n_tiles, int n_slots) {
   return sp < 1 ? 1 : sp;
 }
 
-int wide_wgrad(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, const WideSeg* segs, const int* seg_kpad,
-               int n_seg, const float* dpre, int d_stride, const char* name, int zero_row0 = 0, int zero_rows = 0) {
-  WideWgradArgs a;
+// arguments + tiling of one layer's wide weight gradient (and the memsets of an absent input segment's weight rows)
+int wide_wgrad_plan(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, const WideSeg* segs, const int* seg_kpad,
+                    int n_seg, const float* dpre, int d_stride, int zero_row0, int zero_rows, WideWgradPlan* out) {
+  WideWgradArgs& a = out->a;
   memset(&a, 0, sizeof(a));
   int k_width = 0;
   for (int i = 0; i < n_seg; ++i) k_width += segs[i].width;
   // weight gradients: 128 input features x the whole output width per workgroup (324 -> 315 us for a GNN stage,
   // 180 -> 123 us for Dense-0); the 16-wide embed layer keeps 64 x 64 tiles
   const int KW = k_width <= 64 ? 64 : 128;
-  int kt = 0;
-  for (int i = 0; i < n_seg; ++i) { a.seg[i] = segs[i]; a.seg_kpad[i] = seg_kpad[i]; kt += (segs[i].width + KW - 1) / KW; }
-  a.n_seg = n_seg;
+  int kt = 0, ns = 0;
+  // the 16-wide [x | e] segment of a wide layer rides on the workgroup of K tile 0 (WideWgradArgs::xseg) instead of
+  // costing a whole 128-wide K tile of its own.  Only worth it when the launch is balanced over many workgroups per CU
+  // (the merged launch): on its own a stage is 500 workgroups on 256 CUs and as long as its fullest CU either way
+  // (measured: 298 us unfolded, 333 us folded -- 400 workgroups, the same two per CU, one of them 12.5 % longer)
+  static const int fold = env_int("V2X_WIDE_FOLD", 1);
+  for (int i = 0; i < n_seg; ++i) {
+    if (fold && m->wide_merge_now && KW == 128 && n_seg > 1 && segs[i].width == XE && !a.xseg.ptr) { a.xseg = segs[i]; a.xseg_kpad = seg_kpad[i]; continue; }
+    a.seg[ns] = segs[i]; a.seg_kpad[ns] = seg_kpad[i]; kt += (segs[i].width + KW - 1) / KW;
+    ++ns;
+  }
+  a.n_seg = ns;
   a.dpre = dpre; a.d_stride = d_stride; a.n_real = ld.n_out; a.pad = ld.pad;
   a.slab = m->slab; a.slab_stride = m->P; a.layer_off = ld.off; a.slot_stride = ld.slot_stride;
   a.n_idx = x.n_idx; a.row_stride = x.row_stride; a.base_mul = x.base_mul; a.idx_base = x.idx_base;
@@ -704,11 +728,51 @@ int wide_wgrad(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, con
       hipLaunchKernelGGL(k_zero_rows, zg, dim3(256), 0, st, dst, ld.slot_stride, count);
     }
   }
-  const dim3 grid(kt, nt, x.grid_y * sp);
-  if (ntw == 4) { auto k = k_wide_wgrad<64, 4>; LAUNCH(m, name, k, grid, 0, st, a); }
-  else if (ntw == 5) { auto k = k_wide_wgrad<128, 5>; LAUNCH(m, name, k, grid, 0, st, a); }
-  else if (ntw == 8) { auto k = k_wide_wgrad<128, 8>; LAUNCH(m, name, k, grid, 0, st, a); }
+  out->kt = kt; out->nt = nt; out->ntw = ntw; out->sp = sp;
+  return V2X_OK;
+}
+
+int wide_wgrad(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x, const WideSeg* segs, const int* seg_kpad,
+               int n_seg, const float* dpre, int d_stride, const char* name, int zero_row0 = 0, int zero_rows = 0) {
+  WideWgradPlan p;
+  CHK(wide_wgrad_plan(m, st, ld, x, segs, seg_kpad, n_seg, dpre, d_stride, zero_row0, zero_rows, &p));
+  if (m->wide_roles) {      // collected for the merged launch (wide_wgrad_flush)
+    if ((int)m->wide_roles->size() >= WWM_ROLES) FAIL(m, V2X_ESTATE, "wide wgrad: too many roles for one launch");
+    m->wide_roles->push_back(p);
+    return V2X_OK;
+  }
+  const WideWgradArgs& a = p.a;
+  const dim3 grid(p.kt, p.nt, x.grid_y * p.sp);
+  if (p.ntw == 4) { auto k = k_wide_wgrad<64, 4>; LAUNCH(m, name, k, grid, 0, st, a); }
+  else if (p.ntw == 5) { auto k = k_wide_wgrad<128, 5>; LAUNCH(m, name, k, grid, 0, st, a); }
+  else if (p.ntw == 8) { auto k = k_wide_wgrad<128, 8>; LAUNCH(m, name, k, grid, 0, st, a); }
   else { auto k = k_wide_wgrad<128, 16>; LAUNCH(m, name, k, grid, 0, st, a); }
+  return V2X_OK;
+}
+
+// launch the collected roles as one grid, heaviest workgroups first (they are dispatched in block order and the launch is
+// as long as its last-finishing workgroup)
+int wide_wgrad_flush(v2x_model* m, hipStream_t st, const IdxMap& x) {
+  std::vector<WideWgradPlan>& roles = *m->wide_roles;
+  if (roles.empty()) return V2X_OK;
+  std::stable_sort(roles.begin(), roles.end(), [](const WideWgradPlan& p, const WideWgradPlan& q) {
+    auto w = [](const WideWgradPlan& r) { return (r.ntw == 4 ? 64 : 128) * 16 * r.ntw; };     // MFMA work of one workgroup
+    return w(p) > w(q);
+  });
+  WideWgradMulti mu;
+  memset(&mu, 0, sizeof(mu));
+  int n = 0, total = 0;
+  for (const WideWgradPlan& p : roles) {
+    mu.w[n] = p.a; mu.kt[n] = p.kt; mu.nt[n] = p.nt;
+    mu.kind[n] = p.ntw == 16 ? WWM_128x16 : (p.ntw == 8 ? WWM_128x8 : (p.ntw == 5 ? WWM_128x5 : WWM_64x4));
+    mu.start[n] = total;
+    total += p.kt * p.nt * x.grid_y * p.sp;
+    ++n;
+  }
+  for (int i = n; i <= WWM_ROLES; ++i) mu.start[i] = total;
+  mu.n_roles = n;
+  roles.clear();
+  LAUNCH(m, "k_wgrad_wide_all", k_wide_wgrad_multi, dim3(total), 0, st, mu);
   return V2X_OK;
 }
 
@@ -1034,9 +1098,20 @@ int wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const fl
 // all GNN stages (needs dpre[0..L]) in ceil((L+1)/4) launches
 int wgrad_gnn_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch& d) {
   if (is_wide(m)) {
-    for (int s = m->L; s >= 0; --s)
-      CHK(wide_wgrad_gnn(m, st, s, x, d.xe, s ? m->h[s - 1] : nullptr, s ? m->a[s - 1] : d.nbr, m->dpre[s]));
-    return V2X_OK;
+    if (m->wide_merge_now) m->wide_roles = &m->wide_roles_buf;          // collect: L + 1 graph layers (+ Dense-0), one grid
+    int rc = V2X_OK;
+    for (int s = m->L; s >= 0 && rc == V2X_OK; --s)
+      rc = wide_wgrad_gnn(m, st, s, x, d.xe, s ? m->h[s - 1] : nullptr, s ? m->a[s - 1] : d.nbr, m->dpre[s]);
+    if (m->wide_merge_now && rc == V2X_OK) {
+      const int F = m->F, L = m->L;
+      WideSeg w0[3] = {WideSeg{m->h[L], F, F}, WideSeg{d.xe, XE, XE}, WideSeg{m->a[L], F, F}};
+      const int kp[3] = {0, F, F + XE};
+      rc = wide_wgrad(m, st, m->dense[0], x, w0, kp, 3, m->dz1, H1, "k_wgrad_dense0");
+      if (rc == V2X_OK) rc = wide_wgrad_flush(m, st, x);
+    }
+    m->wide_roles = nullptr;
+    m->wide_roles_buf.clear();
+    return rc;
   }
   WgradMulti mu;
   // The embed layer's gradient (16 MFMAs per block, load-bound) rides on the graph layers' roles when its F / 16 output
@@ -1077,7 +1152,7 @@ int wgrad_mlp(v2x_model* m, hipStream_t st, const IdxMap& x, const float* xe, co
   if (is_wide(m)) {
     WideSeg w0[3] = {WideSeg{h, F, F}, WideSeg{xe, XE, XE}, WideSeg{agg, F, F}};
     const int kp[3] = {0, F, F + XE};
-    CHK(wide_wgrad(m, st, m->dense[0], x, w0, kp, 3, m->dz1, H1, "k_wgrad_dense0"));
+    if (!m->wide_merge_now) CHK(wide_wgrad(m, st, m->dense[0], x, w0, kp, 3, m->dz1, H1, "k_wgrad_dense0"));   // else: a role of the merged launch
     WgSeg t1[1] = {WgSeg{m->z1, H1, H1, 0, 0}};
     CHK(wgrad_role(m, m->dense[1], WG_KIND_DENSE1, x, total, t1, 1, m->dz2, H2, mu.w[0]));
     WgSeg t2[1] = {WgSeg{m->z2, H2, H2, 0, 1}};
@@ -1390,6 +1465,11 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   a.y = y_dev;
   a.inv_denom = 1.0f / loss_denominator(m, n_global);
   const bool mlp_wg = mlp_wg_path(m);      // the Dense weight gradients come out of the MLP launch itself
+  // wide path: every layer's weight gradient in ONE launch after the data chain -- unless somebody wants a layer's gradient
+  // as soon as it is final (per-layer all-reduce buckets of data parallelism: m->bucketed)
+  static const int wide_merge = env_int("V2X_WIDE_MERGE", 1);
+  m->wide_merge_now = is_wide(m) && wide_merge && !two && !m->bucketed && m->L + 2 <= WWM_ROLES;
+  struct MergeGuard { v2x_model* m; ~MergeGuard() { m->wide_merge_now = false; } } merge_guard{m};
   if (m->frag_live && !frag_layout(m, d, r)) FAIL(m, V2X_ESTATE, "backward: the saved forward is fragment-major, this backward cannot read it");
   a.frag_groups = m->frag_live ? d.B / FZ_TG : 0;
   if (mlp_wg) CHK(launch_mlp_train_wg(m, st, a));

@@ -201,16 +201,23 @@ def test_small_predict_out_of_step_exchange_times_out_instead_of_hanging():
     cnt = _exchange_counters(eng, 256)
     torch.cuda.synchronize()
     assert int(cnt[0].item()) == N and int(cnt[B - 1].item()) == N and int(cnt[B].item()) == 0     # one launch: N departures per graph
-    side = torch.cuda.Stream()
+    # two NON-default streams: the legacy default stream would serialise the predict behind the bumps
+    side, main = torch.cuda.Stream(), torch.cuda.Stream()
     seen = 0
     t_max = 0.0
-    for attempt in range(60):
+    # 2,000 bumps of whole epochs as ONE replayable graph: they run back to back on the GPU (~5 ms), not at the pace the
+    # host can enqueue them (issued one by one they are long done when the predict starts)
+    bumps = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(bumps, stream=side):
+        for _ in range(2000):
+            cnt[:B].add_(7 * N)
+    for attempt in range(100):
         with torch.cuda.stream(side):
-            for _ in range(300):                      # ~1.5 ms of back-to-back bumps: whole epochs, mid-launch
-                cnt[:B].add_(7 * N)
+            bumps.replay()
         t0 = time.perf_counter()
         try:
-            q = eng.forward(pb)
+            with torch.cuda.stream(main):
+                q = eng.forward(pb)
             assert q.shape == q0.shape
         except v2xgnn.lib.V2XError as exc:
             assert "timed out" in str(exc)
@@ -219,7 +226,7 @@ def test_small_predict_out_of_step_exchange_times_out_instead_of_hanging():
         torch.cuda.synchronize()
         if seen >= 2:
             break
-    assert seen >= 1, "60 predicts raced against 18,000 counter bumps and none saw an out-of-step exchange"
+    assert seen >= 1, "100 predicts raced against 200,000 counter bumps and none saw an out-of-step exchange"
     assert t_max < 20.0, "a timed-out predict took %.1f s" % t_max
     torch.cuda.synchronize()
     # the library re-armed the exchange when it reported the time-out: predicts are right again, bit for bit

@@ -1553,6 +1553,7 @@ struct AdamArgs {
   int64_t loss_slot_stride;                              // rowloss index of (output slot, i) = slot * loss_slot_stride + i * loss_stride
   int loss_split; float* loss_part; unsigned* loss_cnt;  // ranges per output (> 1 only with a single output)
   int64_t range_begin4, range_end4;                      // float4 range of the flat buffer this launch covers ([0, n4) = all)
+  int64_t range2_begin4, range2_end4;                    // optional second range, walked after the first (empty: begin == end)
   const float* grad_direct;                              // where slab-less layers left their gradient
   int groups;                                            // threads per float4 column (1, 4 or 16): split of the slab sum
 };
@@ -1598,9 +1599,11 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
   __shared__ float4 part[256];
   const int G = a.groups, cols = 256 / G;
   const int col = threadIdx.x % cols, grp = threadIdx.x / cols;
-  for (int64_t base = a.range_begin4 + (int64_t)blockIdx.x * cols; base < a.range_end4; base += (int64_t)a.n_adam_blocks * cols) {
-    const int64_t i = base + col;
-    const bool act = i < a.range_end4;
+  const int64_t len1 = a.range_end4 - a.range_begin4, len_all = len1 + (a.range2_end4 - a.range2_begin4);
+  for (int64_t base = (int64_t)blockIdx.x * cols; base < len_all; base += (int64_t)a.n_adam_blocks * cols) {
+    const int64_t t = base + col;                         // position in [range 1 | range 2]
+    const bool act = t < len_all;
+    const int64_t i = t < len1 ? a.range_begin4 + t : a.range2_begin4 + (t - len1);
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
     bool direct = false;
     if (a.slab) {

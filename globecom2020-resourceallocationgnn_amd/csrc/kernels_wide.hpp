@@ -186,6 +186,11 @@ struct WideWgradArgs {
   int64_t layer_off, slot_stride;
   int n_idx, row_stride, base_mul, idx_base;
   int n_split, rows_per_split;           // rows_per_split is a multiple of 32
+  // single-GPU fit step, one row split: the workgroup holds the layer's FINAL gradient tile -- it applies Keras Adam to its
+  // parameters right there (param / mom / vel: the flat buffers; adam_scal = {lr_t, beta1, beta2, eps} in device memory, so
+  // that a replayed hipGraph sees this step's lr_t) and the gradient never travels: - 8 of the 28 bytes per parameter that
+  // k_reduce_adam moved, and the other 20 ride under the launch's MFMA work instead of being a 280 us launch of their own
+  float* param; float* mom; float* vel; const float* adam_scal; int adam;
 };
 
 
@@ -201,7 +206,7 @@ template <int KW, int NT> struct WideWgradLds {
   static constexpr int X = 2 * WW_TR * LDX, D = 2 * WW_TR * LDD, E = 2 * WW_TR * LDE;
 };
 
-template <int KW, int NT, bool FOLD>
+template <int KW, int NT, bool FOLD, bool ADAM = false>
 __device__ __forceinline__ void wide_wgrad_body(const WideWgradArgs& a, float* sXp, float* sDp, float* sEp, int bx, int by, int bz) {
   typedef WideWgradLds<KW, NT> Lds;
   constexpr int WW_TR = Lds::WW_TR;
@@ -320,7 +325,23 @@ __device__ __forceinline__ void wide_wgrad_body(const WideWgradArgs& a, float* s
   }
 
   // lane holds dW[kpad0 + 64*ks + 16*wv + 4*kg + r][n0 + nt*16 + j]
-  float* dst = a.slab + (int64_t)sp * a.slab_stride + a.layer_off + slot * a.slot_stride;
+  const int64_t lbase = a.layer_off + slot * a.slot_stride;
+  float* dst = a.slab + (int64_t)sp * a.slab_stride + lbase;
+  float lr_t = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f;
+  if (ADAM) { lr_t = a.adam_scal[0]; b1 = a.adam_scal[1]; b2 = a.adam_scal[2]; eps = a.adam_scal[3]; }
+  float* pp = a.param + lbase; float* pm = a.mom + lbase; float* pv = a.vel + lbase;
+  // one final gradient value: to the gradient buffer / slab, or straight through Keras Adam (k_reduce_adam's expressions)
+  auto emit = [&](int64_t off, float g) {
+    if (ADAM) {
+      float mo = pm[off], ve = pv[off], p = pp[off];
+      mo = b1 * mo + (1.f - b1) * g;
+      ve = b2 * ve + (1.f - b2) * (g * g);
+      p -= lr_t * mo / (sqrtf(ve) + eps);
+      pm[off] = mo; pv[off] = ve; pp[off] = p;
+    } else {
+      dst[off] = g;
+    }
+  };
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
@@ -331,7 +352,7 @@ __device__ __forceinline__ void wide_wgrad_body(const WideWgradArgs& a, float* s
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int col = n0 + nt * 16 + j;
-        if (col < a.n_real) dst[(int64_t)rr * a.n_real + col] = acc[ks][nt][r];
+        if (col < a.n_real) emit((int64_t)rr * a.n_real + col, acc[ks][nt][r]);
       }
     }
   if (FOLD) {                                         // ... and dW[xseg_kpad + 4*kg + r][n0 + (wv + 4 t)*16 + j]
@@ -342,11 +363,11 @@ __device__ __forceinline__ void wide_wgrad_body(const WideWgradArgs& a, float* s
 #pragma unroll
       for (int t = 0; t < NE; ++t) {
         const int col = n0 + (wv + 4 * t) * 16 + j;
-        if (wv + 4 * t < NT && col < a.n_real) dst[(int64_t)rr * a.n_real + col] = accE[t][r];
+        if (wv + 4 * t < NT && col < a.n_real) emit((int64_t)rr * a.n_real + col, accE[t][r]);
       }
     }
   }
-  if (do_bias && n0 + tid < a.n_real) dst[(int64_t)a.pad.k_real * a.n_real + n0 + tid] = bsum;
+  if (do_bias && n0 + tid < a.n_real) emit((int64_t)a.pad.k_real * a.n_real + n0 + tid, bsum);
 }
 
 template <int KW, int NT>
@@ -400,10 +421,16 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad_multi(WideWgradMulti mu) 
 #pragma unroll
   for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
   const bool fold = a.xseg.ptr && bx == 0;
-  if (kind == WWM_128x16) { if (fold) wide_wgrad_body<128, 16, true>(a, sX, sD, sE, bx, by, bz); else wide_wgrad_body<128, 16, false>(a, sX, sD, sE, bx, by, bz); }
-  else if (kind == WWM_128x8) { if (fold) wide_wgrad_body<128, 8, true>(a, sX, sD, sE, bx, by, bz); else wide_wgrad_body<128, 8, false>(a, sX, sD, sE, bx, by, bz); }
-  else if (kind == WWM_128x5) { if (fold) wide_wgrad_body<128, 5, true>(a, sX, sD, sE, bx, by, bz); else wide_wgrad_body<128, 5, false>(a, sX, sD, sE, bx, by, bz); }
+#define V2X_WWM_ROLE(KWV, NTV)                                                                                          \
+  {                                                                                                                     \
+    if (a.adam) { if (fold) wide_wgrad_body<KWV, NTV, true, true>(a, sX, sD, sE, bx, by, bz); else wide_wgrad_body<KWV, NTV, false, true>(a, sX, sD, sE, bx, by, bz); } \
+    else { if (fold) wide_wgrad_body<KWV, NTV, true>(a, sX, sD, sE, bx, by, bz); else wide_wgrad_body<KWV, NTV, false>(a, sX, sD, sE, bx, by, bz); } \
+  }
+  if (kind == WWM_128x16) V2X_WWM_ROLE(128, 16)
+  else if (kind == WWM_128x8) V2X_WWM_ROLE(128, 8)
+  else if (kind == WWM_128x5) V2X_WWM_ROLE(128, 5)
   else wide_wgrad_body<64, 4, false>(a, sX, sD, sE, bx, by, bz);
+#undef V2X_WWM_ROLE
 }
 
 

@@ -105,6 +105,9 @@ struct v2x_model {
   // wide path, single-GPU training: the layers' weight gradients are collected and launched as ONE grid (wide_wgrad_flush)
   bool wide_merge_now = false;                  // inside a backward pass that merges
   bool bucketed = false;                        // data parallelism wants each layer's gradient as soon as it is final
+  bool fuse_adam_now = false;                   // ... and applies Adam in the weight-gradient epilogues (WideWgradArgs::adam)
+  float* adam_scal = nullptr;                   // {lr_t, beta1, beta2, eps} of the current step, in device memory
+  bool prof_no_fuse = false;
   std::vector<WideWgradPlan> wide_roles_buf;
   std::vector<WideWgradPlan>* wide_roles = nullptr;      // non-null: wide_wgrad collects instead of launching
 };
@@ -720,6 +723,10 @@ int wide_wgrad_plan(v2x_model* m, hipStream_t st, LayerDesc& ld, const IdxMap& x
     a.slab = m->grads;
     ld.n_slabs = 0;
   }
+  if (m->fuse_adam_now && &ld != &m->gnn[0]) {         // (the embed layer keeps k_reduce_adam: its absent-input rows have no tile)
+    if (sp != 1 || zero_rows > 0) FAIL(m, V2X_ESTATE, "wide wgrad: Adam cannot ride on a split weight gradient");
+    a.adam = 1; a.param = m->params; a.mom = m->mom; a.vel = m->vel; a.adam_scal = m->adam_scal;
+  }
   if (zero_rows > 0) {      // weight rows of an absent (identically zero) input segment: exact zero gradient
     const int64_t count = (int64_t)zero_rows * ld.n_out;
     for (int c = 0; c < sp; ++c) {
@@ -1205,8 +1212,15 @@ struct LossJob { int n_out, n_idx, stride; float scale; int64_t slot_stride; }; 
 int64_t bucket_begin(const v2x_model* m, int bucket) { return bucket == 0 ? m->dense[0].off : 0; }
 int64_t bucket_end(const v2x_model* m, int bucket) { return bucket == 1 ? m->dense[0].off : m->P; }
 
+float adam_lr_t(const v2x_model* m, int64_t iteration) {
+  const double t = (double)iteration;
+  return (float)(m->cfg.lr * std::sqrt(1.0 - std::pow((double)m->cfg.beta2, t)) / (1.0 - std::pow((double)m->cfg.beta1, t)));
+}
+
+// fused_adam: the layers gnn[1..L] and dense[0] were updated by their weight-gradient launch (WideWgradArgs::adam): this
+// launch covers what is left of the flat buffer, [0, gnn[1].off) and [dense[1].off, P)
 int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, float* grad_dst, LossJob lj = LossJob{0, 0, 0, 0.f, 0},
-                       int bucket = -1) {
+                       int bucket = -1, bool fused_adam = false) {
   AdamArgs a;
   memset(&a, 0, sizeof(a));
   a.param = m->params; a.grad = grad_dst ? grad_dst : m->grads; a.mom = m->mom; a.vel = m->vel;
@@ -1223,11 +1237,14 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
   }
   a.n4 = m->P / 4;
   a.range_begin4 = bucket_begin(m, bucket) / 4; a.range_end4 = bucket_end(m, bucket) / 4;
+  if (fused_adam) {
+    a.range_begin4 = 0; a.range_end4 = m->gnn[1].off / 4;
+    a.range2_begin4 = m->dense[1].off / 4; a.range2_end4 = m->P / 4;
+  }
   a.do_adam = do_adam ? 1 : 0;
   if (do_adam) {
     m->iterations += 1;
-    const double t = (double)m->iterations;
-    a.lr_t = (float)(m->cfg.lr * std::sqrt(1.0 - std::pow((double)m->cfg.beta2, t)) / (1.0 - std::pow((double)m->cfg.beta1, t)));
+    a.lr_t = adam_lr_t(m, m->iterations);
     a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
     if (m->pk_fwd) { a.pack.fwd = m->pk_fwd; a.pack.bwd = m->pk_bwd; a.pack.F = m->F; a.pack.S = m->S; a.pack.L = m->L; a.pack.xr = m->Dn + m->De; }
   }
@@ -1236,7 +1253,7 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
   a.groups = 1;
   if (a.slab && a.n4 < 256 * 1024 && max_slabs_used >= 16) a.groups = a.n4 < 64 * 1024 ? 16 : 4;
   const int cols = 256 / a.groups;
-  int blocks = (int)((a.range_end4 - a.range_begin4 + cols - 1) / cols);
+  int blocks = (int)((a.range_end4 - a.range_begin4 + a.range2_end4 - a.range2_begin4 + cols - 1) / cols);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   a.n_adam_blocks = blocks;
@@ -1622,6 +1639,17 @@ int presize_rows(v2x_model* m, int n_rows) {
   return V2X_OK;
 }
 
+// Adam in the weight-gradient epilogues (single-GPU fit step of a wide model): needs the merged launch and ONE row split
+// for every layer it covers (gnn[1..L], dense[0]) -- true as soon as K tiles x slots fill the chip (per-node weights)
+bool wide_adam_fusable(const v2x_model* m, const DevBatch& d) {
+  static const int on = env_int("V2X_WIDE_ADAM", 1), wide_merge = env_int("V2X_WIDE_MERGE", 1);
+  if (!on || !wide_merge || !is_wide(m) || m->bucketed || m->prof_no_fuse || !m->adam_scal || m->L + 2 > WWM_ROLES) return false;
+  if (getenv("V2X_TWO_STREAMS")) return false;
+  const IdxMap x = idx_map(m, d, Range{0, d.B});
+  const int kt = 2 * ((m->F + 127) / 128);                    // [h | agg] K tiles ([x | e] folded or one more: more tiles = fewer splits)
+  return wide_splits(x.n_idx, kt, x.grid_y) == 1;
+}
+
 }  // namespace
 
 // ======================================================================================= C ABI
@@ -1670,7 +1698,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   const size_t pb = (size_t)m->P * sizeof(float);
   if (dev_alloc(m, &m->params, m->P) || dev_alloc(m, &m->grads, m->P) || dev_alloc(m, &m->mom, m->P) ||
       dev_alloc(m, &m->vel, m->P) || dev_alloc(m, &m->loss_dev, (size_t)m->N + 1) || dev_alloc(m, &m->zero_buf, 1024) ||
-      dev_alloc(m, &m->loss_part, 128))
+      dev_alloc(m, &m->loss_part, 128) || dev_alloc(m, &m->adam_scal, 16))
     return fail("allocation");
   // V2X_FUSED=0 (read when the model is created) keeps the layer-by-layer kernels: A/B measurements and the test that
   // the two paths agree bitwise
@@ -1726,7 +1754,7 @@ void v2x_destroy(v2x_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second.exec);
   for (auto& r : m->prof_recs) { hipEventDestroy(r.ev0); hipEventDestroy(r.ev1); }
   float* ptrs[] = {m->params, m->grads, m->mom, m->vel, m->z1, m->z2, m->z3, m->q, m->dq, m->dz1, m->dz2, m->dz3,
-                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part, m->pk_fwd, m->pk_bwd};
+                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part, m->pk_fwd, m->pk_bwd, m->adam_scal};
   for (float* p : m->dpre) if (p) hipFree(p);
   if (m->gate_bits) hipFree(m->gate_bits);
   if (m->nbmask) hipFree(m->nbmask);
@@ -1863,9 +1891,19 @@ static int fwd_bwd(v2x_model* m, const v2x_batch* b, const float* y, int y_on_de
   CHK(resolve_y(m, y, y_on_device, d.R, st, &yd));
   CHK(presize(m, d));
   if (with_adam) {
-    // lr_t depends on the iteration count, so the Adam node stays outside the replayed graph
-    CHK(run_maybe_graph(m, st, make_key(2, d, yd, n_global), [&]() { return run_step(m, st, d, true, yd, n_global); }));
-    CHK(launch_reduce_adam(m, st, 1, true, nullptr, loss_job(m, d, n_global)));
+    // lr_t depends on the iteration count, so the Adam node stays outside the replayed graph.  Wide path: Adam rides on the
+    // weight-gradient launch for the layers that launch writes in place; this step's lr_t reaches the (replayed) kernels
+    // through device memory (the copy from a pageable host variable is staged by the runtime before it returns)
+    const bool fuse = wide_adam_fusable(m, d);
+    if (fuse) {
+      const float sc[4] = {adam_lr_t(m, m->iterations + 1), m->cfg.beta1, m->cfg.beta2, m->cfg.eps};
+      HIPCHK(m, hipMemcpyAsync(m->adam_scal, sc, sizeof(sc), hipMemcpyHostToDevice, st));
+    }
+    m->fuse_adam_now = fuse;
+    const int rc = run_maybe_graph(m, st, make_key(fuse ? 9 : 2, d, yd, n_global), [&]() { return run_step(m, st, d, true, yd, n_global); });
+    m->fuse_adam_now = false;
+    CHK(rc);
+    CHK(launch_reduce_adam(m, st, 1, true, nullptr, loss_job(m, d, n_global), -1, fuse));
   } else {
     CHK(run_maybe_graph(m, st, make_key(3, d, yd, n_global), [&]() {
       CHK(run_step(m, st, d, true, yd, n_global));

@@ -1,6 +1,7 @@
 """End-to-end parity of the drop-in boundary (BS / GnnQModel / GnnEngine) on the GPU:
 golden vectors produced by the reference's own model code, oracle forward / backward / Adam,
 the Keras-like call surface and its error behaviour."""
+import contextlib
 import os
 
 import numpy as np
@@ -405,3 +406,62 @@ def test_graph_replay_of_train_steps_at_alternating_batch_sizes():
         lb = ref.train_step(pb, y)
         assert np.array_equal(la.cpu().numpy(), lb), B
         assert np.array_equal(eng.get_flat(), ref.get_flat()), B
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_wide_fit_step_with_adam_in_the_weight_gradient_launch(use_graph):
+    """BASELINE configs[3]'s shape (100 links x 256 features x 3 layers, per-node weights): a fit step applies Keras Adam
+    in the epilogue of the merged weight-gradient launch for the layers that launch writes in place (csrc/kernels_wide.hpp,
+    WideWgradArgs::adam) and k_reduce_adam covers the rest.  Three steps must equal (a) the split step forward_backward +
+    apply_gradients, where k_reduce_adam updates everything from the gradient buffer, and (b) the oracle's Keras Adam on the
+    engine's own gradients; eager and as a replayed hipGraph (lr_t reaches the replayed kernels through device memory)."""
+    import torch
+    from oracle.keras_semantics import KerasAdam
+    N, F, L, B = 100, 256, 3, 8
+    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L)
+    rng = np.random.default_rng(321)
+    P = f32_params(spec, rng)
+    x, e, adj = random_inputs(rng, B, N, ref_topology=True)
+    pb = PackedBatch.from_dense(x, e, adj)
+    y = rng.normal(0.0, 1.0, size=(B * N, 4)).astype(np.float32)
+    ctx = torch.cuda.stream(torch.cuda.Stream()) if use_graph else contextlib.nullcontext()
+    with ctx:
+        fused, split = GnnEngine(spec, use_graph=use_graph), GnnEngine(spec, use_graph=use_graph)
+        for eng in (fused, split):
+            eng.set_weights(oc.params_to_list(P))
+        db = fused.to_device(pb)
+        yd = torch.from_numpy(y).cuda()
+        names = set()
+        ref = oc.cast_params(P, np.float64)
+        opt = KerasAdam()
+        for step in range(3):
+            if step == 0 and not use_graph:
+                fused.profile(True)
+            lf = fused.train_step(db, yd)
+            if step == 0 and not use_graph:
+                names = set(fused.profile_read())
+                fused.profile(False)
+            ls = split.forward_backward(db, yd)
+            g = v2xgnn.flat_to_keras_list(spec, split.get_grad_flat())
+            split.apply_gradients()
+            torch.cuda.synchronize()
+            assert np.allclose(lf.cpu().numpy(), ls.cpu().numpy(), rtol=1e-5, atol=1e-7)
+            wf, ws = fused.get_flat(), split.get_flat()
+            # same gradients, same Adam expressions; the two kernels may contract their fused multiply-adds differently, and
+            # from the second step on the weights they differentiate at differ by that rounding: where a moment is at
+            # rounding-noise level the direction of Adam's (sign-like) step is not determined -- a handful of entries
+            err = np.abs(wf - ws)
+            tol = 2e-6 if step == 0 else 1e-5
+            assert (err > tol).mean() <= (0.0 if step == 0 else 1e-5), (step, err.max(), (err > tol).sum())
+            opt.step(oc.param_arrays(ref), oc.param_arrays(oc.params_from_list(ospec(spec), g, np.float64)))
+            for i, (a, b) in enumerate(zip(fused.get_weights(), oc.params_to_list(ref))):
+                e2 = np.abs(a.astype(np.float64) - b)
+                assert (e2 > 1e-5 * (step + 1)).mean() <= (0.0 if step == 0 else 1e-4), (step, i, e2.max())
+        mf, vf, itf = fused.get_optimizer_state()
+        ms, vs, its = split.get_optimizer_state()
+        assert itf == its == 3
+        assert np.allclose(mf, ms, rtol=1e-5, atol=1e-9) and np.allclose(vf, vs, rtol=1e-5, atol=1e-12)
+        if not use_graph:
+            assert "k_wgrad_wide_all" in names and "k_wgrad_gnn" not in names, names
+        fused.close()
+        split.close()

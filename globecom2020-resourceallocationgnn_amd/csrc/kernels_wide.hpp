@@ -342,18 +342,47 @@ __device__ __forceinline__ void wide_wgrad_body(const WideWgradArgs& a, float* s
       dst[off] = g;
     }
   };
+  // The accumulators leave through a wave-private LDS transpose: for a fixed (strip, r) a wave holds 4 weight rows x TN
+  // columns with a lane's values 16 columns apart; written to LDS and read back along the rows, every lane has float4s of
+  // consecutive columns -- 16-byte accesses on whole rows instead of 4-byte ones on 64-byte pieces (x 3 loads + 3 stores
+  // per element with Adam on board: the scalar form made the merged launch 200 us longer than the Adam launch it replaced;
+  // this form 105 us).  After the loop's last barrier nobody reads the operand tiles any more; a wave's LDS accesses
+  // execute in order.
+  constexpr int TNS = TN + ((TN % 64 == 16 || TN % 64 == 48) ? 0 : 16);     // row stride = 16 mod 32 banks: conflict-free writes
+  constexpr int C4 = TN / 4, NP4 = (4 * C4 + 63) / 64;
+  static_assert(4 * 4 * TNS <= 2 * WW_TR * LDD, "transpose buffer must fit the dpre tiles");
+  float* wbuf = sDp + wv * (4 * TNS);
+  auto emit4 = [&](int64_t off, f32x4 g) {
+    if (ADAM) {
+      f32x4 mo = ld4(pm + off), ve = ld4(pv + off), p = ld4(pp + off);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        mo[e] = b1 * mo[e] + (1.f - b1) * g[e];
+        ve[e] = b2 * ve[e] + (1.f - b2) * (g[e] * g[e]);
+        p[e] -= lr_t * mo[e] / (sqrtf(ve[e]) + eps);
+      }
+      st4(pm + off, mo); st4(pv + off, ve); st4(pp + off, p);
+    } else {
+      st4(dst + off, g);
+    }
+  };
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int kk = 64 * ks + 16 * wv + 4 * kg + r;
-      const int rr = kk < kw ? real_row(a.pad, kpad0 + kk) : -1;
-      if (rr < 0) continue;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int col = n0 + nt * 16 + j;
-        if (col < a.n_real) emit((int64_t)rr * a.n_real + col, acc[ks][nt][r]);
+      for (int nt = 0; nt < NT; ++nt) wbuf[kg * TNS + nt * 16 + j] = acc[ks][nt][r];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int p4 = 0; p4 < NP4; ++p4) {
+        const int i = lane + 64 * p4, row4 = min(i / C4, 3), c4 = i % C4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(wbuf + row4 * TNS + 4 * c4);
+        const int kk = 64 * ks + 16 * wv + 4 * row4 + r;
+        const int rr = kk < kw ? real_row(a.pad, kpad0 + kk) : -1;
+        const int col = n0 + 4 * c4;
+        if (i < 4 * C4 && rr >= 0 && col < a.n_real) emit4((int64_t)rr * a.n_real + col, v);
       }
+      __builtin_amdgcn_wave_barrier();
     }
   if (FOLD) {                                         // ... and dW[xseg_kpad + 4*kg + r][n0 + (wv + 4 t)*16 + j]
 #pragma unroll

@@ -1212,6 +1212,18 @@ struct LossJob { int n_out, n_idx, stride; float scale; int64_t slot_stride; }; 
 int64_t bucket_begin(const v2x_model* m, int bucket) { return bucket == 0 ? m->dense[0].off : 0; }
 int64_t bucket_end(const v2x_model* m, int bucket) { return bucket == 1 ? m->dense[0].off : m->P; }
 
+// Gradient buckets of the phased forward+backward (data parallelism, v2x_forward_backward_phase), in the order in which they
+// become final.  Narrow features (graph-major fused kernels: the graph layers finish together): [Dense layers], [graph
+// layers].  Wide features (layer-wise kernels, one weight-gradient launch per layer): [Dense layers], [stage L], ...,
+// [stage 1], [embed] -- L + 2 buckets, the all-reduce of each overlappable with the rest of the backward pass.
+int n_phase_buckets(const v2x_model* m) { return m->F >= 128 ? m->L + 2 : 2; }
+void phase_bucket_range(const v2x_model* m, int bucket, int64_t* b, int64_t* e) {
+  if (m->F < 128) { *b = bucket_begin(m, bucket); *e = bucket_end(m, bucket); return; }
+  if (bucket == 0) { *b = m->dense[0].off; *e = m->P; return; }
+  const LayerDesc& ld = m->gnn[m->L + 1 - bucket];
+  *b = ld.off; *e = ld.off + ld.slot_stride * m->S;
+}
+
 float adam_lr_t(const v2x_model* m, int64_t iteration) {
   const double t = (double)iteration;
   return (float)(m->cfg.lr * std::sqrt(1.0 - std::pow((double)m->cfg.beta2, t)) / (1.0 - std::pow((double)m->cfg.beta1, t)));
@@ -1220,7 +1232,8 @@ float adam_lr_t(const v2x_model* m, int64_t iteration) {
 // fused_adam: the layers gnn[1..L] and dense[0] were updated by their weight-gradient launch (WideWgradArgs::adam): this
 // launch covers what is left of the flat buffer, [0, gnn[1].off) and [dense[1].off, P)
 int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, float* grad_dst, LossJob lj = LossJob{0, 0, 0, 0.f, 0},
-                       int bucket = -1, bool fused_adam = false) {
+                       int bucket = -1, bool fused_adam = false, int64_t range_begin = -1, int64_t range_end = -1,
+                       bool advance_iteration = true) {
   AdamArgs a;
   memset(&a, 0, sizeof(a));
   a.param = m->params; a.grad = grad_dst ? grad_dst : m->grads; a.mom = m->mom; a.vel = m->vel;
@@ -1237,13 +1250,14 @@ int launch_reduce_adam(v2x_model* m, hipStream_t st, int n_slabs, bool do_adam, 
   }
   a.n4 = m->P / 4;
   a.range_begin4 = bucket_begin(m, bucket) / 4; a.range_end4 = bucket_end(m, bucket) / 4;
+  if (range_begin >= 0) { a.range_begin4 = range_begin / 4; a.range_end4 = range_end / 4; }
   if (fused_adam) {
     a.range_begin4 = 0; a.range_end4 = m->gnn[1].off / 4;
     a.range2_begin4 = m->dense[1].off / 4; a.range2_end4 = m->P / 4;
   }
   a.do_adam = do_adam ? 1 : 0;
   if (do_adam) {
-    m->iterations += 1;
+    if (advance_iteration) m->iterations += 1;
     a.lr_t = adam_lr_t(m, m->iterations);
     a.beta1 = m->cfg.beta1; a.beta2 = m->cfg.beta2; a.eps = m->cfg.eps;
     if (m->pk_fwd) { a.pack.fwd = m->pk_fwd; a.pack.bwd = m->pk_bwd; a.pack.F = m->F; a.pack.S = m->S; a.pack.L = m->L; a.pack.xr = m->Dn + m->De; }
@@ -1921,8 +1935,7 @@ static int fwd_bwd(v2x_model* m, const v2x_batch* b, const float* y, int y_on_de
 int v2x_forward_backward_phase(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device, int32_t n_global, int phase,
                                float* loss_out, int loss_on_device, void* stream) {
   if (!m) FAIL(m, V2X_EINVAL, "null model");
-  if (phase != 0 && phase != 1) FAIL(m, V2X_EINVAL, "forward_backward_phase: phase must be 0 or 1");
-  if (is_wide(m)) FAIL(m, V2X_EINVAL, "forward_backward_phase: narrow feature widths only (use v2x_forward_backward)");
+  if (phase < 0 || phase >= n_phase_buckets(m)) FAIL(m, V2X_EINVAL, "forward_backward_phase: phase must be in [0, %d)", n_phase_buckets(m));
   hipStream_t st = (hipStream_t)stream;
   HIPCHK(m, hipSetDevice(m->cfg.device));
   DevBatch d;
@@ -1934,6 +1947,39 @@ int v2x_forward_backward_phase(v2x_model* m, const v2x_batch* b, const float* y,
   const Range all{0, d.B};
   const IdxMap x = idx_map(m, d, all);
   const int F = m->F, L = m->L;
+  if (is_wide(m)) {
+    // one weight-gradient launch per layer: phase 0 = forward, decision MLP backward, the Dense layers' gradients; phase k =
+    // the data gradient handed down by stage s + 1 (not before: the all-reduce of the bucket a phase completes starts when the
+    // phase's LAST launch is done), the transposed aggregation and the weight gradient of stage s = L + 1 - k
+    if (phase > 0 && !m->have_fwd) FAIL(m, V2X_ESTATE, "forward_backward_phase: phase %d before phase 0", phase);
+    m->bucketed = true;
+    const int rc = run_maybe_graph(m, st, make_key(20 + phase, d, yd, n_global), [&]() -> int {
+      int64_t rb, re;
+      phase_bucket_range(m, phase, &rb, &re);
+      if (phase == 0) {
+        CHK(run_forward(m, st, d, all, true));
+        MlpArgs a;
+        mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
+        a.y = yd;
+        a.inv_denom = 1.0f / loss_denominator(m, n_global);
+        CHK(launch_mlp(m, st, a, true));
+        CHK(wgrad_mlp(m, st, x, d.xe, m->h[L], m->a[L]));
+        return launch_reduce_adam(m, st, 1, false, nullptr, LossJob{0, 0, 0, 0.f, 0}, -1, false, rb, re);
+      }
+      const int s = L + 1 - phase;
+      if (s < L) CHK(launch_dgrad(m, st, s + 1, x, m->dpre[s + 1], m->gha));
+      CHK(launch_agg(m, st, d, all, m->N, F, m->gha + F, 2 * F, m->gha, 2 * F, (s < L) ? m->h[s] : nullptr, m->dpre[s], 1));
+      CHK(wide_wgrad_gnn(m, st, s, x, d.xe, s ? m->h[s - 1] : nullptr, s ? m->a[s - 1] : d.nbr, m->dpre[s]));
+      const bool last = s == 0;
+      if (m->gnn[s].n_slabs > 0 || last)
+        return launch_reduce_adam(m, st, 1, false, nullptr, last ? loss_job(m, d, n_global) : LossJob{0, 0, 0, 0.f, 0}, -1, false, rb, re);
+      return V2X_OK;
+    });
+    m->bucketed = false;
+    CHK(rc);
+    if (phase == 0) m->have_fwd = true;
+    return phase == n_phase_buckets(m) - 1 ? emit_loss(m, loss_out, loss_on_device, st) : V2X_OK;
+  }
   if (phase == 0) {
     CHK(run_maybe_graph(m, st, make_key(5, d, yd, n_global), [&]() -> int {
       CHK(run_forward(m, st, d, all, !mlp_fused_training(m)));
@@ -1971,10 +2017,24 @@ int v2x_forward_backward_phase(v2x_model* m, const v2x_batch* b, const float* y,
   return emit_loss(m, loss_out, loss_on_device, st);
 }
 
+int v2x_grad_bucket_count(const v2x_model* m) { return m ? n_phase_buckets(m) : 0; }
+
 int64_t v2x_grad_bucket(const v2x_model* m, int bucket, int64_t* offset) {
-  if (!m || bucket < 0 || bucket > 1) return 0;
-  if (offset) *offset = bucket_begin(m, bucket);
-  return bucket_end(m, bucket) - bucket_begin(m, bucket);
+  if (!m || bucket < 0 || bucket >= n_phase_buckets(m)) return 0;
+  int64_t b, e;
+  phase_bucket_range(m, bucket, &b, &e);
+  if (offset) *offset = b;
+  return e - b;
+}
+
+int v2x_apply_gradients_range(v2x_model* m, int64_t offset, int64_t count, int advance_iteration, void* stream) {
+  if (!m) FAIL(m, V2X_EINVAL, "null model");
+  if (offset < 0 || count <= 0 || offset + count > m->P || (offset & 3) || (count & 3))
+    FAIL(m, V2X_EINVAL, "apply_gradients_range: [%lld, +%lld) must lie inside the %lld parameters and be float4-aligned",
+         (long long)offset, (long long)count, (long long)m->P);
+  HIPCHK(m, hipSetDevice(m->cfg.device));
+  return launch_reduce_adam(m, (hipStream_t)stream, 0, true, nullptr, LossJob{0, 0, 0, 0.f, 0}, -1, false, offset, offset + count,
+                            advance_iteration != 0);
 }
 
 int v2x_train_step(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device, int32_t n_graphs_global,

@@ -205,15 +205,37 @@ class GnnEngine(object):
         return self._step(self._lib.v2x_forward_backward, batch, y, n_global, want_loss)
 
     def forward_backward_phase(self, batch, y, phase, n_global=None, want_loss=True):
-        """forward_backward in two calls (v2x_forward_backward_phase): after phase 0 the Dense-layer gradient bucket is
-        final, after phase 1 the graph-layer bucket and the losses.  Device batches only."""
+        """forward_backward in len(grad_buckets()) calls (v2x_forward_backward_phase): after phase k bucket k of the gradient
+        is final; the last phase also gives the losses.  Device batches only."""
         fn = lambda h, s, yp, yd, ng, lo, ld, st: self._lib.v2x_forward_backward_phase(h, s, yp, yd, ng, int(phase), lo, ld, st)
-        return self._step(fn, batch, y, n_global, want_loss and phase == 1)
+        last = int(self._lib.v2x_grad_bucket_count(self._h)) - 1
+        return self._step(fn, batch, y, n_global, want_loss and phase == last)
+
+    def param_tensor(self):
+        """torch view (no copy) of the flat parameter buffer in HBM (the all-gather of a sharded optimizer step writes it).
+        Taking it tells the library that the parameters may change behind its back (v2x_param_ptr)."""
+        torch = _torch()
+        ptr = int(self._lib.v2x_param_ptr(self._h))
+
+        class _Holder(object):
+            pass
+        hld = _Holder()
+        hld.__cuda_array_interface__ = {"shape": (self.n_params,), "typestr": "<f4", "data": (ptr, False),
+                                        "version": 2, "strides": None}
+        t = torch.as_tensor(hld, device="cuda:%d" % self.device)
+        t._v2x_owner = self
+        return t
+
+    def apply_gradients_range(self, offset, count, advance_iteration):
+        """Keras Adam on parameters [offset, offset + count) only (v2x_apply_gradients_range)."""
+        self._check(self._lib.v2x_apply_gradients_range(self._h, int(offset), int(count), 1 if advance_iteration else 0,
+                                                        self._stream()))
 
     def grad_buckets(self):
-        """[(offset, count)] of the all-reduce buckets inside grad_tensor(), in the order they become final."""
+        """[(offset, count)] of the all-reduce buckets inside grad_tensor(), in the order they become final: phase k of
+        forward_backward_phase completes bucket k."""
         out = []
-        for b in (0, 1):
+        for b in range(int(self._lib.v2x_grad_bucket_count(self._h))):
             off = C.c_int64()
             n = int(self._lib.v2x_grad_bucket(self._h, b, C.byref(off)))
             out.append((int(off.value), n))

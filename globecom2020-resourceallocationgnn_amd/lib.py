@@ -57,6 +57,8 @@ SYMBOLS = [
     ("v2x_apply_gradients", C.c_int, [_P, _P]),
     ("v2x_forward_backward_phase", C.c_int, [_P, C.POINTER(Batch), _P, C.c_int, _I, C.c_int, _P, C.c_int, _P]),
     ("v2x_grad_bucket", _L, [_P, C.c_int, C.POINTER(_L)]),
+    ("v2x_grad_bucket_count", C.c_int, [_P]),
+    ("v2x_apply_gradients_range", C.c_int, [_P, _L, _L, C.c_int, _P]),
     ("v2x_agg_fwd", C.c_int, [C.POINTER(Batch), _I, _I, _P, _P, _P]),
     ("v2x_agg_bwd", C.c_int, [C.POINTER(Batch), _I, _I, _P, _P, _P]),
     ("v2x_node_update_fwd", C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P]),

@@ -134,14 +134,22 @@ int  v2x_train_step(v2x_model* m, const v2x_batch* b, const float* y, int y_on_d
 int  v2x_forward_backward(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device,
                           int32_t n_graphs_global, float* loss_out, int loss_on_device, void* stream);
 int  v2x_apply_gradients(v2x_model* m, void* stream);
-/* the same forward+backward in two calls, for overlapping the gradient all-reduce with the backward pass (feat_dim <= 64):
- *   phase 0: forward, decision MLP + Huber + its backward, the Dense layers' weight gradients -> bucket 0 is final
- *   phase 1: graph-layer backward and weight gradients -> bucket 1 is final; loss_out as above
- * v2x_grad_bucket gives a bucket's length and its offset (floats) inside v2x_grad_ptr(): bucket 0 = the Dense layers
- * (tail of the flat layout), bucket 1 = the graph layers (head).                                                        */
+/* the same forward+backward in v2x_grad_bucket_count(m) calls ("phases"), for overlapping the gradient all-reduce with the
+ * backward pass: after phase k, bucket k of the flat gradient is final and the host may start its collective while the
+ * later phases compute.  v2x_grad_bucket gives a bucket's length and its offset (floats) inside v2x_grad_ptr().
+ *   feat_dim <= 64 (graph-major fused kernels): 2 phases -- [the Dense layers] (tail of the flat layout), [the graph layers]
+ *   feat_dim >= 128 (one weight-gradient launch per layer): L + 2 phases -- [the Dense layers], [stage L], ..., [stage 1],
+ *     [embed]: 4.6 + 3 x 13.5 + 6.9 M floats at configs[3] ("bandwidth-bound, overlappable with the tail
+ *     of backward")
+ * loss_out is written by the last phase.  Phases must be called in order, 0 first.                                        */
 int  v2x_forward_backward_phase(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device,
                                 int32_t n_graphs_global, int phase, float* loss_out, int loss_on_device, void* stream);
+int  v2x_grad_bucket_count(const v2x_model* m);
 int64_t v2x_grad_bucket(const v2x_model* m, int bucket, int64_t* offset);
+/* Keras Adam on parameters [offset, offset + count) only (float4-aligned), from the gradient buffer: the optimizer step of
+ * a rank that owns a 1 / G slice of every bucket after a reduce-scatter (the host all-gathers the parameters afterwards).
+ * advance_iteration != 0 on the first call of a step (Adam's t), 0 on the others.                                       */
+int  v2x_apply_gradients_range(v2x_model* m, int64_t offset, int64_t count, int advance_iteration, void* stream);
 
 /* ---- per-kernel entry points (parity tests; all pointers [dev]) ------------------------ */
 /* AggLayer.call forward: out[q] = sum_{p in N(q)} h[p]            (BS_brain.py:69-76)      */

@@ -59,6 +59,83 @@ class OracleEngine(object):
     def grad_tensor(self):
         return self._g
 
+    # ---- the phased step and the sharded optimizer step of v2xgnn.dp (same contract as GnnEngine's)
+    phases_on_host = True
+
+    def _layer_sizes(self):
+        gnn = [sum(a.size for a in st.values()) for st in self.params['gnn']]
+        dense = [sum(a.size for a in st.values()) for st in self.params['dense']]
+        return gnn, dense
+
+    def grad_buckets(self):
+        """[(offset, count)] in the order the buckets become final; this engine's flat order is layer-major like the
+        library's: graph layers 0..L, then the Dense layers."""
+        gnn, dense = self._layer_sizes()
+        offs = np.concatenate([[0], np.cumsum(gnn + dense)])
+        L = len(gnn) - 1
+        if self.spec.feat_dim < 128:
+            return [(int(offs[L + 1]), int(sum(dense))), (0, int(offs[L + 1]))]
+        return [(int(offs[L + 1]), int(sum(dense)))] + [(int(offs[s]), int(gnn[s])) for s in range(L, -1, -1)]
+
+    def forward_backward_phase(self, batch, y, phase, n_global=None, want_loss=True):
+        """Phase 0 computes the step; phase k RELEASES bucket k into grad_tensor() -- everything not yet released reads NaN,
+        so a collective started too early poisons the result."""
+        buckets = self.grad_buckets()
+        if phase == 0:
+            self._phase_loss = self.forward_backward(batch, y, n_global, want_loss)
+            self._full = self._g.clone()
+            self._g.fill_(float('nan'))
+        off, n = buckets[phase]
+        self._g[off:off + n] = self._full[off:off + n]
+        return self._phase_loss if phase == len(buckets) - 1 else None
+
+    def param_tensor(self):
+        """flat float64 tensor of the parameters; params_changed() writes it back into the parameter arrays"""
+        self._pflat = torch.from_numpy(np.concatenate([np.asarray(a, np.float64).ravel() for a in oc.param_arrays(self.params)]))
+        return self._pflat
+
+    def _sync_pflat(self, offset, count):
+        """the updated range only: an all-gather into another range of the tensor may be in flight"""
+        if getattr(self, "_pflat", None) is not None:
+            flat = np.concatenate([np.asarray(a, np.float64).ravel() for a in oc.param_arrays(self.params)])
+            self._pflat[offset:offset + count] = torch.from_numpy(flat[offset:offset + count])
+
+    def params_changed(self):
+        flat, pos = self._pflat.numpy(), 0
+        for a in oc.param_arrays(self.params):
+            a[...] = flat[pos:pos + a.size].reshape(a.shape).astype(self.dtype)
+            pos += a.size
+
+    def apply_gradients_range(self, offset, count, advance_iteration):
+        """Keras Adam (keras_semantics.KerasAdam's expressions) on the flat range only; moments outside it are untouched."""
+        if self.opt.m is None:
+            self.opt.m = [np.zeros_like(p) for p in oc.param_arrays(self.params)]
+            self.opt.v = [np.zeros_like(p) for p in oc.param_arrays(self.params)]
+        if advance_iteration:
+            self.opt.iterations += 1
+        t = self.opt.iterations
+        dt = self.dtype
+        lr_t = dt(self.opt.lr * np.sqrt(1.0 - self.opt.b2 ** t) / (1.0 - self.opt.b1 ** t))
+        b1, b2, eps, one = dt(self.opt.b1), dt(self.opt.b2), dt(self.opt.eps), dt(1.0)
+        g_all, pos = self._g.numpy(), 0
+        for p, m, v in zip(oc.param_arrays(self.params), self.opt.m, self.opt.v):
+            lo, hi = max(offset, pos), min(offset + count, pos + p.size)
+            if lo < hi:
+                sl = slice(lo - pos, hi - pos)
+                pf, mf, vf = p.reshape(-1), m.reshape(-1), v.reshape(-1)
+                g = g_all[lo:hi].astype(dt)
+                mf[sl] = b1 * mf[sl] + (one - b1) * g
+                vf[sl] = b2 * vf[sl] + (one - b2) * (g * g)
+                pf[sl] -= lr_t * mf[sl] / (np.sqrt(vf[sl]) + eps)
+            pos += p.size
+        self._sync_pflat(offset, count)
+
+    def get_optimizer_state(self):
+        z = lambda arrs: np.concatenate([np.asarray(a, np.float64).ravel() for a in arrs])
+        if self.opt.m is None:
+            return np.zeros(self.n_params), np.zeros(self.n_params), self.opt.iterations
+        return z(self.opt.m), z(self.opt.v), self.opt.iterations
+
     def apply_gradients(self):
         flat = self._g.numpy()
         grads, pos = [], 0

@@ -178,3 +178,77 @@ def test_bench_starts_its_own_ranks():
     weak = res["config"]["weak"]
     assert weak["graphs_per_gpu"] == 512 and weak["global_batch"] == 1024 and weak["value"] > 0
     assert res["aggregation"] == "edge-gather" and res["fast_path"]["aggregation"] == "complement" and res["fast_path"]["value"] > 0
+
+
+def _wide_worker(rank, world, port, mode, ret):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from v2xgnn import GnnSpec, PackedBatch, GnnEngine
+        from v2xgnn.dp import DataParallelTrainer
+        from oracle import compact as oc
+        from util import f32_params, random_inputs
+        N, F, L, B = 12, 128, 2, 64
+        spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L)
+        rng = np.random.default_rng(5)
+        P = f32_params(spec, rng)
+        x, e, adj = random_inputs(rng, B, N)
+        y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+        pb = PackedBatch.from_dense(x, e, adj)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            eng = GnnEngine(spec, use_graph=(mode != "plain"))
+            eng.set_weights(oc.params_to_list(P))
+            tr = DataParallelTrainer(eng, overlap=(mode == "overlap"), shard_optimizer=(mode == "shard"))
+            sb, sy = tr.shard(pb, y)
+            db, yd = eng.to_device(sb), torch.from_numpy(np.ascontiguousarray(sy)).cuda()
+            torch.cuda.synchronize()
+            losses, grads = [], []
+            for _ in range(3):
+                losses.append(tr.train_step(db, yd, n_graphs_global=pb.n_graphs).cpu().numpy())
+                torch.cuda.synchronize()
+                grads.append(eng.get_grad_flat())
+            m, v, it = tr.gather_optimizer_state()
+        ret[rank] = (eng.get_flat(), np.stack(losses), np.stack(grads), m, v, it, eng.grad_buckets())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_wide_model_per_layer_buckets_and_sharded_optimizer():
+    """VERDICT r03 item 1c on the real engine (feat_dim 128, two ranks on the box's one GPU, gloo): the per-layer phases of
+    v2x_forward_backward_phase with one asynchronous all-reduce per bucket, and the sharded optimizer step (reduce-scatter
+    emulated by gloo's all-reduce, v2x_apply_gradients_range on the rank's half of every bucket, all-gather of the parameters
+    into the aliased parameter buffer), against the one-all-reduce step.  Per-layer launches and the merged single-GPU launch
+    sum rows in the same order, so the bucketed gradients are bit-identical to the single all-reduce's."""
+    import torch.multiprocessing as mp
+    runs = {}
+    for mode in ("plain", "overlap", "shard"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        ret = mp.Manager().dict()
+        mp.spawn(_wide_worker, args=(2, port, mode, ret), nprocs=2, join=True)
+        runs[mode] = dict(ret)
+    buckets = runs["plain"][0][6]
+    assert len(buckets) == 4 and buckets[3][0] == 0 and buckets[0][0] + buckets[0][1] == runs["plain"][0][0].size
+    for r in (0, 1):
+        w0, l0, g0 = runs["plain"][r][0], runs["plain"][r][1], runs["plain"][r][2]
+        assert np.all(np.isfinite(w0))
+        for mode in ("overlap", "shard"):
+            w, l, g = runs[mode][r][0], runs[mode][r][1], runs[mode][r][2]
+            assert np.allclose(l, l0, rtol=1e-6, atol=1e-8), mode
+            if mode == "overlap":
+                assert np.array_equal(g[0], g0[0]), "first step's bucketed gradients differ from the single all-reduce's"
+            # (later steps: the sharded / bucketed Adam and the single launch may contract their multiply-adds differently)
+            assert np.abs(w - w0).max() <= 2e-5, (mode, np.abs(w - w0).max())
+        m0, v0, it0 = runs["plain"][r][3], runs["plain"][r][4], runs["plain"][r][5]
+        ms, vs, its = runs["shard"][r][3], runs["shard"][r][4], runs["shard"][r][5]
+        assert it0 == its == 3
+        assert np.abs(ms - m0).max() <= 1e-4 * np.abs(m0).max() and np.abs(vs - v0).max() <= 1e-4 * np.abs(v0).max()
+    for mode in ("plain", "overlap", "shard"):
+        assert np.array_equal(runs[mode][0][0], runs[mode][1][0]), mode + ": replicas diverged"

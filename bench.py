@@ -299,9 +299,11 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
             "legs": legs}
 
 
-def rl_episode(links, feat, batch, gamma, train_steps, seed, engine_factory=None, device=0, use_graph=False, envs=0):
-    """One episode of the DQN loop (RL_Train_main.py:98-118 -> Agent.train, BS_brain.py:750-910) through the package's own
-    simulator / agent counterparts: train_steps x (50 rollout transitions + 1 replay of `batch`).  -> wall-clock split."""
+def rl_episode(links, feat, batch, gamma, train_steps, seed, engine_factory=None, device=0, use_graph=False, envs=0, episodes=1):
+    """`episodes` episodes of the DQN loop (RL_Train_main.py:98-118 -> Agent.train, BS_brain.py:750-910) through the package's
+    own simulator / agent counterparts: train_steps x (50 rollout transitions + 1 replay of `batch`) each.  The agent is
+    built once and runs a two-step warm-up episode first (allocations, hipGraph captures: the reference's Agent also lives
+    for the whole run, RL_Train_main.py:92-118); the timed region is Agent.train itself.  -> wall-clock split."""
     import random
     from v2xgnn.rl import Agent, RL_Config
     from v2xgnn.rl.train import start_env, start_env_batched
@@ -317,27 +319,37 @@ def rl_episode(links, feat, batch, gamma, train_steps, seed, engine_factory=None
     else:
         kw.update(device=device, use_graph=use_graph)
     agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, feat, env, cfg, **kw)
+    agent.train(1, 2)                                   # warm-up with THIS agent
     split = {"rollout_s": 0.0, "replay_s": 0.0}
     roll, rep = agent.generate_d2d_transition, agent.replay
+    rep_dev = getattr(agent, "_replay_on_device", None)
 
     def timed(fn, key):
         def inner(*a, **k):
             t0 = time.perf_counter()
             out = fn(*a, **k)
-            if engine_factory is None:
-                import torch
-                torch.cuda.synchronize()
-            split[key] += time.perf_counter() - t0
+            split[key] += time.perf_counter() - t0      # host time of the call: nothing synchronises the GPU here
             return out
         return inner
     agent.generate_d2d_transition, agent.replay = timed(roll, "rollout_s"), timed(rep, "replay_s")
+    if rep_dev is not None:
+        agent._replay_on_device = timed(rep_dev, "replay_s")
+    if engine_factory is None:
+        import torch
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    loss = agent.train(1, train_steps)[0]
+    loss = agent.train(episodes, train_steps)[0]
+    if engine_factory is None:
+        torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     assert np.all(np.isfinite(loss))
-    return {"wall_s": round(wall, 4), "train_steps_per_s": round(train_steps / wall, 3),
+    n = episodes * train_steps
+    return {"wall_s": round(wall, 4), "train_steps": n, "train_steps_per_s": round(n / wall, 3),
             "rollout_s": round(split["rollout_s"], 4), "replay_s": round(split["replay_s"], 4),
-            "env_steps": int(agent.num_step), "mean_loss": round(float(loss.mean()), 6)}
+            "ms_per_train_step": round(1e3 * wall / n, 3), "rollout_ms_per_step": round(1e3 * split["rollout_s"] / n, 3),
+            "replay_ms_per_step": round(1e3 * split["replay_s"] / n, 3),
+            "other_ms_per_step": round(1e3 * (wall - split["rollout_s"] - split["replay_s"]) / n, 3),
+            "env_steps": int(agent.num_step), "mean_loss": round(float(loss[:, -1].mean()), 6)}
 
 
 def _print_last(line):
@@ -353,31 +365,31 @@ def _print_last(line):
 
 
 def main_rl(args):
-    """--workload cfg0: BASELINE configs[0] (default Sim_Config: 4 links, 16 features, batch 256, gamma 0.2, one episode
-    of 20 train steps), on the engine and -- as cpu_baseline, kind "port" -- on the CPU oracle behind the same agent.
+    """--workload cfg0: BASELINE configs[0] (default Sim_Config: 4 links, 16 features, batch 256, gamma 0.2, episodes of 20
+    train steps), on the engine and -- as cpu_baseline, kind "port" -- on the CPU oracle behind the same agent.
     --workload cfg2loop: configs[2] on one GPU (20 links, 64 features, replay batch 4096, HBM-resident replay)."""
     import torch
     links, feat, batch, gamma = (4, 16, 256, 0.2) if args.workload == "cfg0" else (20, 64, 4096, 0.5)
-    steps = 20
+    steps, episodes = 20, max(1, args.episodes)
     ctx = torch.cuda.stream(torch.cuda.Stream())
     with ctx:
-        rl_episode(links, feat, batch, gamma, 2, 7, use_graph=True, envs=args.envs)   # warm-up: allocations, graph capture
-        gpu = rl_episode(links, feat, batch, gamma, steps, 1001, use_graph=True, envs=args.envs)
+        gpu = rl_episode(links, feat, batch, gamma, steps, 1001, use_graph=True, envs=args.envs, episodes=episodes)
     cpu = None
     if args.workload == "cfg0" and not args.no_cpu_baseline:
         from oracle.engine import OracleEngine
         r = rl_episode(links, feat, batch, gamma, steps, 1001, engine_factory=lambda spec: OracleEngine(spec, dtype=np.float32),
-                       envs=args.envs)
+                       envs=args.envs, episodes=1)
         cpu = {"value": r["train_steps_per_s"], "unit": "train-steps/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
-               "cpu_model": cpu_model(), "sample": "the same episode (seed 1001) with the numpy fp32 oracle as the Q-network", "detail": r}
+               "cpu_model": cpu_model(), "sample": "one episode (seed 1001, after the same warm-up) with the numpy fp32 oracle as the Q-network", "detail": r}
     _print_last(json.dumps({"metric": "DQN train steps/s (50 simulator transitions + 1 replay of batch %d each), %d V2V links, feat_dim %d"
                                 % (batch, links, feat),
-                      "value": gpu["train_steps_per_s"], "unit": "train-steps/s", "n_gpus": 1, "steps": steps, "warmup": 2,
-                      "ms_per_step": round(1e3 * gpu["wall_s"] / steps, 3), "higher_is_better": True, "scaling": "weak",
+                      "value": gpu["train_steps_per_s"], "unit": "train-steps/s", "n_gpus": 1, "steps": steps * episodes, "warmup": 2,
+                      "ms_per_step": gpu["ms_per_train_step"], "higher_is_better": True, "scaling": "weak",
                       "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded simulator)",
-                      "config": {"workload": "BASELINE.json configs[%d]: one episode = %d train steps x (50 rollouts + 1 replay), "
-                                             "%d links, feat_dim=%d, batch %d, gamma %g"
-                                             % (0 if args.workload == "cfg0" else 2, steps, links, feat, batch, gamma),
+                      "config": {"workload": "BASELINE.json configs[%d]: %d episode(s) x %d train steps x (50 rollouts + 1 replay), "
+                                             "%d links, feat_dim=%d, batch %d, gamma %g; one agent, two-step warm-up episode outside "
+                                             "the timed region"
+                                             % (0 if args.workload == "cfg0" else 2, episodes, steps, links, feat, batch, gamma),
                                  "simulators": ("%d stepped as arrays (rl/batched_env.py)" % args.envs) if args.envs > 0 else "1 (rl/environment.py)",
                                  "split": gpu}, "roofline": None, "cpu_baseline": cpu}))
 
@@ -492,6 +504,7 @@ def build_parser():
                     help="single-GPU rehearsal of a G-GPU strong-scaling run: time shard 0 of the global batch cut into G shards "
                          "(Huber mean over the global batch, no all-reduce); value = this shard's graphs / s")
     ap.add_argument("--envs", type=int, default=0, help="cfg0 / cfg2loop: number of simulators stepped as arrays (0 = the single one)")
+    ap.add_argument("--episodes", type=int, default=5, help="cfg0 / cfg2loop: timed episodes of 20 train steps")
     ap.add_argument("--no-fast-path", "--no-edge-gather", dest="no_fast_path", action="store_true",
                     help="skip the second timed pass with the complement aggregation (the fast path for complete-minus-few "
                          "graphs) that is printed beside the headline; the headline itself runs the general edge-index gather")

@@ -351,9 +351,11 @@ class Agent(object):
         # the reference reads "original" Q statistics from p AFTER it was overwritten in place (:684-690, :743-746)
         return result, q_mean, q_max_mean, q_mean.copy(), q_max_mean.copy()
 
-    def _replay_on_device(self):
+    def _replay_on_device(self, defer=False):
         """replay() with the minibatch gathered, scored, labelled and fitted in HBM.  Under data parallelism every
-        rank draws the same indices and processes only its own contiguous share of them."""
+        rank draws the same indices and processes only its own contiguous share of them.
+        defer: return (per-output losses, [Q mean; Q max mean]) as DEVICE tensors instead of the reference's tuple -- nothing
+        in the step then waits for the GPU (train() reads a whole episode's statistics back in one copy)."""
         from ..bs_brain import History
         n, B = self.num_D2D, self.batch_size
         model, target = self.brain.model, self.brain.target_model
@@ -384,6 +386,8 @@ class Agent(object):
         stats = rep.torch.stack([yv.sum(dim=(0, 2)) / self.num_Actions, yv.max(dim=2).values.sum(dim=0)])
         if trainer is not None and trainer.world > 1:
             trainer.dist.all_reduce(stats, group=trainer.group)
+        if defer and hasattr(loss, 'cpu'):
+            return loss, stats / B
         stats = (stats / B).cpu().numpy()
         loss = np.asarray(loss.cpu().numpy() if hasattr(loss, 'cpu') else loss, np.float64)
         result = History()
@@ -408,20 +412,38 @@ class Agent(object):
         self.num_step = 0
         reward_step = np.zeros((num_episodes, num_train_steps, self.num_transition))
         reward_episode = np.zeros(num_episodes)
+        # HBM-resident replay: the per-step losses and Q statistics stay on the device and are read back once per episode
+        # (the reference reads them after every fit, BS_brain.py:835-845 -- two host synchronisations per train step here)
+        defer = self.device_replay is not None and os.environ.get("V2X_RL_DEFER_STATS", "1") != "0"
         for ep in range(num_episodes):
             self.env.new_random_game(self.num_D2D)
+            pending = []
             for it in range(num_train_steps):
                 reward_step[ep, it, :] = self.generate_d2d_transition(self.num_transition)
-                result, qm, qx, _, _ = self.replay()
-                for k in range(n):
-                    loss[k, ep, it] = result.history['D%d_Decide_Output_loss' % (k + 1)][0]
-                q_mean[:, ep, it], q_max[:, ep, it] = qm, qx
+                if defer:
+                    out = self._replay_on_device(defer=True)
+                    if len(out) == 2:
+                        pending.append(out)
+                    else:
+                        result, qm, qx, _, _ = out
+                        defer = False
+                if not defer:
+                    result, qm, qx, _, _ = self.replay()
+                    for k in range(n):
+                        loss[k, ep, it] = result.history['D%d_Decide_Output_loss' % (k + 1)][0]
+                    q_mean[:, ep, it], q_max[:, ep, it] = qm, qx
                 # target sync whenever the job has collected another 500 transitions (BS_brain.py:846-847 tests
                 # num_step % 500 once per train step; num_step advances by 50 per step there, so this is the same rule)
                 mark = (self.num_step * world) // UPDATE_TARGET_FREQUENCY
                 if mark > self._sync_mark:
                     self._sync_mark = mark
                     self.brain.update_target_model()
+            if pending:
+                torch = self.device_replay.torch
+                lo = torch.stack([p[0].double() for p in pending]).cpu().numpy()            # [steps, n]
+                st = torch.stack([p[1] for p in pending]).cpu().numpy()                     # [steps, 2, n]
+                loss[:, ep, :len(pending)] = lo.T
+                q_mean[:, ep, :len(pending)], q_max[:, ep, :len(pending)] = st[:, 0].T, st[:, 1].T
             reward_episode[ep] = np.sum(reward_step[ep])
             if verbose:
                 print(datetime.datetime.now().strftime('%H:%M:%S'), 'episode', ep + 1, 'reward %.3f' % reward_episode[ep],

@@ -39,6 +39,8 @@ class DeviceReplay(object):
         self._stage = []
         self._row_ptr = {}
         self._bufs = {}
+        self._idx_ring = {}
+        self._n_staged = 0
         self._regular = np.ones(0, bool)       # host-side: slot holds a graph with in-degree n-2 everywhere
 
     # ------------------------------------------------------------------ storage
@@ -76,9 +78,11 @@ class DeviceReplay(object):
         regular = col.shape[0] == self.n_edges and not np.any(np.diff(row_ptr) != self.n - 2)
         mask = ((adj != 0).astype(np.int64) << np.arange(self.n, dtype=np.int64)[:, None]).sum(axis=0).astype(np.int32)   # [q]: bits p
         colrow = col.astype(np.int32) if regular else np.zeros(max(self.n_edges, 1), np.int32)
-        self._stage.append((pack_xe(np.asarray(x, np.float32), np.asarray(e, np.float32)),
-                            pack_xe(np.asarray(x_next, np.float32), np.asarray(e_next, np.float32)),
-                            colrow, np.asarray(action, np.int32).reshape(-1), float(reward), mask, regular))
+        self._stage.append((pack_xe(np.asarray(x, np.float32), np.asarray(e, np.float32))[None],
+                            pack_xe(np.asarray(x_next, np.float32), np.asarray(e_next, np.float32))[None],
+                            colrow[None], np.asarray(action, np.int32).reshape(1, -1), np.array([float(reward)], np.float64),
+                            mask[None], np.array([regular], bool)))
+        self._n_staged += 1
 
     def add_many(self, x, e, adj, action, reward, x_next, e_next):
         """K transitions at once (the batched rollout stores one per environment and step): x, x_next [K, n, Dn]; e, e_next
@@ -104,23 +108,22 @@ class DeviceReplay(object):
         xe_next = pack_xe(xn.reshape(K * n, -1), en.reshape(K * n, -1)).reshape(K, n, -1)
         action = np.asarray(action, np.int32).reshape(K, n)
         reward = np.asarray(reward, np.float64).reshape(K)
-        for k in range(K):
-            self._stage.append((xe[k], xe_next[k], col[k], action[k], float(reward[k]), mask[k], bool(regular[k])))
+        self._stage.append((xe, xe_next, col, action, reward, mask, regular))      # one block of K transitions
+        self._n_staged += K
 
     def __len__(self):
-        return min(self.capacity, self.size + len(self._stage))
+        return min(self.capacity, self.size + self._n_staged)
 
     def flush(self):
         """Staged transitions -> HBM (one copy per tensor; ring wrap handled by splitting at the end of the storage)."""
         if not self._stage:
             return
         torch = self.torch
-        k = len(self._stage)
+        k = self._n_staged
         self._grow(min(self.capacity, self.size + k))
-        cols = [np.stack([s[i] for s in self._stage]) for i in range(4)]
-        cols.append(np.array([s[4] for s in self._stage], np.float64))
-        cols.append(np.stack([s[5] for s in self._stage]))
-        regular = np.array([s[6] for s in self._stage], bool)
+        one = len(self._stage) == 1                  # the batched rollout stages one block per train step: no re-stacking
+        cols = [self._stage[0][i] if one else np.concatenate([s[i] for s in self._stage]) for i in range(6)]
+        regular = self._stage[0][6] if one else np.concatenate([s[6] for s in self._stage])
         dst = (self.xe, self.xe_next, self.col, self.action, self.reward, self.mask)
         pos, done = self.head, 0
         while done < k:
@@ -134,6 +137,7 @@ class DeviceReplay(object):
         self.head = pos
         self.size = min(self.capacity, self.size + k)
         self._stage = []
+        self._n_staged = 0
 
     # ------------------------------------------------------------------ sampling
     def _gather(self, src, idx_dev, k, name):
@@ -149,6 +153,25 @@ class DeviceReplay(object):
                                        current_stream_ptr(self.device.index))
         _lib.check(self._lib, rc, None)
         return out
+
+    def _upload_indices(self, slots):
+        """The storage slots of a minibatch -> HBM without a blocking copy: through one of four pinned staging buffers
+        (a pinned source makes the copy asynchronous; its event guards the buffer's reuse) into a device buffer whose address
+        does not change."""
+        torch, k = self.torch, len(slots)
+        ring = self._idx_ring.setdefault(k, {"pin": [torch.empty(k, dtype=torch.int32).pin_memory() for _ in range(4)],
+                                             "ev": [None] * 4, "dev": torch.empty(k, dtype=torch.int32, device=self.device),
+                                             "next": 0})
+        i = ring["next"]
+        ring["next"] = (i + 1) % 4
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()
+        ring["pin"][i].numpy()[:] = slots
+        ring["dev"].copy_(ring["pin"][i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["ev"][i] = ev
+        return ring["dev"]
 
     def row_ptr(self, k):
         if k not in self._row_ptr:
@@ -168,7 +191,7 @@ class DeviceReplay(object):
         torch = self.torch
         k = len(idx)
         slots = self.logical_to_slot(idx)
-        idx_dev = torch.from_numpy(slots).to(self.device)
+        idx_dev = self._upload_indices(slots)
         xe = self._gather(self.xe, idx_dev, k, 'xe').view(k * self.n, 16)
         xe_next = self._gather(self.xe_next, idx_dev, k, 'xe_next').view(k * self.n, 16)
         action = self._gather(self.action, idx_dev, k, 'action')

@@ -278,8 +278,9 @@ def test_device_replay_add_many_stages_what_add_stages():
     for k in range(K):
         one.add(x[k], e[k], adj[k], act[k], rew[k], x2[k], e2[k])
     many.add_many(x, e, adj, act, rew, x2, e2)
-    assert len(one._stage) == len(many._stage) == K
-    for a, b in zip(one._stage, many._stage):
-        for u, v in zip(a, b):
-            assert np.array_equal(np.asarray(u), np.asarray(v)), (u, v)
-    assert [s[6] for s in many._stage] == [True, True, True, False, True, True, True]
+    # (staged as blocks of transitions: K blocks of one against one block of K)
+    assert len(one) == len(many) == K and len(one._stage) == K and len(many._stage) == 1
+    for i in range(7):
+        u, v = np.concatenate([s[i] for s in one._stage]), many._stage[0][i]
+        assert u.dtype == np.asarray(v).dtype and np.array_equal(u, np.asarray(v)), i
+    assert list(many._stage[0][6]) == [True, True, True, False, True, True, True]

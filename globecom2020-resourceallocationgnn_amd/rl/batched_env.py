@@ -129,20 +129,27 @@ class BatchedEnviron(object):
         self.dest = np.zeros((E, N), np.int64)
         self._v2v_shadow = np.zeros((E, N, N))
         self._v2i_shadow = np.zeros((E, N))
+        import random as _stdlib_random
+        fast = _stdlib_random.Random()
         with self._rng() as rs:
             for e, s in enumerate(rs):
+                # the scalar integer draws of a reset (5 per vehicle) at the stdlib generator's C speed: MTStream IS that
+                # generator draw for draw, so its state is lent out and taken back (one state copy each way per environment
+                # instead of a numpy round trip per draw: 5,000 draws per reset of 50 environments x 20 links)
+                fast.setstate(s._export())
                 k = 0
                 for _ in range(N // 4):                        # add_new_vehicles_by_number (:217-234)
-                    ind = s.randrange(0, len(p.down_lanes))
+                    ind = fast.randrange(0, len(p.down_lanes))
                     for code, lane_x, lane_y in ((1, p.down_lanes[ind], None), (0, p.up_lanes[ind], None),
                                                  (2, None, p.left_lanes[ind]), (3, None, p.right_lanes[ind])):
                         if lane_y is None:
-                            self.pos[e, k] = (lane_x, s.randint(0, p.height))
+                            self.pos[e, k] = (lane_x, fast.randint(0, p.height))
                         else:
-                            self.pos[e, k] = (s.randint(0, p.width), lane_y)
+                            self.pos[e, k] = (fast.randint(0, p.width), lane_y)
                         self.dirs[e, k] = code
-                        self.vel[e, k] = s.randint(10, 15)
+                        self.vel[e, k] = fast.randint(10, 15)
                         k += 1
+                s._import(fast.getstate())
                 s.gauss_array((N, N), 3)                        # V2V_Shadowing / V2I_Shadowing: drawn, never used (:232-233)
                 s.gauss_array((N,), 8)
                 self._v2v_shadow[e] = s.gauss_array((N, N), Environ.V2V_SHADOW_STD)
@@ -150,11 +157,12 @@ class BatchedEnviron(object):
         self.renew_channels_fastfading()
         with self._rng() as rs:                                # renew_neighbor (:360-376)
             for e, s in enumerate(rs):
-                z = np.array([[complex(x, y) for x, y in self.pos[e]]])
-                dist = abs(z.T - z)
+                z = self.pos[e, :, 0] + 1j * self.pos[e, :, 1]
+                order = np.argsort(np.abs(z[:, None] - z[None, :]), axis=0)          # column i: nodes by distance from i
+                fast.setstate(s._export())
                 for i in range(N):
-                    order = np.argsort(dist[:, i])
-                    self.dest[e, i] = s.sample(list(order[1:(len(order) - 2)]), 1)[0]
+                    self.dest[e, i] = fast.sample(list(order[1:N - 2, i]), 1)[0]
+                s._import(fast.getstate())
         self.activate_links = np.ones((E, N, 1), dtype=bool)
 
     # ------------------------------------------------------------------ mobility

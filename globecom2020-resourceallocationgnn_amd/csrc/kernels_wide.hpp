@@ -499,6 +499,9 @@ struct AggDenseArgs {
   int n_fg;                             // 64-wide feature groups per graph (one workgroup each)
   int rows_cap, mask_words;             // rows_cap: max nodes rounded up to 16
   int* err;                             // host-visible flag word (bit 0: a graph exceeds rows_cap)
+  // k_adj_masks only: the work plan of the ragged fused forward (kernels_ragged.hpp) -- plan[w] = first graph whose first row
+  // is >= w * plan_capp, w = 0 .. plan_n (plan[plan_n] = n_graphs); written by one thread per graph, no search
+  int32_t* plan; int plan_capp, plan_n;
 };
 
 // CSR-by-destination -> per-source bit masks, one workgroup per graph (integer atomics in LDS: order-independent).
@@ -512,6 +515,12 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
   const int g = a.g_base + blockIdx.x;
   const int r_begin = a.graph_off ? a.graph_off[g] : g * a.n_nodes;
   const int n = (a.graph_off ? a.graph_off[g + 1] : r_begin + a.n_nodes) - r_begin;
+  if (a.plan && tid == 0) {
+    const int prev = g > a.g_base ? (a.graph_off ? a.graph_off[g - 1] : (g - 1) * a.n_nodes) : -1;
+    for (int w = prev < 0 ? 0 : prev / a.plan_capp + 1; w <= r_begin / a.plan_capp && w <= a.plan_n; ++w) a.plan[w] = g;
+    if (blockIdx.x == (unsigned)a.n_graphs - 1)
+      for (int w = r_begin / a.plan_capp + 1; w <= a.plan_n; ++w) a.plan[w] = a.g_base + a.n_graphs;
+  }
   if (n > a.rows_cap || n < 0) { if (tid == 0 && a.err) atomicOr(a.err, 1); return; }
   int* sR = reinterpret_cast<int*>(sD + a.rows_cap * a.mask_words);         // [rows_cap + 1] the graph's slice of row_ptr
   for (int i = tid; i <= n; i += 256) sR[i] = a.row_ptr[r_begin + i];

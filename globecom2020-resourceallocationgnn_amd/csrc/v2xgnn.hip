@@ -7,6 +7,7 @@
 #include "kernels_fused.hpp"
 #include "kernels_mlpwg.hpp"
 #include "kernels_small.hpp"
+#include "kernels_ragged.hpp"
 #include "host_pack.hpp"
 
 #include <hip/hip_runtime.h>
@@ -77,6 +78,7 @@ struct v2x_model {
   // staging for host-side inputs
   DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
   DevBuf adj_mask;              // adjacency bit masks of the current batch (dense-graph aggregation)
+  DevBuf plan_buf;              // work plan of the ragged fused forward (kernels_ragged.hpp): first graph per row interval
   long long* ts_buf = nullptr;                  // V2X_FUSED_TS=1: phase time stamps of the fused forward (measurement)
   bool raw_params = false;                      // v2x_param_ptr was called: re-pack before every fused forward
   bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
@@ -1441,10 +1443,77 @@ int launch_small_forward(v2x_model* m, hipStream_t st, const DevBatch& d, float*
   FAIL(m, V2X_EINVAL, "small forward: unsupported feat_dim %d", m->F);
 }
 
+// ------------------------------------------------------------------------------------ ragged fused forward
+// (kernels_ragged.hpp) variable-size graphs of <= 128 nodes, shared weights, narrow features, dense enough for the bit masks
+bool ragged_fused_path(const v2x_model* m, const DevBatch& d) {
+  static const int on = env_int("V2X_RAGGED_FUSED", 1);
+  return on && m->cfg.variable_graphs && m->S == 1 && d.goff && !d.nbr && m->F <= 64 && m->L <= FZ_MAXL && d.max_nodes <= 128 &&
+         d.max_nodes <= RG_CAP / 2 && use_dense_agg(d, m->F);
+}
+int ragged_capp(const DevBatch& d) { return RG_CAP - d.max_nodes + 1; }
+int ragged_wgs(const DevBatch& d) { return (d.R + ragged_capp(d) - 1) / ragged_capp(d); }
+
+template <int F>
+int launch_ragged_fwd_f(v2x_model* m, hipStream_t st, const RaggedFwdArgs& a, int n_wgs) {
+  auto k = k_gnn_fwd_ragged<F>;
+  static const bool once = [] { allow_big_lds((const void*)k_gnn_fwd_ragged<F>); return true; }();
+  (void)once;
+  LAUNCH_T(m, "k_gnn_fwd_ragged", k, dim3(n_wgs), RG_THREADS, (size_t)RaggedLds<F>::TOTAL * 4, st, a);
+  return V2X_OK;
+}
+
+int launch_ragged_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
+  RaggedFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.xe = d.xe; a.graph_off = d.goff; a.row_ptr = d.rp;
+  a.mask_words = (d.max_nodes + 31) / 32;
+  a.adjT = (const unsigned*)m->adj_mask.p + (size_t)d.R * a.mask_words;
+  a.plan = (const int32_t*)m->plan_buf.p;
+  for (int s = 0; s <= m->L; ++s) { a.W[s] = m->params + m->gnn[s].off; a.h[s] = m->h[s]; a.a[s] = m->a[s]; }
+  a.n_graphs = d.B; a.n_rows = d.R; a.L = m->L; a.capp = ragged_capp(d); a.xr = m->Dn + m->De; a.err = m->flag_dev;
+  a.ts = m->ts_buf;
+  const int n_wgs = ragged_wgs(d);
+  switch (m->F) {
+    case 16: return launch_ragged_fwd_f<16>(m, st, a, n_wgs);
+    case 32: return launch_ragged_fwd_f<32>(m, st, a, n_wgs);
+    case 64: return launch_ragged_fwd_f<64>(m, st, a, n_wgs);
+  }
+  FAIL(m, V2X_EINVAL, "ragged forward: unsupported feat_dim %d", m->F);
+}
+
+template <int F>
+int launch_ragged_bwd_f(v2x_model* m, hipStream_t st, const RaggedBwdArgs& a, int n_wgs) {
+  auto k = k_gnn_bwd_ragged<F>;
+  static const bool once = [] { allow_big_lds((const void*)k_gnn_bwd_ragged<F>); return true; }();
+  (void)once;
+  LAUNCH_T(m, "k_gnn_bwd_ragged", k, dim3(n_wgs), RG_THREADS, (size_t)RaggedBwdLds<F>::TOTAL * 4, st, a);
+  return V2X_OK;
+}
+
+// L + 1 transposed aggregations + L data gradients of ragged graphs in one launch (masks and plan: the forward's)
+int launch_ragged_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
+  RaggedBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.gha = m->gha; a.graph_off = d.goff;
+  a.mask_words = (d.max_nodes + 31) / 32;
+  a.adj = (const unsigned*)m->adj_mask.p;
+  a.plan = (const int32_t*)m->plan_buf.p;
+  for (int s = 0; s <= m->L; ++s) { a.W[s] = m->params + m->gnn[s].off; a.h[s] = m->h[s]; a.dpre[s] = m->dpre[s]; }
+  a.n_graphs = d.B; a.n_rows = d.R; a.L = m->L; a.capp = ragged_capp(d); a.xr = m->Dn + m->De; a.err = m->flag_dev;
+  const int n_wgs = ragged_wgs(d);
+  switch (m->F) {
+    case 16: return launch_ragged_bwd_f<16>(m, st, a, n_wgs);
+    case 32: return launch_ragged_bwd_f<32>(m, st, a, n_wgs);
+    case 64: return launch_ragged_bwd_f<64>(m, st, a, n_wgs);
+  }
+  FAIL(m, V2X_EINVAL, "ragged backward: unsupported feat_dim %d", m->F);
+}
+
 int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool with_mlp = true) {
   const int F = m->F, L = m->L;
   const IdxMap x = idx_map(m, d, r);
   m->frag_live = !with_mlp && frag_layout(m, d, r);
+  const bool ragged = ragged_fused_path(m, d) && r.g0 == 0 && r.ng == d.B;
   if (fused_path(m, d) && r.g0 == 0 && r.ng == d.B) {
     CHK(launch_fused_fwd(m, st, d, m->frag_live));       // embed + L stages + L+1 aggregations: one launch
   } else {
@@ -1453,7 +1522,12 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
       q.adj = (unsigned*)m->adj_mask.p;
       q.adjT = q.adj + (size_t)d.R * q.mask_words;
       q.err = m->flag_dev;
+      if (ragged) { q.plan = (int32_t*)m->plan_buf.p; q.plan_capp = ragged_capp(d); q.plan_n = ragged_wgs(d); }
       CHK(build_adj_masks(m, st, q));
+    }
+    if (ragged) {                                        // embed + L stages + L + 1 aggregations of ragged graphs: one launch
+      CHK(launch_ragged_fwd(m, st, d));
+      goto mlp;
     }
     CHK(launch_node_fwd(m, st, 0, x, d.xe, nullptr, d.nbr, m->h[0]));
     CHK(launch_agg(m, st, d, r, m->N, F, m->h[0], F, nullptr, 0, nullptr, m->a[0], 0));
@@ -1462,6 +1536,7 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
       CHK(launch_agg(m, st, d, r, m->N, F, m->h[s], F, nullptr, 0, nullptr, m->a[s], 0));
     }
   }
+mlp:
   if (!with_mlp) return V2X_OK;          // training: the MLP runs fused with its backward (k_mlp_train)
   MlpArgs a;
   mlp_args(m, a, x, d.xe, m->h[L], m->a[L]);
@@ -1514,8 +1589,11 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   static const bool per_stage = env_int("V2X_WG_PER_STAGE", 0) != 0;
   const bool split = two && per_stage && !is_wide(m);
   const bool fused = fused_path(m, d) && r.g0 == 0 && r.ng == d.B && !split;
+  static const int ragged_bwd = env_int("V2X_RAGGED_FUSED_BWD", 1);
   if (fused) {
     CHK(launch_fused_bwd(m, st, d));       // L+1 transposed aggregations + L data gradients: one launch
+  } else if (ragged_bwd && !split && ragged_fused_path(m, d) && r.g0 == 0 && r.ng == d.B) {
+    CHK(launch_ragged_bwd(m, st, d));      // the same for ragged graphs (masks and plan from this step's forward)
   } else {
     for (int s = L; s >= 1; --s) {
       // dpre_s = (dh_direct + Agg^T(dagg)) * relu'(h_s)
@@ -1633,6 +1711,7 @@ int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
 int presize(v2x_model* m, const DevBatch& d) {
   CHK(ensure_rows(m, d.R));
   if (use_dense_agg(d, m->F)) CHK(ensure(m, m->adj_mask, (size_t)2 * d.R * ((d.max_nodes + 31) / 32) * 4));
+  if (ragged_fused_path(m, d)) CHK(ensure(m, m->plan_buf, (size_t)(ragged_wgs(d) + 2) * 4));
   const IdxMap x = idx_map(m, d, Range{0, d.B});
   CHK(ensure_slabs(m, max_slabs(m, x.n_idx, x.grid_y)));
   return V2X_OK;
@@ -1742,7 +1821,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
       return fail("allocation");
     m->pk_stale = true;             // first forward packs whatever the parameters are by then
   }
-  if (m->pk_fwd && env_int("V2X_FUSED_TS", 0)) {
+  if ((m->pk_fwd || m->cfg.variable_graphs) && env_int("V2X_FUSED_TS", 0)) {
     if (dev_alloc(m, &m->ts_buf, 4 * 8 * 64)) return fail("allocation");
     hipMemset(m->ts_buf, 0, 4 * 8 * 64 * 8);
   }
@@ -1777,7 +1856,7 @@ void v2x_destroy(v2x_model* m) {
   for (float* p : ptrs) if (p) hipFree(p);
   for (float* p : m->h) if (p) hipFree(p);
   for (float* p : m->a) if (p) hipFree(p);
-  DevBuf* bufs[] = {&m->st_xe, &m->st_nbr, &m->st_goff, &m->st_rp, &m->st_ci, &m->st_y, &m->st_q, &m->adj_mask};
+  DevBuf* bufs[] = {&m->st_xe, &m->st_nbr, &m->st_goff, &m->st_rp, &m->st_ci, &m->st_y, &m->st_q, &m->adj_mask, &m->plan_buf};
   for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
   if (m->flag_host) hipHostFree(m->flag_host);
   if (m->ts_buf) hipFree(m->ts_buf);
@@ -2311,7 +2390,8 @@ int v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap) {
   const bool fused = fused_path(m, d);
   const char* agg = fused ? (fused_compl(m, d) ? "complement" : "edge-gather")
                           : (use_dense_agg(d, m->F) ? "dense(complement-or-mfma-per-graph)" : "edge-gather");
-  snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s", fused ? "fused" : "layerwise", agg,
+  snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s",
+           fused ? "fused" : (ragged_fused_path(m, d) ? "fused(ragged)" : "layerwise"), agg,
            mlp_wg_path(m) ? "train_wg" : (mlp_fused_training(m) ? "train" : "fwd+bwd"),
            frag_layout(m, d, Range{0, d.B}) ? "fragment-major" : "row-major");
   return V2X_OK;

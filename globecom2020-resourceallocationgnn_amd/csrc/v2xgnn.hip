@@ -83,6 +83,7 @@ struct v2x_model {
   bool raw_params = false;                      // v2x_param_ptr was called: re-pack before every fused forward
   bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
   bool compl_sums = true;                       // V2X_FUSED_COMPL (read at create): dense graphs aggregate through the complement
+  bool ragged_fused = true, ragged_fused_bwd = true;   // V2X_RAGGED_FUSED / V2X_RAGGED_FUSED_BWD (read at create): kernels_ragged.hpp
   bool small_predict = true;                    // V2X_SMALL_PREDICT (read at create): few-graph forwards in one launch (kernels_small.hpp)
   unsigned long long* small_h = nullptr;        // its exchange buffer [L + 1][SMALL_ROWS][F] tagged words
   unsigned long long* small_sync = nullptr;     // and per-graph departure counters [SMALL_ROWS] (64-bit)
@@ -1446,10 +1447,12 @@ int launch_small_forward(v2x_model* m, hipStream_t st, const DevBatch& d, float*
 // ------------------------------------------------------------------------------------ ragged fused forward
 // (kernels_ragged.hpp) variable-size graphs of <= 128 nodes, shared weights, narrow features, dense enough for the bit masks
 bool ragged_fused_path(const v2x_model* m, const DevBatch& d) {
-  static const int on = env_int("V2X_RAGGED_FUSED", 1);
-  return on && m->cfg.variable_graphs && m->S == 1 && d.goff && !d.nbr && m->F <= 64 && m->L <= FZ_MAXL && d.max_nodes <= 128 &&
-         d.max_nodes <= RG_CAP / 2 && use_dense_agg(d, m->F);
+  // (any density: a row's aggregation walks its mask's one bits or -- rows with more edges than non-edges in graphs of >= 16
+  //  nodes -- the zero bits; the masks are built for this path whether or not the dense MFMA aggregation wants them)
+  return m->ragged_fused && m->cfg.variable_graphs && m->S == 1 && d.goff && !d.nbr && m->F <= 64 && m->L <= FZ_MAXL && d.max_nodes <= 128 &&
+         d.max_nodes <= RG_CAP / 2;
 }
+bool need_adj_masks(const v2x_model* m, const DevBatch& d) { return use_dense_agg(d, m->F) || ragged_fused_path(m, d); }
 int ragged_capp(const DevBatch& d) { return RG_CAP - d.max_nodes + 1; }
 int ragged_wgs(const DevBatch& d) { return (d.R + ragged_capp(d) - 1) / ragged_capp(d); }
 
@@ -1517,7 +1520,7 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
   if (fused_path(m, d) && r.g0 == 0 && r.ng == d.B) {
     CHK(launch_fused_fwd(m, st, d, m->frag_live));       // embed + L stages + L+1 aggregations: one launch
   } else {
-    if (use_dense_agg(d, F)) {
+    if (need_adj_masks(m, d)) {
       AggDenseArgs q = agg_dense_args(d, r, m->N, F);
       q.adj = (unsigned*)m->adj_mask.p;
       q.adjT = q.adj + (size_t)d.R * q.mask_words;
@@ -1589,7 +1592,7 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   static const bool per_stage = env_int("V2X_WG_PER_STAGE", 0) != 0;
   const bool split = two && per_stage && !is_wide(m);
   const bool fused = fused_path(m, d) && r.g0 == 0 && r.ng == d.B && !split;
-  static const int ragged_bwd = env_int("V2X_RAGGED_FUSED_BWD", 1);
+  const bool ragged_bwd = m->ragged_fused_bwd;
   if (fused) {
     CHK(launch_fused_bwd(m, st, d));       // L+1 transposed aggregations + L data gradients: one launch
   } else if (ragged_bwd && !split && ragged_fused_path(m, d) && r.g0 == 0 && r.ng == d.B) {
@@ -1710,7 +1713,7 @@ int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
 
 int presize(v2x_model* m, const DevBatch& d) {
   CHK(ensure_rows(m, d.R));
-  if (use_dense_agg(d, m->F)) CHK(ensure(m, m->adj_mask, (size_t)2 * d.R * ((d.max_nodes + 31) / 32) * 4));
+  if (need_adj_masks(m, d)) CHK(ensure(m, m->adj_mask, (size_t)2 * d.R * ((d.max_nodes + 31) / 32) * 4));
   if (ragged_fused_path(m, d)) CHK(ensure(m, m->plan_buf, (size_t)(ragged_wgs(d) + 2) * 4));
   const IdxMap x = idx_map(m, d, Range{0, d.B});
   CHK(ensure_slabs(m, max_slabs(m, x.n_idx, x.grid_y)));
@@ -1797,6 +1800,8 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   // the two paths agree bitwise
   m->compl_sums = env_int("V2X_FUSED_COMPL", 1) != 0;
   m->small_predict = env_int("V2X_SMALL_PREDICT", 1) != 0;
+  m->ragged_fused = env_int("V2X_RAGGED_FUSED", 1) != 0;
+  m->ragged_fused_bwd = env_int("V2X_RAGGED_FUSED_BWD", 1) != 0;
   if (m->small_predict && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
     const size_t hb = (size_t)(m->L + 1) * SMALL_ROWS * m->F * sizeof(unsigned long long), sb = (size_t)2 * SMALL_ROWS * sizeof(unsigned);
     void *ph = nullptr, *ps = nullptr;

@@ -7,7 +7,8 @@ import pytest
 
 import v2xgnn
 from v2xgnn import GnnSpec, PackedBatch, GnnEngine
-from util import ospec, random_inputs, f32_params, assert_fwd_close, assert_grad_close, assert_close
+from util import (ospec, random_inputs, f32_params, assert_fwd_close, assert_grad_close, assert_close, oracle_step,
+                  assert_grads_match_oracle)
 from oracle import compact as oc
 
 pytestmark = pytest.mark.gpu
@@ -224,3 +225,87 @@ def test_two_phase_step_equals_single_call(N, F, B, use_graph):
             one.apply_gradients()
             two.apply_gradients()
     assert np.allclose(one.get_flat(), two.get_flat(), rtol=1e-6, atol=1e-8)
+
+
+def _ragged_batch(rng, sizes, kind):
+    """kind: 'ref' = the reference topology (in-degree n - 2), 'mixed' = per graph one of: reference, half-dense random,
+    sparse random; a few rows of the larger graphs lose ALL their in-edges (isolated destinations)."""
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    R = int(offs[-1])
+    row_ptr, cols, max_e = [0], [], 0
+    for gi, n in enumerate(sizes):
+        mode = 0 if kind == 'ref' else gi % 3
+        if mode == 0:
+            adj = ~np.eye(n, dtype=bool)
+            if n > 1:
+                dest = rng.integers(0, n - 1, size=n)
+                dest = dest + (dest >= np.arange(n))
+                adj[dest, np.arange(n)] = False
+        elif mode == 1:
+            adj = rng.uniform(size=(n, n)) < 0.55
+        else:
+            adj = rng.uniform(size=(n, n)) < 0.3
+        if kind == 'mixed' and n >= 20:
+            adj[:, rng.integers(0, n, size=2)] = False        # destinations with no in-neighbour at all
+            adj[rng.integers(0, n)] = False                   # a source nobody hears
+        e_g = 0
+        for q in range(n):
+            src = np.nonzero(adj[:, q])[0]
+            cols.append(src)
+            row_ptr.append(row_ptr[-1] + len(src))
+            e_g += len(src)
+        max_e = max(max_e, e_g)
+    col_idx = np.concatenate(cols).astype(np.int32) if row_ptr[-1] else np.zeros(0, np.int32)
+    x = np.concatenate([rng.normal(0.84, 0.39, size=(R, 4)), rng.normal(0.6, 0.21, size=(R, 4)), np.full((R, 1), 10.0)], 1).astype(np.float32)
+    e = rng.normal(0.88, 0.11, size=(R, 4)).astype(np.float32)
+    return PackedBatch(len(sizes), 0, v2xgnn.pack_xe(x, e), np.array(row_ptr, np.int32), col_idx, max_e, graph_off=offs,
+                       max_nodes=int(max(sizes))), x, e, offs
+
+
+RAGGED = [  # feat_dim, layers, topology, sizes
+    (64, 2, 'ref', [128] * 3 + [8] * 40 + [127, 1, 2, 16, 15, 17, 64, 100]),         # tiles of one 128-node graph, > 16 tiny graphs per tile
+    (64, 2, 'mixed', list(np.random.default_rng(1).integers(8, 129, size=70))),
+    (32, 3, 'mixed', list(np.random.default_rng(2).integers(1, 129, size=90))),
+    (16, 1, 'ref', list(np.random.default_rng(3).integers(8, 129, size=50))),
+    (64, 2, 'ref', [40, 33]),                                                         # less than one workgroup of rows
+    (64, 4, 'mixed', list(np.random.default_rng(4).integers(30, 129, size=24))),
+]
+
+
+@pytest.mark.parametrize("F,L,kind,sizes", RAGGED)
+def test_ragged_fused_layers_vs_layerwise_and_oracle(F, L, kind, sizes):
+    """csrc/kernels_ragged.hpp: variable-size graphs with shared weights run embed + L stages + L + 1
+    aggregations as ONE launch, and the L + 1 transposed aggregations + L data gradients as ONE.  Against the float64 oracle
+    (forward, loss, every gradient array) and against the layer-wise kernels (V2X_RAGGED_FUSED=0: same arithmetic up to the
+    fp32 order of the aggregation sums), over graph sizes 1..128, tiles made of one big graph or of dozens of tiny ones,
+    the reference topology, half-dense and sparse graphs in one batch, isolated nodes."""
+    rng = np.random.default_rng(7 * F + L + len(sizes))
+    spec = GnnSpec(n_nodes=1, feat_dim=F, n_mp_layers=L, share_weights=True, variable_graphs=True)
+    pb, x, e, offs = _ragged_batch(rng, [int(n) for n in sizes], kind)
+    P = f32_params(spec, rng)
+    fused = _engine(spec, oc.params_to_list(P), True)
+    os.environ["V2X_RAGGED_FUSED"] = "0"
+    try:
+        plain = _engine(spec, oc.params_to_list(P), True)
+    finally:
+        del os.environ["V2X_RAGGED_FUSED"]
+    info = fused.path_info(pb)
+    assert info["graph_layers"] == "fused(ragged)" and plain.path_info(pb)["graph_layers"] == "layerwise", info
+    q, qp = fused.forward(pb), plain.forward(pb)
+    y = (q + rng.normal(0, 1.2, size=q.shape)).astype(np.float32)
+    step = oracle_step(spec, P, x, e, (offs, pb.row_ptr, pb.col_idx), y, q_at=q, n_denominator=pb.n_rows)
+    assert_fwd_close(q, step['q'], "ragged fused forward vs oracle")
+    assert_fwd_close(q, qp, "ragged fused forward vs layer-wise")
+    loss = fused.forward_backward(pb, y, n_global=pb.n_rows)
+    assert_close(loss, step['loss'], 2e-4, 1e-6, "loss vs oracle")
+    # (the oracle is handed the fused path's q: the element-wise check of the backward.  The layer-wise path would
+    #  differentiate the loss at ITS q, and with 126-neighbour sums |q| reaches 1e4: its fp32 rounding alone moves the
+    #  unit-scale residuals q - y -- the two paths' gradients are not comparable, only their forwards are)
+    g = fused.get_grad_flat()
+    assert_grads_match_oracle(v2xgnn.flat_to_keras_list(spec, g), P, step, "ragged fused F=%d L=%d %s" % (F, L, kind))
+    for _ in range(3):
+        fused.train_step(pb, y, n_global=pb.n_rows)
+    assert np.all(np.isfinite(fused.get_flat())) and fused.get_optimizer_state()[2] == 3
+    fused.check_errors()
+    fused.close()
+    plain.close()

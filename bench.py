@@ -807,6 +807,10 @@ def run_workload(args, ctx, light=False):
                           "aggregation": path.get("aggregation"), "kernel_path": path, "fast_path": fast, "weak": weak,
                           "ranks_seen": (dist.get_world_size() if dist is not None else 1), "rccl_version": rccl,
                           "collective_backend": (dist.get_backend() if dist is not None else None),
+                          "dp_form": (None if trainer is None else
+                                      ("sharded optimizer: reduce-scatter + Adam on the slice + all-gather, per bucket" if trainer.shard_optimizer
+                                       else ("one all-reduce per gradient bucket, overlapped with the backward phases" if trainer.overlap
+                                             else "one all-reduce of the flat gradient"))),
                           "lib_sha256": lib_sha256(),
                           "launch": "eager" if args.no_graph else "hipGraph replay",
                           "parallelism": "dp%d" % world},

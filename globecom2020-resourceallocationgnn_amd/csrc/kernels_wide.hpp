@@ -33,12 +33,24 @@ struct WideGemmArgs {
 
 constexpr int WD_TM = 128, WD_KC = 16;
 
-// NT = output tile width in 16-column MFMA tiles (4: 64 columns; 5: Dense-0's 80 outputs as one strip), RT = 16-row tiles per
-// wave (workgroup tile = 64 RT rows), KC = K depth of an LDS chunk (16 or 32: MFMAs between two workgroup barriers =
-// 2 KC / 16 x RT x NT per wave).  Measured at configs[3]'s share: 64-column tiles at 2 workgroups per CU beat
-// whole-width tiles (L2 absorbs the operand re-reads, occupancy matters more).
-template <bool TRANS, int NT, int RT = 2, int KC = WD_KC>
-__global__ __launch_bounds__(256, 2) void k_wide_gemm(WideGemmArgs a) {
+// NT = output tile width in 16-column MFMA tiles (4: 64 columns; 5: Dense-0's 80 outputs as one strip); the workgroup tile is
+// 128 rows x 16 NT columns, K in chunks of 16 through a double-buffered LDS tile.  Measured at configs[3]'s share (DESIGN.md
+// 3b): 64-column tiles at five workgroups per CU beat whole-width tiles, 256-row tiles and 32-deep chunks (L2 absorbs the
+// operand re-reads, occupancy matters more).
+//
+// Round 4 -- the loop's address arithmetic.  Taking things out of the kernel (results then wrong) showed what the launch
+// pays for: without ANY LDS read 252 us (of 256), without the barrier 247, without the global loads and their LDS stores
+// 208 -- and a load requested two chunks ahead instead of one changes nothing.  It is not latency: the ~60 VALU / SALU
+// instructions per chunk that recomputed, for every load, the segment of the K column, the padded -> real weight row, a
+// 64-bit row x stride product and a 0 / 1 mask multiply took issue cycles the MFMAs of the SIMD's other waves could not use
+// (5 waves x 60 x 4 cycles against 5 x 1024 cycles of MFMA per chunk round = the 18 % that were missing).  Now every thread
+// keeps running pointers: an activation pointer per row pass that advances by 16 floats per chunk and jumps by a precomputed
+// per-thread distance at the (uniform) chunk where the next input segment starts, and one weight pointer that advances by
+// 16 rows, the pad rows of the [x | e] block read from a clamped address and zeroed (one compare + two packed multiplies);
+// rows past the slot's last are clamped duplicates whose results are never stored.
+template <bool TRANS, int NT>
+__global__ __launch_bounds__(256, 5) void k_wide_gemm(WideGemmArgs a) {      // five workgroups per CU (29 / 31 KB of LDS each): <= 96 registers
+  constexpr int RT = 2, KC = WD_KC;
   constexpr int TM = 64 * RT, LDB = KC + 4;
   constexpr int TN = 16 * NT, LDA = TN + 4;
   constexpr int PA = (KC * NT + 63) / 64;                        // float4 passes of the weight chunk [KC][TN]
@@ -50,109 +62,122 @@ __global__ __launch_bounds__(256, 2) void k_wide_gemm(WideGemmArgs a) {
   const int slot = blockIdx.z, m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
   const float* Wg = a.W + slot * a.slot_stride;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, kg = lane >> 4;
+  const int n_chunks = a.k_total / KC;
 
-  // global -> register staging roles: pass p covers activation rows (tid + 256 p) / CPR, 4 k-columns each
-  int64_t rowg[PB];
-#pragma unroll
-  for (int p = 0; p < PB; ++p)
-    rowg[p] = (int64_t)(a.idx_base + min(m0 + (tid + 256 * p) / CPR, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
+  // ---- running pointers (explicit GLOBAL address space: a pointer that is advanced by a per-thread distance between two
+  // kernel arguments would otherwise decay to a generic one -- FLAT loads, which the wait-count pass cannot count).
+  // Activations: pass q covers tile row (tid + 256 q) / 4, k-columns 4 (tid % 4) .. + 3 of the chunk
+  static_assert(PB == 2 && PA <= 2, "staging registers are named explicitly (arrays of them ended up in scratch)");
+  typedef const __attribute__((address_space(1))) f32x4* gf4_p;          // (ext-vector type: HIP's float4 class has no address-space-qualified copy)
   const int cB = (tid % CPR) << 2;
+  const int c1 = a.seg[0].width / KC, c2 = a.n_seg > 1 ? c1 + a.seg[1].width / KC : 1 << 30;   // first chunk of segment 1 / 2
+  const int64_t row0 = (int64_t)(a.idx_base + min(m0 + tid / CPR, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
+  const int64_t row1 = (int64_t)(a.idx_base + min(m0 + (tid + 256) / CPR, a.n_idx - 1)) * a.row_stride + slot * a.base_mul;
+  gfloat_p pB0 = (gfloat_p)a.seg[0].ptr + row0 * a.seg[0].stride + cB, pB1 = (gfloat_p)a.seg[0].ptr + row1 * a.seg[0].stride + cB;
+  // Weights.  Forward: pass q holds k row ka of the chunk and 4 output columns; its real weight row is the padded row minus
+  // the pad rows below it, pad rows themselves clamped to the last real row before them.  Transposed (data gradients): output
+  // column nT = weight row (skipping `skip` rows at `split`), 4 consecutive k = 4 consecutive floats of that row.
+  gfloat_p pA0, pA1;
+  int kaA0 = 0, kaA1 = 0;
+  {
+    const int i0 = min(tid, NA - 1), i1 = min(tid + 256, NA - 1);
+    if (!TRANS) {
+      kaA0 = i0 / (4 * NT); kaA1 = i1 / (4 * NT);
+      pA0 = (gfloat_p)Wg + min(n0 + ((i0 % (4 * NT)) << 2), a.n_real - 4);
+      pA1 = (gfloat_p)Wg + min(n0 + ((i1 % (4 * NT)) << 2), a.n_real - 4);
+    } else {
+      const int nT0 = min(n0 + i0 / CPR, a.n_out - 1), nT1 = min(n0 + i1 / CPR, a.n_out - 1);
+      pA0 = (gfloat_p)Wg + (int64_t)(nT0 < a.split ? nT0 : nT0 + a.skip) * a.n_real + ((i0 % CPR) << 2);
+      pA1 = (gfloat_p)Wg + (int64_t)(nT1 < a.split ? nT1 : nT1 + a.skip) * a.n_real + ((i1 % CPR) << 2);
+    }
+  }
+  const int pad_at = a.pad.pad_at, pad_end = a.pad.pad_at + a.pad.n_pad, n_pad = a.pad.n_pad, k_last = a.pad.k_real - 1;
 
-  const int n_chunks = (a.k_total + KC - 1) / KC;
-  auto gload = [&](int kc, float4 (&va)[PA], float4 (&vb)[PB]) {
-    // a thread's 4 k-columns never straddle two segments (widths are multiples of 16), a KC = 32 chunk may: the segment is
-    // resolved per thread; columns past the end of the contraction (k_total is a multiple of 16, not of 32) are zeroed
-    int kcol = kc * KC + cB;
-    const bool kin = kcol < a.k_total;
-    if (!kin) kcol = 0;
-    const float* p = a.seg[0].ptr; int st = a.seg[0].stride;
-    if (a.n_seg > 1 && kcol >= a.seg[0].width) {
-      kcol -= a.seg[0].width; p = a.seg[1].ptr; st = a.seg[1].stride;
-      if (a.n_seg > 2 && kcol >= a.seg[1].width) { kcol -= a.seg[1].width; p = a.seg[2].ptr; st = a.seg[2].stride; }
+  int kc_next = 0;                                               // the chunk the pointers point at
+  // one set of staging registers, loads one chunk ahead (two chunks ahead with a second set measured the same: 256 / 237 us)
+  f32x4 va0_0, va1_0 = (f32x4){0.f, 0.f, 0.f, 0.f}, vb0_0, vb1_0;
+  auto load_a = [&](gfloat_p p, int ka) -> f32x4 {
+    if (!TRANS) {
+      const int kk = kc_next * KC + ka;
+      const int rr = min(kk < pad_at ? kk : (kk < pad_end ? pad_at - 1 : kk - n_pad), k_last);
+      const f32x4 t = *reinterpret_cast<gf4_p>(p + (int64_t)rr * a.n_real);
+      // pad rows are ZERO weights: Dense-0 reads the packed [x | e] block but has no weights for e (its pad rows meet
+      // non-zero data); the address stays valid (clamped), the value is dropped
+      const float mk = (kk >= pad_at && kk < pad_end) ? 0.f : 1.f;
+      return t * mk;
     }
-    const float mkb = kin ? 1.f : 0.f;
-#pragma unroll
-    for (int q = 0; q < PB; ++q) {
-      const float4 t = *reinterpret_cast<const float4*>(p + rowg[q] * st + kcol);
-      vb[q] = KC == WD_KC ? t : make_float4(t.x * mkb, t.y * mkb, t.z * mkb, t.w * mkb);
-    }
-#pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int i = tid + 256 * q;
-      bool ok;
-      int64_t off;
-      if (!TRANS) {                        // k row i / (4 NT), 4 output columns
-        const int ka = i / (4 * NT), col = n0 + ((i % (4 * NT)) << 2);
-        const int kk = kc * KC + min(ka, KC - 1);
-        const int rr = kk < a.k_total ? real_row(a.pad, kk) : -1;
-        ok = i < NA && col < a.n_real && rr >= 0;
-        off = (int64_t)rr * a.n_real + col;
-      } else {                             // output column i / (KC / 4), 4 k values
-        const int nT = n0 + i / CPR, ka = (i % CPR) << 2;
-        ok = i < NA && nT < a.n_out && kc * KC + ka < a.k_total;
-        off = (int64_t)(nT < a.split ? nT : nT + a.skip) * a.n_real + kc * KC + ka;
-      }
-      const float4 t = *reinterpret_cast<const float4*>(Wg + (ok ? off : 0));
-      const float mk = ok ? 1.f : 0.f;
-      va[q] = make_float4(t.x * mk, t.y * mk, t.z * mk, t.w * mk);
+    return *reinterpret_cast<gf4_p>(p + kc_next * KC);
+  };
+#define V2X_WG_GLOAD(S)                                                                                            \
+  {                                                                                                                \
+    vb0_##S = *reinterpret_cast<gf4_p>(pB0); vb1_##S = *reinterpret_cast<gf4_p>(pB1);                              \
+    va0_##S = load_a(pA0, kaA0);                                                                                   \
+    if (PA > 1) va1_##S = load_a(pA1, kaA1);                                                                       \
+    if (kc_next + 1 < n_chunks) { /* else: the last prefetch re-loads the last chunk into the idle buffer */       \
+      ++kc_next;                                                                                                   \
+      pB0 += KC; pB1 += KC;                                                                                        \
+      if (kc_next == c1) { /* uniform; twice per workgroup: the next input segment's rows */                       \
+        pB0 = (gfloat_p)a.seg[1].ptr + row0 * a.seg[1].stride + cB; pB1 = (gfloat_p)a.seg[1].ptr + row1 * a.seg[1].stride + cB; \
+      }                                                                                                            \
+      if (kc_next == c2) {                                                                                         \
+        pB0 = (gfloat_p)a.seg[2].ptr + row0 * a.seg[2].stride + cB; pB1 = (gfloat_p)a.seg[2].ptr + row1 * a.seg[2].stride + cB; \
+      }                                                                                                            \
+    }                                                                                                              \
+  }
+  auto store_a = [&](int buf, int i, f32x4 v) {
+    if (i >= NA) return;
+    if (!TRANS) {
+      *reinterpret_cast<f32x4*>(&sA[buf][(i / (4 * NT)) * LDA + ((i % (4 * NT)) << 2)]) = v;
+    } else {
+      const int na = i / CPR, ka = (i % CPR) << 2;
+      sA[buf][(ka + 0) * LDA + na] = v[0]; sA[buf][(ka + 1) * LDA + na] = v[1];
+      sA[buf][(ka + 2) * LDA + na] = v[2]; sA[buf][(ka + 3) * LDA + na] = v[3];
     }
   };
-  auto lstore = [&](int buf, const float4 (&va)[PA], const float4 (&vb)[PB]) {
-#pragma unroll
-    for (int q = 0; q < PB; ++q)
-      *reinterpret_cast<float4*>(&sB[buf][((tid + 256 * q) / CPR) * LDB + cB]) = vb[q];
-#pragma unroll
-    for (int q = 0; q < PA; ++q) {
-      const int i = tid + 256 * q;
-      if (i >= NA) continue;
-      if (!TRANS) {
-        *reinterpret_cast<float4*>(&sA[buf][(i / (4 * NT)) * LDA + ((i % (4 * NT)) << 2)]) = va[q];
-      } else {
-        const int na = i / CPR, ka = (i % CPR) << 2;
-        sA[buf][(ka + 0) * LDA + na] = va[q].x; sA[buf][(ka + 1) * LDA + na] = va[q].y;
-        sA[buf][(ka + 2) * LDA + na] = va[q].z; sA[buf][(ka + 3) * LDA + na] = va[q].w;
-      }
-    }
-  };
+#define V2X_WG_LSTORE(buf, S)                                                                                      \
+  {                                                                                                                \
+    *reinterpret_cast<f32x4*>(&sB[buf][(tid / CPR) * LDB + cB]) = vb0_##S;                                         \
+    *reinterpret_cast<f32x4*>(&sB[buf][((tid + 256) / CPR) * LDB + cB]) = vb1_##S;                                 \
+    store_a(buf, tid, va0_##S);                                                                                    \
+    if (PA > 1) store_a(buf, tid + 256, va1_##S);                                                                  \
+  }
 
   f32x4 acc[RT][NT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define V2X_WG_MFMA(buf)                                                                                           \
+  {                                                                                                                \
+    f32x4 b[RT];                                                                                                   \
+    _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) b[rt] = ld4(&sB[buf][(16 * RT * wv + 16 * rt + j) * LDB + 4 * kg]); \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                               \
+      float w[NT];                                                                                                 \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) w[nt] = sA[buf][(4 * kg + s) * LDA + nt * 16 + j];        \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                           \
+        _Pragma("unroll") for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = V2X_MFMA(w[nt], b[rt][s], acc[rt][nt]);   \
+    }                                                                                                              \
+  }
 
-  float4 va[PA], vb[PB];
-  gload(0, va, vb);
-  lstore(0, va, vb);
+  V2X_WG_GLOAD(0)
+  V2X_WG_LSTORE(0, 0)
   __syncthreads();
 #pragma unroll 1
   for (int kc = 0; kc < n_chunks; ++kc) {
     const int buf = kc & 1;
-    // unconditional (clamped) prefetch: a load under `if` makes hipcc wait for it at the join, i.e. BEFORE the
-    // MFMAs it is supposed to overlap; the last iteration re-loads its own chunk into the idle buffer
-    gload(min(kc + 1, n_chunks - 1), va, vb);
+    // unconditional prefetch (a load under `if` makes hipcc wait for it at the join, i.e. BEFORE the MFMAs it is supposed
+    // to overlap); the last iteration re-loads its own chunk into the idle buffer
+    V2X_WG_GLOAD(0)
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < KC / 16; ++g) {
-      f32x4 b[RT];
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) b[rt] = ld4(&sB[buf][(16 * RT * wv + 16 * rt + j) * LDB + 16 * g + 4 * kg]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        float w[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w[nt] = sA[buf][(16 * g + 4 * kg + s) * LDA + nt * 16 + j];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = V2X_MFMA(w[nt], b[rt][s], acc[rt][nt]);
-      }
-    }
+    V2X_WG_MFMA(buf)
     __builtin_amdgcn_sched_barrier(0);
-    lstore(buf ^ 1, va, vb);
+    V2X_WG_LSTORE(buf ^ 1, 0)
     __syncthreads();
   }
 
+#undef V2X_WG_MFMA
+#undef V2X_WG_GLOAD
+#undef V2X_WG_LSTORE
   // epilogue: lane holds out[row 16*RT*wv + 16*rt + j][n0 + nt*16 + 4*kg .. +3]
   const float* bias = Wg + (int64_t)a.pad.k_real * a.n_real;
 #pragma unroll

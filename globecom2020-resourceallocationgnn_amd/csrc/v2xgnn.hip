@@ -255,6 +255,17 @@ void set_attrs(int F) {
   if (F == 32) set_attrs_f<32>();
   if (F == 64) set_attrs_f<64>();
   if (F >= 128) {                     // wide path: tail MLP kernels + the narrow weight-gradient kernel for Dense 1..3
+    if (getenv("V2X_DEBUG_OCC")) {
+      int n1 = 0, n2 = 0, n3 = 0, n4 = 0;
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, k_wide_gemm<false, 4>, 256, 0);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, k_wide_gemm<true, 4>, 256, 0);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, k_wide_wgrad_multi, 256, 0);
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&n4, k_agg_dense<false>, 256, 36 * 1024);
+      hipFuncAttributes fa;
+      hipFuncGetAttributes(&fa, (const void*)k_wide_gemm<false, 4>);
+      fprintf(stderr, "occupancy (workgroups per CU): k_wide_gemm<false,4> %d, <true,4> %d, k_wide_wgrad_multi %d, k_agg_dense(36 KB) %d; "
+              "k_wide_gemm<false,4>: %d regs, %zu B static LDS, maxDynamic %d\n", n1, n2, n3, n4, fa.numRegs, fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes);
+    }
     allow_big_lds((const void*)k_mlp_fwd<0>);
     allow_big_lds((const void*)k_mlp_bwd<0>);
     allow_big_lds((const void*)k_wgrad<64, 1>);
@@ -637,20 +648,13 @@ int wide_nt(int n_out) { return n_out <= 80 ? 5 : 4; }
 
 int launch_wide_gemm(v2x_model* m, hipStream_t st, WideGemmArgs& a, int grid_z, bool trans, const char* name) {
   const int nt = wide_nt(a.n_out);
-  // tile variants (V2X_WIDE_RT = 16-row tiles per wave: 2 or 4; V2X_WIDE_KC = K depth of an LDS chunk: 16 or 32)
-  static const int rt_env = env_int("V2X_WIDE_RT", 2), kc_env = env_int("V2X_WIDE_KC", 16);
-  const int rt = (nt == 4 && rt_env == 4) ? 4 : 2, kc = kc_env == 32 ? 32 : 16;
-  const dim3 grid((a.n_idx + 64 * rt - 1) / (64 * rt), (a.n_out + 16 * nt - 1) / (16 * nt), grid_z);
-#define V2X_WIDE_GEMM(T, NTV, RTV, KCV) { auto k = k_wide_gemm<T, NTV, RTV, KCV>; LAUNCH(m, name, k, grid, 0, st, a); return V2X_OK; }
+  const dim3 grid((a.n_idx + WD_TM - 1) / WD_TM, (a.n_out + 16 * nt - 1) / (16 * nt), grid_z);
+#define V2X_WIDE_GEMM(T, NTV) { auto k = k_wide_gemm<T, NTV>; LAUNCH(m, name, k, grid, 0, st, a); return V2X_OK; }
   if (!trans) {
-    if (nt == 5) { if (kc == 32) V2X_WIDE_GEMM(false, 5, 2, 32) V2X_WIDE_GEMM(false, 5, 2, 16) }
-    if (rt == 4) V2X_WIDE_GEMM(false, 4, 4, 16)          // (RT = 4 with KC = 32 would need 91 KB of LDS)
-    if (kc == 32) V2X_WIDE_GEMM(false, 4, 2, 32)
-    V2X_WIDE_GEMM(false, 4, 2, 16)
+    if (nt == 5) V2X_WIDE_GEMM(false, 5)
+    V2X_WIDE_GEMM(false, 4)
   }
-  if (rt == 4) V2X_WIDE_GEMM(true, 4, 4, 16)
-  if (kc == 32) V2X_WIDE_GEMM(true, 4, 2, 32)
-  V2X_WIDE_GEMM(true, 4, 2, 16)
+  V2X_WIDE_GEMM(true, 4)
 #undef V2X_WIDE_GEMM
 }
 

@@ -35,7 +35,14 @@ class DataParallelTrainer(object):
         # all-reduce (1.2 MB, latency-bound on xGMI) is worth more than 30 us -- and the models it applies to (feature
         # width <= 64) have at most a few MB of gradients.
         import os
-        self.overlap = (os.environ.get("V2X_DP_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
+        # Wide models (feat_dim >= 128: one bucket per layer, configs[3]: 207.6 MB of gradients) overlap by default: measured on
+        # one MI355X with the RCCL path forced (tools/dp_host_overhead.py --wide) the phased step costs 3.82 ms against 3.65 ms
+        # with one all-reduce after the merged weight-gradient launch -- 0.17 ms, which the all-reduce of four of the five
+        # buckets behind the remaining backward repays as soon as the collective takes longer than that (8 GPUs over xGMI:
+        # ~1 ms for 207.6 MB; unmeasured here, one GPU per box).
+        wide = getattr(getattr(backend, "spec", None), "feat_dim", 0) >= 128
+        env = os.environ.get("V2X_DP_OVERLAP")
+        self.overlap = ((env == "1") if env is not None else wide) if overlap is None else bool(overlap)
         # shard_optimizer: reduce-scatter + Adam on the rank's 1 / G slice of every bucket + all-gather of the parameters
         # (V2X_DP_SHARD_OPTIMIZER=1); see train_step
         self.shard_optimizer = (os.environ.get("V2X_DP_SHARD_OPTIMIZER", "0") == "1") if shard_optimizer is None else bool(shard_optimizer)

@@ -159,9 +159,10 @@ class BatchedEnviron(object):
             for e, s in enumerate(rs):
                 z = self.pos[e, :, 0] + 1j * self.pos[e, :, 1]
                 order = np.argsort(np.abs(z[:, None] - z[None, :]), axis=0)          # column i: nodes by distance from i
+                cand = order[1:N - 2].T.tolist()                                     # (python ints: random.sample indexes with them)
                 fast.setstate(s._export())
                 for i in range(N):
-                    self.dest[e, i] = fast.sample(list(order[1:N - 2, i]), 1)[0]
+                    self.dest[e, i] = fast.sample(cand[i], 1)[0]
                 s._import(fast.getstate())
         self.activate_links = np.ones((E, N, 1), dtype=bool)
 

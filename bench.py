@@ -84,6 +84,8 @@ def algorithmic_flops(name, R, F, L, C=4, Dn=9, De=4):
     table["k_wgrad_all"] = table["k_wgrad_gnn"] + table["k_wgrad_dense"]
     table["k_gnn_fwd_fused"] = embed + L * gnn                        # embed + L stages (graph-major fused launch)
     table["k_gnn_bwd_fused"] = L * table["k_node_dgrad"]              # L data gradients
+    table["k_gnn_fwd_ragged"] = table["k_gnn_fwd_fused"]              # the same layers for variable-size graphs (kernels_ragged.hpp)
+    table["k_gnn_bwd_ragged"] = table["k_gnn_bwd_fused"]
     if F >= 128:
         table["k_wgrad_gnn"] = gnn                       # wide path: one launch per stage ...
         table["k_wgrad_wide_all"] = L * gnn + embed + dense0     # ... or all graph layers + Dense-0 as roles of one grid
@@ -116,6 +118,10 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     # (the backward gates with the SIGN BITS of h_s the forward leaves behind, one bit per feature, not with the rows)
     table["k_gnn_fwd_fused"] = 4 * R * (Dn + De) + csr + 2 * (L + 1) * 4 * R * F + L * R * F // 8
     table["k_gnn_bwd_fused"] = 4 * R * 2 * F + L * R * F // 8 + csr + (L + 1) * 4 * R * F
+    # ragged fused launches (csrc/kernels_ragged.hpp): by-destination / by-source bit masks (4 words per row) instead of the CSR
+    # slice, the rows of h_s as ReLU' gates in the backward
+    table["k_gnn_fwd_ragged"] = 4 * R * (Dn + De) + 16 * R + 2 * (L + 1) * 4 * R * F
+    table["k_gnn_bwd_ragged"] = 4 * R * 2 * F + L * 4 * R * F + 16 * R + (L + 1) * 4 * R * F
     table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"] - 4 * R * C  # fwd + Huber + bwd fused: q is not re-read
     table["k_mlp_train_wg"] = table["k_mlp_train"]    # weight gradients from the values on chip: no further node-row bytes
     table["k_adj_masks"] = csr + 2 * 4 * R * ((min(max(N, 1), 128) + 31) // 32)   # CSR in, bit masks by source and by destination out

@@ -304,15 +304,15 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
   ts.mark();                                                     // (TS) CSR slice in LDS
   constexpr bool compl_sums = COMPL;     // (a compile-time form: both gathers side by side cost registers and spill)
-  if (compl_sums) {                      // non-neighbour masks of the tile's rows (while the embed operands are in flight)
-    __syncthreads();
+  {                                      // the CSR rows of the tile as bit sets (while the embed operands are in flight): the
+    __syncthreads();                     // in-neighbours of a row (edge form) / its NON-neighbours (complement form)
     const unsigned valid = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
     for (int r = threadIdx.x; r < FZ_TG * N; r += FZ_THREADS) {
       unsigned nb = 0u;
       if (r < nrows)
         for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) nb |= 1u << x.sCol[e];
-      x.sC[r] = ~nb & valid;
-      if (a.nbmask && r < nrows) a.nbmask[r_begin + r] = ~nb & valid;
+      x.sC[r] = compl_sums ? (~nb & valid) : nb;
+      if (compl_sums && a.nbmask && r < nrows) a.nbmask[r_begin + r] = ~nb & valid;
     }
     ts.mark();                                                   // (TS) masks built
   }
@@ -365,28 +365,34 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   if (compl_sums) { fz_reduce_sums<FB, ROWF>(x.sS, x.sT); __syncthreads(); }
   ts.mark();                                                     // 2: after barrier
 
-  // neighbour gather of slot k for this lane's graph: a[kb] = sum over in-edges, ascending sources (k_agg_small order)
-  auto gather = [&](int k, f32x4 (&ag)[FB]) {
+  // Edge form of AggLayer.call (BS_brain.py:69-76) for ALL of this wave's slots of the lane's graph at once:
+  //     a[i][kb] = sum over the in-edges p -> k_i of row p,   ascending sources (k_agg_small's order: bitwise its sums).
+  // Round 4.  Until now every slot walked its own CSR row and read its ~N - 2 source rows from LDS -- 18 x 4 b128 reads per
+  // slot, and a wave's three slots (same graph!) read nearly the same 20 rows three times: the phase was LDS-bandwidth
+  // bound (4.6-5.3 us against 1.8 us for the complement form).  With N <= 32 a CSR row is a 32-bit SET: the wave walks the
+  // graph's rows p = 0 .. N - 1 once, reads row p once, and adds it to the slots whose set holds p (multiply by the 0 / 1
+  // bit: x * 1 + acc and x * 0 + acc are exact for finite x -- the backward's tail has always done the same): 20 x 4
+  // reads instead of 54 x 4, same values, same order.  Cost independent of the degree (<= N rows): sparse graphs read at
+  // most what a complete graph reads.
+  auto gather_all = [&](f32x4 (&ag)[NSA][FB]) {
+    unsigned msk[NSA];
 #pragma unroll
-    for (int kb = 0; kb < FB; ++kb) ag[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int rl = jc * N + k;
-    int e = x.sRp[rl];
-    const int e1 = x.sRp[rl + 1];
-    for (; e + 4 <= e1; e += 4) {
-      const float* b0p = myrow + (int)x.sCol[e] * (FZ_TG * ROWF);
-      const float* b1p = myrow + (int)x.sCol[e + 1] * (FZ_TG * ROWF);
-      const float* b2p = myrow + (int)x.sCol[e + 2] * (FZ_TG * ROWF);
-      const float* b3p = myrow + (int)x.sCol[e + 3] * (FZ_TG * ROWF);
-      f32x4 v0[FB], v1[FB], v2[FB], v3[FB];
+    for (int i = 0; i < NSA; ++i) {
+      msk[i] = i < NS ? x.sC[jc * N + wv + FZ_WAVES * i] : 0u;
 #pragma unroll
-      for (int kb = 0; kb < FB; ++kb) { v0[kb] = ld4(b0p + kb * 4); v1[kb] = ld4(b1p + kb * 4); v2[kb] = ld4(b2p + kb * 4); v3[kb] = ld4(b3p + kb * 4); }
-#pragma unroll
-      for (int kb = 0; kb < FB; ++kb) { ag[kb] += v0[kb]; ag[kb] += v1[kb]; ag[kb] += v2[kb]; ag[kb] += v3[kb]; }
+      for (int kb = 0; kb < FB; ++kb) ag[i][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    for (; e < e1; ++e) {
-      const float* b0p = myrow + (int)x.sCol[e] * (FZ_TG * ROWF);
+    for (int p = 0; p < N; ++p) {
+      const float* bp = myrow + p * (FZ_TG * ROWF);
+      f32x4 v[FB];
 #pragma unroll
-      for (int kb = 0; kb < FB; ++kb) ag[kb] += ld4(b0p + kb * 4);
+      for (int kb = 0; kb < FB; ++kb) v[kb] = ld4(bp + kb * 4);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const float f = (float)((msk[i] >> p) & 1u);
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) ag[i][kb] += v[kb] * f;
+      }
     }
   };
 
@@ -419,10 +425,10 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
     f32x4 ag[NSA][FB];                     // gathered a_{s-1} rows; slot i's registers become its output h_s afterwards
     // (1) gather phase
     if (compl_sums) colsum();
+    else gather_all(ag);
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       if (compl_sums) gather_c(wv + FZ_WAVES * i, ag[i]);
-      else gather(wv + FZ_WAVES * i, ag[i]);
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) stg4(ap + rowi[i] * F + kb * 16 + 4 * kg, ag[i][kb]);
     }
@@ -507,12 +513,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
   // ---- a_L = Agg(h_L) for the decision MLP
   {
     float* ap = aptr(L);
-    if (compl_sums) colsum();
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      f32x4 ag[FB];
-      if (compl_sums) gather_c(wv + FZ_WAVES * i, ag);
-      else gather(wv + FZ_WAVES * i, ag);
+    auto put = [&](int i, const f32x4 (&ag)[FB]) {
       if (a.frag_out) {
         float* af = ap + ((int64_t)(wv + FZ_WAVES * i) * gridDim.x + blockIdx.x) * (FB * 256) + lane * 4;
 #pragma unroll
@@ -522,6 +523,20 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
 #pragma unroll
         for (int kb = 0; kb < FB; ++kb) stg4(ar + kb * 16, ag[kb]);
       }
+    };
+    if constexpr (COMPL) {               // slot by slot: three slots' sums side by side spill next to nothing else here, but
+      colsum();                          // the complement form never needs them together
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        f32x4 ag[FB];
+        gather_c(wv + FZ_WAVES * i, ag);
+        put(i, ag);
+      }
+    } else {
+      f32x4 agl[NSA][FB];
+      gather_all(agl);
+#pragma unroll
+      for (int i = 0; i < NS; ++i) put(i, agl[i]);
     }
   }
   ts.mark(true);                                                 // end
@@ -539,8 +554,8 @@ __global__ __launch_bounds__(FZ_THREADS, 2) void k_gnn_fwd_fused(FusedFwdArgs a)
   x.sS = x.sH + 4 * x.SUB;                                       // compl_sums: [8 waves][4][16][ROWF] partial column sums
   x.sT = x.sS + (COMPL ? FZ_SUMS_ROWS * P::ROWF : 0);            // compl_sums: [4][16][ROWF] their totals
   x.sRp = reinterpret_cast<int*>(x.sT + (COMPL ? FZ_TOT_ROWS * P::ROWF : 0));    // [16 N + 1] edge offsets relative to the tile
-  x.sC = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // compl_sums: [16 N] non-neighbour masks
-  x.sCol = reinterpret_cast<unsigned char*>(x.sC + (COMPL ? FZ_TG * a.N : 0));   // [edges] graph-local sources
+  x.sC = reinterpret_cast<unsigned*>(x.sRp + FZ_TG * a.N + 1);   // [16 N] the rows' in-neighbour sets (complement form: non-neighbours)
+  x.sCol = reinterpret_cast<unsigned char*>(x.sC + FZ_TG * a.N);   // [edges] graph-local sources
   x.lane = threadIdx.x & 63;
   x.wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   x.kg = x.lane >> 4;
@@ -701,15 +716,35 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
     if (RING && s > 0) { wload(0, 0, item_base(s, 0)); wload(1, 1, item_base(s, 0)); }
     f32x4 dpre[NSA][FB];
     // (1) transposed gathers (ascending destinations, two per iteration: k_agg_small<true> order), + dh, ReLU' gate
+    if constexpr (!COMPL) {
+      // edge form, all of the wave's slots at once (see the forward's gather_all): walk the destinations q = 0 .. N - 1, read
+      // dagg row q once, add it to the slots p_i that send to q (bit q of the by-source set); ascending q = k_agg_small<true>
+      unsigned msk[NSA];
+#pragma unroll
+      for (int i = 0; i < NSA; ++i) {
+        msk[i] = i < NS ? x.sM[jc * N + wv + FZ_WAVES * i] : 0u;
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) dpre[i][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      for (int q = 0; q < N; ++q) {
+        const float* bq = myrow + q * (FZ_TG * ROWF);
+        f32x4 v[FB];
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) v[kb] = ld4(bq + kb * 4);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const float f = (float)((msk[i] >> q) & 1u);
+#pragma unroll
+          for (int kb = 0; kb < FB; ++kb) dpre[i][kb] += v[kb] * f;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
       f32x4 acc[FB];
-#pragma unroll
-      for (int kb = 0; kb < FB; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      unsigned bits = x.sM[jc * N + wv + FZ_WAVES * i];
       if constexpr (COMPL) {                                          // column sum minus the rows of the non-successors
         // (the column sum is re-read per slot: keeping it in registers across the slots spills next to the weight ring)
-        bits = ~bits & valid;
+        unsigned bits = ~x.sM[jc * N + wv + FZ_WAVES * i] & valid;
 #pragma unroll
         for (int kb = 0; kb < FB; ++kb) acc[kb] = ld4(tot + kb * 4);
         while (bits) {
@@ -720,21 +755,8 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
           for (int kb = 0; kb < FB; ++kb) acc[kb] -= ld4(b0 + kb * 4);
         }
       } else {
-        while (bits) {
-          const int q0 = __builtin_ctz(bits);
-          bits &= bits - 1;
-          const bool two = bits != 0;
-          const int q1 = two ? __builtin_ctz(bits) : q0;
-          bits &= bits - 1;                                        // (0 & anything stays 0)
-          const float m1 = two ? 1.f : 0.f;
-          const float* b0 = myrow + q0 * (FZ_TG * ROWF);
-          const float* b1 = myrow + q1 * (FZ_TG * ROWF);
-          f32x4 v0[FB], v1[FB];
 #pragma unroll
-          for (int kb = 0; kb < FB; ++kb) { v0[kb] = ld4(b0 + kb * 4); v1[kb] = ld4(b1 + kb * 4); }
-#pragma unroll
-          for (int kb = 0; kb < FB; ++kb) { acc[kb] += v0[kb]; acc[kb] += v1[kb] * m1; }
-        }
+        for (int kb = 0; kb < FB; ++kb) acc[kb] = dpre[i][kb];
       }
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) {

@@ -478,7 +478,7 @@ def dropin_boundary(device, seconds=1.5):
             "train_dnn_ms": round(1e3 * float(med[2]), 4), "replays_timed": int(len(parts)),
             "predict_one_step_us": round(1e6 * float(np.median(one_ts)), 2),
             "numpy_packer_alone_ms": round(1e3 * float(np.median(np_ts)), 4),
-            "pack_threads": os.environ.get("V2X_PACK_THREADS", "auto (<= 16)")}
+            "pack_threads": os.environ.get("V2X_PACK_THREADS", "auto (<= 8 pooled workers)")}
 
 
 def self_launch(argv, n):
@@ -655,7 +655,7 @@ def run_workload(args, ctx, light=False):
                 step()
             torch.cuda.synchronize()
             probe = (time.perf_counter() - tp) / 5
-            steps = max(steps, int(np.ceil(min_seconds / max(probe, 1e-6))))
+            steps = max(steps, int(np.ceil(1.06 * min_seconds / max(probe, 1e-6))))     # (the probe runs a little slow: clocks still ramping)
             if dist is not None:
                 t = torch.tensor([steps], dtype=torch.int64, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -424,15 +424,17 @@ def test_adjacency_cache_skips_only_what_it_has_seen():
 
 def test_bench_gpus_2_without_a_launcher_starts_two_ranks():
     """`python bench.py --gpus 2` with no torch.distributed.run around it must start its ranks itself (it used to
-    SystemExit).  Without a GPU each rank stops at the engine's no-CPU-fallback check -- AFTER the launch: both ranks report
-    it, and the exit code is the launcher's."""
+    SystemExit).  Without a GPU each rank stops at the engine's no-CPU-fallback check -- AFTER the launch: the launcher's
+    failure report names bench.py's ranks (it terminates the second rank as soon as the first has failed, so only one of them
+    is sure to get its message out), and the exit code is the launcher's."""
     import subprocess
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["HIP_VISIBLE_DEVICES"] = ""
     env["CUDA_VISIBLE_DEVICES"] = ""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
-                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode != 0
-    assert out.stderr.count("bench.py needs a GPU") >= 2, out.stderr[-2000:]
+    assert out.stderr.count("bench.py needs a GPU") >= 1, out.stderr[-2000:]
+    assert "local_rank" in out.stderr or "ChildFailedError" in out.stderr, out.stderr[-2000:]     # torch.distributed.run's report
     assert "launch with torch.distributed.run" not in out.stderr

@@ -50,6 +50,8 @@ python tools/dropin_profile.py 2>&1 | grep -v amdgpu.ids > $O/dropin_profile.txt
 python tools/dp_host_overhead.py --wide 2>&1 | grep -v -e amdgpu.ids -e "version" -e Hostname -e Librccl > $O/dp_host_overhead_wide.txt
 python tools/dp_host_overhead.py 2>&1 | grep -v -e amdgpu.ids -e "version" -e Hostname -e Librccl > $O/dp_host_overhead.txt
 python tools/roofline_table.py $O/bench.json $O/hbm_traffic.json > $O/roofline.md 2>&1
+# only the summaries travel back (gpurun merges <= 64 MiB): drop the raw rocprofv3 databases
+rm -rf $O/fetch $O/write $O/st1 $O/st2 $O/st3 $O/lds0 $O/lds1 $O/prof $O/prof_cfg4 $O/prof_cfg5 $O/fetch_cfg4 $O/write_cfg4 $O/mfma_cfg4 $O/fetch_cfg5 $O/write_cfg5 $O/mfma_cfg5
 for f in $O/bench_*.json $O/bench.json; do echo "$f: $(python -c "
 import json
 d=json.loads(open('$f').read().strip().splitlines()[-1])

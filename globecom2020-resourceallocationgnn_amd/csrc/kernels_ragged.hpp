@@ -11,7 +11,8 @@
 //
 // Work split: the batch's rows are cut at multiples of CAPP = RG_CAP - max_nodes + 1; workgroup w owns the graphs whose FIRST
 // row lies in [w CAPP, (w + 1) CAPP) -- at most RG_CAP rows, every graph exactly once, balanced by rows whatever the size
-// mix.  The first graph of every interval comes from a plan k_adj_masks writes (one thread per graph: no search).
+// mix.  The first graph of every interval comes from a plan k_adj_masks writes (one thread per graph: no search) -- or, by
+// default, from k_ragged_plan below, which packs the same runs tightly.
 // Aggregation, per row: through the complement (column sum of the graph minus the rows at the ZERO bits of the row's
 // by-destination mask) when the row has more edges than non-edges and its graph at least 16 nodes, else the rows at the ONE
 // bits directly -- k_agg_dense's rule (kernels_wide.hpp); masks are the ones k_adj_masks builds for the backward anyway.
@@ -29,6 +30,50 @@ constexpr int RG_RT = (RG_CAP / 16 + RG_WAVES - 1) / RG_WAVES;   // row tiles a 
 constexpr int RG_BIG = 16;                     // graphs of >= RG_BIG nodes get a column-sum slot (at most RG_CAP / RG_BIG + 1 per tile)
 constexpr int RG_SLOTS = RG_CAP / RG_BIG + 1;
 constexpr int RG_MW = 4;                       // mask words per row (graphs of <= 128 nodes)
+
+// The same split, packed: workgroup w + 1 starts at the LAST graph that still fits behind workgroup w's first one
+// (rows <= RG_CAP) -- the fewest workgroups a split into runs of whole graphs can have, tiles ~ (RG_CAP - mean size / 2)
+// rows full instead of CAPP on average (configs[4]: 490 workgroups of ~285 rows instead of 720 of 193 -- two rounds of the
+// 256 CUs instead of three).  The chain "next start" is data dependent; one workgroup resolves it without walking it:
+// nxt[g] by a bounded binary search over the offsets for every g at once, then log2(n_wgs) rounds of pointer doubling,
+// workgroup w composing the powers named by the bits of w.  All in LDS (3 (n_graphs + 1) + n_wgs + 1 words: the host
+// falls back to the interval plan of k_adj_masks past RG_PLAN_LDS_WORDS).  plan[w] = first graph of workgroup w, plan[w]
+// = n_graphs for the launch's surplus workgroups (the grid stays the interval count, an upper bound known without a
+// read-back), which leave at once.
+constexpr int RG_PLAN_THREADS = 1024, RG_PLAN_LDS_WORDS = 38 * 1024;
+struct RaggedPlanArgs { const int32_t* graph_off; int32_t* plan; int n_graphs, n_wgs, cap; };
+
+__global__ __launch_bounds__(RG_PLAN_THREADS) void k_ragged_plan(RaggedPlanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) int splan[];
+  const int B = a.n_graphs, W = a.n_wgs, tid = threadIdx.x;
+  int* off = splan;
+  int* cur = off + B + 1;
+  int* oth = cur + B + 1;
+  int* first = oth + B + 1;                                                // [W + 1]
+  for (int g = tid; g <= B; g += RG_PLAN_THREADS) off[g] = a.graph_off[g];
+  for (int w = tid; w <= W; w += RG_PLAN_THREADS) first[w] = 0;
+  __syncthreads();
+  for (int g = tid; g <= B; g += RG_PLAN_THREADS) {
+    // largest t in (g, min(B, g + cap)] with off[t] - off[g] <= cap; a graph that alone exceeds cap still advances by one
+    // (the kernels flag it), B is a fixed point
+    int lo = min(g + 1, B), hi = min(B, g + a.cap);
+    const int base = off[g];
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (off[mid] - base <= a.cap) lo = mid; else hi = mid - 1;
+    }
+    cur[g] = lo;
+  }
+  __syncthreads();
+  for (int b = 0; (1 << b) <= W; ++b) {
+    for (int w = tid; w <= W; w += RG_PLAN_THREADS)
+      if ((w >> b) & 1) first[w] = cur[first[w]];
+    for (int g = tid; g <= B; g += RG_PLAN_THREADS) oth[g] = cur[cur[g]];
+    __syncthreads();
+    int* t = cur; cur = oth; oth = t;
+  }
+  for (int w = tid; w <= W; w += RG_PLAN_THREADS) a.plan[w] = first[w];
+}
 
 struct RaggedFwdArgs {
   const float* xe; const int32_t* graph_off; const int32_t* row_ptr;

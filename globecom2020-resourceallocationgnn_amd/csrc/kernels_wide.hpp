@@ -551,13 +551,14 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
   for (int i = tid; i <= n; i += 256) sR[i] = a.row_ptr[r_begin + i];
   for (int i = tid; i < n * a.mask_words; i += 256) sM[i] = 0u;
   __syncthreads();
-  // 32 threads per destination row, TWO passes of 8 rows at a time with all 8 col_idx loads of a thread in flight; the row
-  // bounds come from the LDS copy of row_ptr (round 2 read them from global memory in every pass: two dependent round
-  // trips per 8 rows, 32 in a row for a 128-link graph)
-  for (int i0 = tid; i0 < n * 32; i0 += 512) {
-    int p[2][4], q[2];
+  // 32 threads per destination row, AD_MH passes of 8 rows in flight at once with all 4 col_idx loads of each: a 128-link
+  // graph is two round trips to memory (round 3: two passes in flight, eight round trips -- the launch lasts as long as
+  // its largest graph's chain).  The row bounds come from the LDS copy of row_ptr.
+  constexpr int AD_MH = 8;
+  for (int i0 = tid; i0 < n * 32; i0 += 256 * AD_MH) {
+    int p[AD_MH][4], q[AD_MH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < AD_MH; ++h) {
       const int i = i0 + 256 * h;
       q[h] = min(i >> 5, n - 1);
       const int e0 = sR[q[h]] + (i & 31), e1 = i < n * 32 ? sR[q[h] + 1] : 0;
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
       for (int u = 0; u < 4; ++u) p[h][u] = e0 + 32 * u < e1 ? a.col_idx[e0 + 32 * u] : -1;
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < AD_MH; ++h) {
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (p[h][u] >= 0 && p[h][u] < n) atomicOr(&sM[p[h][u] * a.mask_words + (q[h] >> 5)], 1u << (q[h] & 31));
@@ -578,18 +579,27 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
     }
   }
   __syncthreads();
-  // by destination = the transpose of the bit matrix: lane p reads bit q of row p, a wave ballot is 64 bits of row q
+  // by destination = the transpose of the bit matrix.  A wave takes a 32-destination word column: lane p reads ITS row's
+  // word, the two 32 x 32 bit blocks of the wave (sources 0-31 / 32-63 of the block) are transposed in place by five
+  // exchange steps across lanes (blocks of 16, 8, 4, 2, 1: lane ^ j hands over the half this lane lacks), and lane t ends up
+  // holding 32 source bits of destination 32 qw + t -- one word of its by-destination row.  (Round 3: one LDS read and one
+  // ballot per destination and source block; this launch is bound by its integer instruction count, not by memory.)
+  // Words past the graph's own sources stay unwritten: every reader masks a row to its graph's n bits.
   {
     const int lane = tid & 63, wv = tid >> 6, n_blk = (n + 63) >> 6;
-    for (int q = wv; q < n; q += 4)
+    for (int qw = wv; 32 * qw < n; qw += 4)
       for (int blk = 0; blk < n_blk; ++blk) {
         const int pp = 64 * blk + lane;
-        const bool bit = pp < n && ((sM[pp * a.mask_words + (q >> 5)] >> (q & 31)) & 1u);
-        const unsigned long long bal = __ballot(bit);
-        if (lane == 0) {
-          sD[q * a.mask_words + 2 * blk] = (unsigned)bal;
-          if (2 * blk + 1 < a.mask_words) sD[q * a.mask_words + 2 * blk + 1] = (unsigned)(bal >> 32);
+        unsigned w = pp < n ? sM[pp * a.mask_words + qw] : 0u;
+        unsigned mk = 0x0000ffffu;
+#pragma unroll
+        for (int j = 16; j; j >>= 1) {
+          const unsigned other = (unsigned)__shfl_xor((int)w, j);
+          w = (lane & j) ? ((w & (mk << j)) | ((other >> j) & mk)) : ((w & mk) | ((other & mk) << j));
+          mk ^= mk << (j >> 1);
         }
+        const int q = 32 * qw + (lane & 31), word = 2 * blk + (lane >> 5);
+        if (q < n && word < a.mask_words) sD[q * a.mask_words + word] = w;
       }
   }
   __syncthreads();

@@ -84,6 +84,7 @@ struct v2x_model {
   bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
   bool compl_sums = true;                       // V2X_FUSED_COMPL (read at create): dense graphs aggregate through the complement
   bool ragged_fused = true, ragged_fused_bwd = true;   // V2X_RAGGED_FUSED / V2X_RAGGED_FUSED_BWD (read at create): kernels_ragged.hpp
+  bool ragged_packed = true;    // V2X_RAGGED_PACKED: tiles packed by k_ragged_plan (0: the row-interval plan of k_adj_masks)
   bool small_predict = true;                    // V2X_SMALL_PREDICT (read at create): few-graph forwards in one launch (kernels_small.hpp)
   unsigned long long* small_h = nullptr;        // its exchange buffer [L + 1][SMALL_ROWS][F] tagged words
   unsigned long long* small_sync = nullptr;     // and per-graph departure counters [SMALL_ROWS] (64-bit)
@@ -1460,6 +1461,10 @@ bool need_adj_masks(const v2x_model* m, const DevBatch& d) { return use_dense_ag
 int ragged_capp(const DevBatch& d) { return RG_CAP - d.max_nodes + 1; }
 int ragged_wgs(const DevBatch& d) { return (d.R + ragged_capp(d) - 1) / ragged_capp(d); }
 
+// k_ragged_plan's tables in LDS; past that (tens of thousands of graphs in one batch) the interval plan of k_adj_masks
+int ragged_plan_words(const DevBatch& d) { return 3 * (d.B + 1) + ragged_wgs(d) + 1; }
+bool ragged_packed_plan(const v2x_model* m, const DevBatch& d) { return m->ragged_packed && ragged_plan_words(d) <= RG_PLAN_LDS_WORDS; }
+
 template <int F>
 int launch_ragged_fwd_f(v2x_model* m, hipStream_t st, const RaggedFwdArgs& a, int n_wgs) {
   auto k = k_gnn_fwd_ragged<F>;
@@ -1529,8 +1534,15 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
       q.adj = (unsigned*)m->adj_mask.p;
       q.adjT = q.adj + (size_t)d.R * q.mask_words;
       q.err = m->flag_dev;
-      if (ragged) { q.plan = (int32_t*)m->plan_buf.p; q.plan_capp = ragged_capp(d); q.plan_n = ragged_wgs(d); }
+      const bool packed = ragged && ragged_packed_plan(m, d);
+      if (ragged && !packed) { q.plan = (int32_t*)m->plan_buf.p; q.plan_capp = ragged_capp(d); q.plan_n = ragged_wgs(d); }
       CHK(build_adj_masks(m, st, q));
+      if (packed) {
+        static const bool once = [] { allow_big_lds((const void*)k_ragged_plan); return true; }();
+        (void)once;
+        RaggedPlanArgs pa{d.goff, (int32_t*)m->plan_buf.p, d.B, ragged_wgs(d), RG_CAP};
+        LAUNCH_T(m, "k_ragged_plan", k_ragged_plan, dim3(1), RG_PLAN_THREADS, (size_t)ragged_plan_words(d) * 4, st, pa);
+      }
     }
     if (ragged) {                                        // embed + L stages + L + 1 aggregations of ragged graphs: one launch
       CHK(launch_ragged_fwd(m, st, d));
@@ -1806,6 +1818,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   m->small_predict = env_int("V2X_SMALL_PREDICT", 1) != 0;
   m->ragged_fused = env_int("V2X_RAGGED_FUSED", 1) != 0;
   m->ragged_fused_bwd = env_int("V2X_RAGGED_FUSED_BWD", 1) != 0;
+  m->ragged_packed = env_int("V2X_RAGGED_PACKED", 1) != 0;
   if (m->small_predict && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
     const size_t hb = (size_t)(m->L + 1) * SMALL_ROWS * m->F * sizeof(unsigned long long), sb = (size_t)2 * SMALL_ROWS * sizeof(unsigned);
     void *ph = nullptr, *ps = nullptr;

@@ -269,6 +269,8 @@ RAGGED = [  # feat_dim, layers, topology, sizes
     (16, 1, 'ref', list(np.random.default_rng(3).integers(8, 129, size=50))),
     (64, 2, 'ref', [40, 33]),                                                         # less than one workgroup of rows
     (64, 4, 'mixed', list(np.random.default_rng(4).integers(30, 129, size=24))),
+    (64, 2, 'ref', [1] * 700 + [128, 64, 128] + [2] * 90),                            # runs of one-node graphs: a tile of 320 graphs
+    (32, 2, 'ref', [64] * 25 + [128] * 5 + [32] * 30),                                # tiles that fill exactly (5 x 64 = 320 rows)
 ]
 
 
@@ -303,6 +305,17 @@ def test_ragged_fused_layers_vs_layerwise_and_oracle(F, L, kind, sizes):
     #  unit-scale residuals q - y -- the two paths' gradients are not comparable, only their forwards are)
     g = fused.get_grad_flat()
     assert_grads_match_oracle(v2xgnn.flat_to_keras_list(spec, g), P, step, "ragged fused F=%d L=%d %s" % (F, L, kind))
+    # the tiles packed by k_ragged_plan (the default) against the row-interval plan of k_adj_masks: every row's arithmetic
+    # is the same wherever its graph sits in a tile, so the two agree bit for bit
+    os.environ["V2X_RAGGED_PACKED"] = "0"
+    try:
+        interval = _engine(spec, oc.params_to_list(P), True)
+    finally:
+        del os.environ["V2X_RAGGED_PACKED"]
+    assert np.array_equal(interval.forward(pb), q), "packed plan vs interval plan: forward"
+    interval.forward_backward(pb, y, n_global=pb.n_rows)
+    assert np.array_equal(interval.get_grad_flat(), g), "packed plan vs interval plan: gradients"
+    interval.close()
     for _ in range(3):
         fused.train_step(pb, y, n_global=pb.n_rows)
     assert np.all(np.isfinite(fused.get_flat())) and fused.get_optimizer_state()[2] == 3

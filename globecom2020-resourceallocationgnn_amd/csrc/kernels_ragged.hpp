@@ -75,6 +75,72 @@ __global__ __launch_bounds__(RG_PLAN_THREADS) void k_ragged_plan(RaggedPlanArgs 
   for (int w = tid; w <= W; w += RG_PLAN_THREADS) a.plan[w] = first[w];
 }
 
+// One lane's share of a graph's column sum: rows rg, rg + RGN, ... of the tile, four loads in flight and four running sums
+// (a 128-node graph was a chain of 32 dependent LDS reads); fixed order, so the sums stay reproducible.
+template <int LDT, int RGN>
+__device__ __forceinline__ f32x4 rg_column_partial(const float* col, int rg, int n) {
+  f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int r = rg;
+  for (; r + 3 * RGN < n; r += 4 * RGN) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(col + r * LDT), v1 = *reinterpret_cast<const f32x4*>(col + (r + RGN) * LDT),
+                v2 = *reinterpret_cast<const f32x4*>(col + (r + 2 * RGN) * LDT), v3 = *reinterpret_cast<const f32x4*>(col + (r + 3 * RGN) * LDT);
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  for (; r < n; r += RGN) s0 += *reinterpret_cast<const f32x4*>(col + r * LDT);
+  return (s0 + s1) + (s2 + s3);
+}
+
+// Per-row record of the aggregation walk (built once per workgroup, read by every stage): the first K entries of the
+// row's walk -- the ZERO bits of its mask if the row goes through the complement, else the ONE bits (k_agg_dense's rule:
+// complement when the graph has a column-sum slot and the row more edges than non-edges) -- 7 bits each, their count, and
+// whether the walk has more.  With the reference topology a destination's complement is itself and the link it does not
+// hear (2 entries: the forward keeps 3 in one word).  The backward (a SOURCE's complement is itself and the links that do not
+// hear it, 1 + Poisson(1) entries) keeps the bit walk: its 254 registers have no room for several rows in flight -- a
+// two-word record with the gates held as bits spilled and cost 104 -> 138 us.
+constexpr int RG_REC_K = 3, RG_REC_CNT = 21;
+constexpr unsigned RG_REC_MORE = 1u << 23, RG_REC_DIRECT = 1u << 24;
+template <int K>
+__device__ __forceinline__ void rg_row_entries(const unsigned* mrow, int n, int slot, unsigned (&ent)[K], int& cnt, bool& more,
+                                               bool& direct) {
+  unsigned z[RG_MW];
+  int ones = 0;
+#pragma unroll
+  for (int w = 0; w < RG_MW; ++w) {
+    const int left = n - 32 * w;
+    const unsigned lim = left <= 0 ? 0u : (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
+    z[w] = mrow[w] & lim;
+    ones += __builtin_popcount(z[w]);
+  }
+  direct = slot >= RG_SLOTS || 2 * ones < n;
+  more = false;
+  cnt = 0;
+#pragma unroll
+  for (int e = 0; e < K; ++e) ent[e] = 0u;
+#pragma unroll
+  for (int w = 0; w < RG_MW; ++w) {
+    const int left = n - 32 * w;
+    const unsigned lim = left <= 0 ? 0u : (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
+    unsigned zz = direct ? z[w] : ~z[w] & lim;
+    while (zz && cnt < K) {
+      const unsigned p = 32 * w + __builtin_ctz(zz);
+#pragma unroll
+      for (int e = 0; e < K; ++e)
+        if (e == cnt) ent[e] = p;
+      zz &= zz - 1;
+      ++cnt;
+    }
+    if (zz) more = true;
+  }
+}
+__device__ __forceinline__ unsigned rg_row_record(const unsigned* mrow, int n, int slot) {
+  unsigned ent[RG_REC_K];
+  int cnt; bool more, direct;
+  rg_row_entries<RG_REC_K>(mrow, n, slot, ent, cnt, more, direct);
+  unsigned rec = (direct ? RG_REC_DIRECT : 0u) | (more ? RG_REC_MORE : 0u) | (unsigned)cnt << RG_REC_CNT;
+#pragma unroll
+  for (int e = 0; e < RG_REC_K; ++e) rec |= ent[e] << (7 * e);
+  return rec;
+}
 struct RaggedFwdArgs {
   const float* xe; const int32_t* graph_off; const int32_t* row_ptr;
   const unsigned* adjT;                        // [R][mask_words] by destination: bit p of adjT[q] = edge p -> q
@@ -92,7 +158,7 @@ struct RaggedLds {
   static constexpr int FB = F / 16, LDT = F + 4;
   static constexpr int KP = 2 * F + XE, LDW = F + 4;
   static constexpr int TILE = 0, SUMS = TILE + RG_CAP * LDT, WIMG = SUMS + RG_SLOTS * LDT, BIAS = WIMG + KP * LDW, MASK = BIAS + F,
-                       INFO = MASK + RG_CAP * RG_MW, GOFF = INFO + RG_CAP, TOTAL = GOFF + RG_CAP + 8;
+                       INFO = MASK + RG_CAP * RG_MW, GOFF = INFO + RG_CAP, REC = GOFF + RG_CAP + 8, TOTAL = REC + RG_CAP;
 };
 
 template <int F>
@@ -105,6 +171,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_gnn_fwd_ragged(RaggedFwdArgs 
   unsigned* sMask = reinterpret_cast<unsigned*>(smem + Lds::MASK);
   int* sInfo = reinterpret_cast<int*>(smem + Lds::INFO);                  // per row: r0 | n << 9 | slot << 17  (slot = RG_SLOTS: none)
   int* sGoff = reinterpret_cast<int*>(smem + Lds::GOFF);                  // the tile's graph offsets (local rows)
+  unsigned* sRec = reinterpret_cast<unsigned*>(smem + Lds::REC);          // per row: rg_row_record
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, kg = lane >> 4;
   // per-stage pointers through the kernarg segment (a by-value array indexed at run time would be copied to scratch)
   typedef const __attribute__((address_space(4))) unsigned char* CBytes;
@@ -179,6 +246,7 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_gnn_fwd_ragged(RaggedFwdArgs 
     }
     if ((n < 1 || n > 128) && a.err) atomicOr(a.err, 1);
     sInfo[tid] = r0 | (n << 9) | (slot << 17);
+    sRec[tid] = rg_row_record(sMask + tid * RG_MW, min(max(n, 0), 128), slot);
   }
   store_weights(0, wreg);
   __syncthreads();
@@ -271,13 +339,13 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_gnn_fwd_ragged(RaggedFwdArgs 
         const int r0 = sGoff[g], n = sGoff[g + 1] - r0;
         if (n < RG_BIG) continue;
         if ((slot & (RG_WAVES - 1)) == wv) {
-          f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-          for (int r = rg; r < n; r += RGN) sum += *reinterpret_cast<const f32x4*>(sT + (r0 + r) * LDT + 16 * ckb + 4 * ckg);
+          const f32x4 sum = rg_column_partial<LDT, RGN>(sT + r0 * LDT + 16 * ckb + 4 * ckg, rg, n);
+          f32x4 tot = sum;
 #pragma unroll
           for (int o = COMB; o < 64; o <<= 1)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sum[e] += __shfl_xor(sum[e], o, 64);
-          if (rg == 0) *reinterpret_cast<f32x4*>(sS + slot * LDT + 16 * ckb + 4 * ckg) = sum;
+            for (int e = 0; e < 4; ++e) tot[e] += __shfl_xor(tot[e], o, 64);
+          if (rg == 0) *reinterpret_cast<f32x4*>(sS + slot * LDT + 16 * ckb + 4 * ckg) = tot;
         }
         ++slot;
       }
@@ -285,26 +353,47 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_gnn_fwd_ragged(RaggedFwdArgs 
     stamp();
     __syncthreads();
     stamp();
-    // ---- a_s of this lane's rows: out of the tile, into registers (next stage's B operand) and to HBM
+    // ---- a_s of this lane's rows: out of the tile, into registers (next stage's B operand) and to HBM.  A row whose walk
+    // has at most RG_REC_K entries takes them from its record (prologue): all tile reads of the row are in flight at once
+    // instead of one dependent LDS round trip per bit (find the bit, read, add: ~0.7 us of a ~1.5 us tile), absent entries
+    // read row 0 of the graph with weight 0.  Same additions in the same order as the walk; longer rows take the walk.
 #pragma unroll
     for (int t = 0; t < RG_RT; ++t) {
       f32x4 acc2[FB];
+      const bool live = rr[t] < rows;
+      const int row = min(rr[t], RG_CAP - 1);
+      const int info = sInfo[row];
+      const unsigned rec = live ? sRec[row] : 0u;
+      const int r0 = live ? info & 511 : 0, slot = info >> 17;
+      {
+        const float* base = sT + r0 * LDT + 4 * kg;
+        f32x4 v[RG_REC_K][FB], sm[FB];
 #pragma unroll
-      for (int b = 0; b < FB; ++b) acc2[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (rr[t] < rows) {
-        const int info = sInfo[rr[t]], r0 = info & 511, n = (info >> 9) & 255, slot = info >> 17;
-        int ones = 0;
+        for (int e = 0; e < RG_REC_K; ++e)
 #pragma unroll
-        for (int w = 0; w < RG_MW; ++w) {
-          const int left = n - 32 * w;
-          if (left > 0) ones += __builtin_popcount(sMask[rr[t] * RG_MW + w] & (left >= 32 ? 0xffffffffu : ((1u << left) - 1u)));
+          for (int b = 0; b < FB; ++b) v[e][b] = *reinterpret_cast<const f32x4*>(base + ((rec >> (7 * e)) & 127u) * LDT + 16 * b);
+        const int sl = (rec & RG_REC_DIRECT) || !live ? 0 : slot;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) sm[b] = *reinterpret_cast<const f32x4*>(sS + sl * LDT + 16 * b + 4 * kg);
+        const int cnt = (rec >> RG_REC_CNT) & 3u;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) {
+          f32x4 x = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < RG_REC_K; ++e) x += v[e][b] * (cnt > e ? 1.f : 0.f);
+          acc2[b] = (rec & RG_REC_DIRECT) || !live ? x : sm[b] - x;
         }
-        const bool direct = slot >= RG_SLOTS || 2 * ones < n;
+      }
+      if (rec & RG_REC_MORE) {                                            // (rows of a live lane only)
+        const int n = (info >> 9) & 255;
+        const bool direct = rec & RG_REC_DIRECT;
+#pragma unroll
+        for (int b = 0; b < FB; ++b) acc2[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < RG_MW; ++w) {
           const int left = n - 32 * w;
           if (left <= 0) break;
-          const unsigned m = sMask[rr[t] * RG_MW + w];
+          const unsigned m = sMask[row * RG_MW + w];
           unsigned z = (direct ? m : ~m) & (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
           while (z) {
             const int p = 32 * w + __builtin_ctz(z);
@@ -318,6 +407,8 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_gnn_fwd_ragged(RaggedFwdArgs 
 #pragma unroll
           for (int b = 0; b < FB; ++b) acc2[b] = *reinterpret_cast<const f32x4*>(sS + slot * LDT + 16 * b + 4 * kg) - acc2[b];
         }
+      }
+      if (live) {
 #pragma unroll
         for (int b = 0; b < FB; ++b) st4(a_out + (int64_t)(R0 + rr[t]) * F + b * 16 + 4 * kg, acc2[b]);
       }
@@ -457,13 +548,13 @@ __global__ __launch_bounds__(RG_THREADS, 1) void k_gnn_bwd_ragged(RaggedBwdArgs 
         const int r0 = sGoff[g], n = sGoff[g + 1] - r0;
         if (n < RG_BIG) continue;
         if ((slot & (RG_WAVES - 1)) == wv) {
-          f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-          for (int r = rg; r < n; r += RGN) sum += *reinterpret_cast<const f32x4*>(sT + (r0 + r) * LDT + 16 * ckb + 4 * ckg);
+          const f32x4 sum = rg_column_partial<LDT, RGN>(sT + r0 * LDT + 16 * ckb + 4 * ckg, rg, n);
+          f32x4 tot = sum;
 #pragma unroll
           for (int o = COMB; o < 64; o <<= 1)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) sum[e] += __shfl_xor(sum[e], o, 64);
-          if (rg == 0) *reinterpret_cast<f32x4*>(sS + slot * LDT + 16 * ckb + 4 * ckg) = sum;
+            for (int e = 0; e < 4; ++e) tot[e] += __shfl_xor(tot[e], o, 64);
+          if (rg == 0) *reinterpret_cast<f32x4*>(sS + slot * LDT + 16 * ckb + 4 * ckg) = tot;
         }
         ++slot;
       }

@@ -5,9 +5,8 @@ run() {
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$WL $*', d['ms_per_step'], d['config']['kernel_path']['graph_layers'], {k:v['avg_us'] for k,v in d['kernels'].items()})"
 }
-python -m pytest tests/test_gpu_fused.py tests/test_gpu_fullsize.py tests/test_gpu_model.py tests/test_gpu_kernels.py tests/test_gpu_configs.py -m gpu -x -q -k "cfg4 or cfg3 or ragged or variable or dense or wide or mask" 2>&1 | tail -5
+python -m pytest tests/test_gpu_fused.py tests/test_gpu_fullsize.py tests/test_gpu_model.py tests/test_gpu_kernels.py tests/test_gpu_configs.py -m gpu -x -q -k "cfg4 or ragged or variable" 2>&1 | tail -5
 for i in 1 2; do
-WL=cfg5 run V2X_RAGGED_PACKED=0
 WL=cfg5 run V2X_RAGGED_PACKED=1
 done
-WL=cfg4 run V2X_RAGGED_PACKED=1
+python tools/ragged_phases.py 2>&1 | tail -10

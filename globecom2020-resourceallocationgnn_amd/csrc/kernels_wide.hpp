@@ -59,7 +59,19 @@ __global__ __launch_bounds__(256, 5) void k_wide_gemm(WideGemmArgs a) {      // 
   constexpr int CPR = KC / 4;                                    // float4 per activation row of the chunk
   __shared__ __attribute__((aligned(16))) float sA[2][KC * LDA];         // weights  [k][n]
   __shared__ __attribute__((aligned(16))) float sB[2][TM * LDB];         // activations [row][k]
-  const int slot = blockIdx.z, m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  // Workgroup -> tile, XCD-aware.  The gridDim.y column tiles of one row block all read the SAME activation rows (the
+  // block's [TM x K] strip: 270 KB at K = 528); workgroup ids are dealt round-robin to the 8 XCDs, each with an L2 of its
+  // own, so with the row block as the fastest index the strip came from HBM once per column tile (PMC: 597 MB per node
+  // update against 320 algorithmic, 654 against 315 for a data gradient).  Here the ids i, i + 8, i + 16, ... of a run of
+  // 8 gridDim.y consecutive workgroups -- one XCD, dispatched together -- are the column tiles of ONE row block: the strip is
+  // fetched once and hit in that L2 by the others.  (The last, partial run of row blocks keeps the plain order.)
+  int mb, nb;
+  {
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y, ny = gridDim.y, run = 8 * ny, full = (int)gridDim.x / 8 * run;
+    if (lin < full) { mb = lin / run * 8 + (lin & 7); nb = (lin % run) >> 3; }
+    else { const int l = lin - full; mb = full / ny + l / ny; nb = l % ny; }
+  }
+  const int slot = blockIdx.z, m0 = mb * TM, n0 = nb * TN;
   const float* Wg = a.W + slot * a.slot_stride;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, kg = lane >> 4;
   const int n_chunks = a.k_total / KC;
@@ -227,7 +239,9 @@ struct WideWgradArgs {
 // tiles w, w + 4, ... of that strip (+ 12.5 % MFMAs for one workgroup in KT instead of a whole extra workgroup).
 template <int KW, int NT> struct WideWgradLds {
   static constexpr int WW_TR = NT >= 16 ? 16 : 32;               // rows per chunk (LDS budget: 2 workgroups per CU)
-  static constexpr int LDX = KW + 4, LDD = 16 * NT + 4, LDE = 20;
+  // row strides = 16 mod 64 banks: the operand reads are dwords at [row 4 s + kg][16-aligned offset + j] -- the four k-groups
+  // of a wave land on four disjoint sets of 16 banks (with + 4, round 3, they overlapped: up to 4 lanes per bank)
+  static constexpr int LDX = KW + 16, LDD = 16 * NT + ((16 * NT) % 64 == 0 ? 16 : (16 * NT) % 64 == 16 ? 0 : (16 * NT) % 64 == 32 ? 48 : 32), LDE = 16;
   static constexpr int X = 2 * WW_TR * LDX, D = 2 * WW_TR * LDD, E = 2 * WW_TR * LDE;
 };
 
@@ -468,7 +482,17 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad_multi(WideWgradMulti mu) 
   for (int i = 1; i < WWM_ROLES; ++i) r += (b >= (int)tail[i] && i < (int)tail[WWM_ROLES + 1 + 3 * WWM_ROLES]) ? 1 : 0;
   const int local = b - (int)tail[r];
   const int kt = (int)tail[WWM_ROLES + 1 + r], nt = (int)tail[WWM_ROLES + 1 + WWM_ROLES + r], kind = (int)tail[WWM_ROLES + 1 + 2 * WWM_ROLES + r];
-  const int bx = local % kt, by = (local / kt) % nt, bz = local / (kt * nt);
+  // The kt K tiles of one (column tile, row split) chunk all read the SAME dpre rows; with the K tile as the fastest index
+  // they sat on kt different XCDs and every L2 fetched the rows for itself (PMC: 3.5 GB per launch against 1.3 GB
+  // algorithmic at configs[3]).  As in k_wide_gemm: ids i, i + 8, ... of a run of 8 kt workgroups -- one XCD -- are the K
+  // tiles of one chunk.
+  int bx, chunk;
+  {
+    const int n_chunks = ((int)tail[r + 1] - (int)tail[r]) / kt, run = 8 * kt, full = n_chunks / 8 * run;
+    if (local < full) { bx = (local % run) >> 3; chunk = local / run * 8 + (local & 7); }
+    else { const int l = local - full; bx = l % kt; chunk = full / kt + l / kt; }
+  }
+  const int by = chunk % nt, bz = chunk / nt;
   WideWgradArgs a;
   unsigned* dstw = reinterpret_cast<unsigned*>(&a);
   CWords srcw = base + r * NW;

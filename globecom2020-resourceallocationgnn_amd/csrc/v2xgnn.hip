@@ -1536,13 +1536,16 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
       q.err = m->flag_dev;
       const bool packed = ragged && ragged_packed_plan(m, d);
       if (ragged && !packed) { q.plan = (int32_t*)m->plan_buf.p; q.plan_capp = ragged_capp(d); q.plan_n = ragged_wgs(d); }
-      CHK(build_adj_masks(m, st, q));
+      // (the plan reads the offsets, the masks the CSR: independent -- but as a forked branch of the captured step the two
+      //  cost MORE than one after the other: 0.466 against 0.455 ms per configs[4] step, the graph's cross-branch
+      //  dependencies outweigh the 5 us the plan takes)
       if (packed) {
         static const bool once = [] { allow_big_lds((const void*)k_ragged_plan); return true; }();
         (void)once;
         RaggedPlanArgs pa{d.goff, (int32_t*)m->plan_buf.p, d.B, ragged_wgs(d), RG_CAP};
         LAUNCH_T(m, "k_ragged_plan", k_ragged_plan, dim3(1), RG_PLAN_THREADS, (size_t)ragged_plan_words(d) * 4, st, pa);
       }
+      CHK(build_adj_masks(m, st, q));
     }
     if (ragged) {                                        // embed + L stages + L + 1 aggregations of ragged graphs: one launch
       CHK(launch_ragged_fwd(m, st, d));

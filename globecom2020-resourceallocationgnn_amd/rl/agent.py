@@ -401,6 +401,14 @@ class Agent(object):
         """BS_brain.py:750-910 without the plotting / pickling: episodes x train steps x (50 transitions + 1 replay),
         target sync whenever num_step is a multiple of 500, weights saved every `save_interval` episodes."""
         self.num_Episodes, self.num_Train_Step = num_episodes, num_train_steps
+        # Everything alive now (the imported frameworks, the engines, the simulator) goes to the collector's permanent
+        # generation: a full collection inside a train step walked ~1e6 such objects -- 40-70 ms, once or twice per hundred
+        # steps of a 3 ms loop (measured, tools/prof_rl_sections.py).  Nothing is leaked: frozen objects are still freed by
+        # reference counting; V2X_RL_GC_FREEZE=0 leaves the collector alone.
+        if os.environ.get("V2X_RL_GC_FREEZE", "1") != "0":
+            import gc
+            gc.collect()
+            gc.freeze()
         n = self.num_D2D
         world = self._shard_world()
         self.num_transition = -(-50 // world)          # sharded rollouts: this rank's share of the 50 transitions per step

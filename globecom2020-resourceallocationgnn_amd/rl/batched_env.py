@@ -66,7 +66,11 @@ class BatchedEnviron(object):
         self._mt_keys = self._mt_pos = None
         if self.native:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            native_sim.set_threads(max(1, min(self.E, cores, 32)))
+            # at most 16 OpenMP threads: a call is 20-300 us of work per step, and on the 256-core host of an MI355X box 32
+            # threads brought 25-48 ms stalls a few times per hundred steps (tools/prof_rl_sections.py: spinning workers
+            # against the GPU runtime's own threads) for 0.2 ms of median; V2X_SIM_THREADS overrides
+            cap = int(os.environ.get("V2X_SIM_THREADS", "16"))
+            native_sim.set_threads(max(1, min(self.E, cores, cap)))
             if not self._shared:                               # the streams' MT19937 states, where the library can advance them
                 self._mt_keys = np.empty((self.E, 624), np.uint32)
                 self._mt_pos = np.zeros(self.E, np.int32)

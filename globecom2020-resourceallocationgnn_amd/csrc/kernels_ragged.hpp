@@ -13,6 +13,11 @@
 // row lies in [w CAPP, (w + 1) CAPP) -- at most RG_CAP rows, every graph exactly once, balanced by rows whatever the size
 // mix.  The first graph of every interval comes from a plan k_adj_masks writes (one thread per graph: no search) -- or, by
 // default, from k_ragged_plan below, which packs the same runs tightly.
+// What does NOT help (round 4, built and measured at configs[4]): the tile's graphs as two halves half a stage apart -- waves
+// 0-3 run the node update (MFMAs) of their graphs while waves 4-7, one per SIMD next to them, write / sum / aggregate theirs,
+// plain workgroup barriers at three matched points per slot.  Taken alone the MFMA role made the launch 70 us and the other
+// role 62 us; together 109 us, against 101 us for this kernel: a SIMD does not overlap one wave's fp32 MFMAs with another
+// wave's vector-ALU work (it does overlap them with LDS and memory waits -- which two waves in the SAME phase already cover).
 // Aggregation, per row: through the complement (column sum of the graph minus the rows at the ZERO bits of the row's
 // by-destination mask) when the row has more edges than non-edges and its graph at least 16 nodes, else the rows at the ONE
 // bits directly -- k_agg_dense's rule (kernels_wide.hpp); masks are the ones k_adj_masks builds for the backward anyway.

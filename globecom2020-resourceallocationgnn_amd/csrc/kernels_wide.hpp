@@ -12,6 +12,7 @@
 //   k_wide_gemm<true>   their data gradients:  [dh | dagg] = dpre . W[h rows | agg rows]^T
 //   k_wide_wgrad        dW = in^T . dpre, db = sum dpre   (64 x 64 tile of dW per workgroup, rows streamed)
 #pragma once
+#include <type_traits>
 #include "kernels.hpp"
 
 namespace v2x {
@@ -326,13 +327,53 @@ __device__ __forceinline__ void wide_wgrad_body(const WideWgradArgs& a, float* s
   float bsum = 0.f;                                             // column n0 + tid of the kt == 0 tile
   const bool do_bias = bx == 0 && tid < TN;
 
+  // Every chunk but the last of a split is whole and inside the batch: on a full K tile x full column tile its loads need
+  // neither clamp nor mask, and go through gload_fast (no vector-ALU address arithmetic at all, where gload spends ~15
+  // integer instructions per load on row / segment / mask -- this launch's vector-ALU instructions come out of its MFMA
+  // time: a SIMD does not overlap the two, kernels_ragged.hpp); gload keeps the first chunk, the tail and partial tiles.
+  typedef const __attribute__((address_space(1))) f32x4* gf4_p;
+  // address = UNIFORM chunk base (scalar registers, advanced by scalar adds) + a per-thread 32-bit offset that never changes
+  // (the loads' saddr + voffset form): the passes of a tile are a uniform number of rows apart
+  constexpr bool REG = 256 % (KW / 4) == 0 && 256 % (TN / 4) == 0 && WW_TR * TN / 4 == 256 * DP;     // (not Dense-0's 80 columns)
+  const int64_t row_step = (int64_t)WW_TR * a.row_stride;
+  const int64_t row01 = (int64_t)(a.idx_base + i_begin + WW_TR) * a.row_stride + slot * a.base_mul;       // chunk 1 (chunk 0 takes gload)
+  const int cx0 = (tid % (KW / 4)) << 2, cd0 = n0 + ((tid % (TN / 4)) << 2);
+  const unsigned off_x = (unsigned)((tid / (KW / 4)) * a.row_stride * xst + cx0);
+  const unsigned off_d = (unsigned)((tid / (TN / 4)) * a.row_stride * a.d_stride + cd0);
+  const unsigned off_e = FOLD ? (unsigned)(min(tid >> 2, WW_TR - 1) * a.row_stride * a.xseg.stride + ((tid & 3) << 2)) : 0u;
+  gfloat_p bx_ = (gfloat_p)xp + row01 * xst + kcol0, bd_ = (gfloat_p)a.dpre + row01 * a.d_stride;
+  gfloat_p be_ = FOLD ? (gfloat_p)a.xseg.ptr + row01 * a.xseg.stride : nullptr;
+  const int64_t pass_x = (int64_t)(256 / (KW / 4)) * a.row_stride * xst, pass_d = (int64_t)(256 / (TN / 4)) * a.row_stride * a.d_stride;
+  const int64_t step_x = row_step * xst, step_d = row_step * a.d_stride, step_e = FOLD ? row_step * a.xseg.stride : 0;
+  // plain: every thread's loads of a whole chunk are real elements (full K tile, full column tile, whole passes)
+  const bool plain = REG && kw == KW && n0 + TN <= a.n_real;
+  auto gload_fast = [&](float4 (&vx)[XP], float4 (&vd)[DP], float4& ve) {     // the NEXT whole chunk; the bases move on
+#pragma unroll
+    for (int p = 0; p < XP; ++p) {
+      const f32x4 x = *reinterpret_cast<gf4_p>(bx_ + p * pass_x + off_x);
+      vx[p] = make_float4(x[0], x[1], x[2], x[3]);
+    }
+#pragma unroll
+    for (int p = 0; p < DP; ++p) {
+      const f32x4 d = *reinterpret_cast<gf4_p>(bd_ + p * pass_d + off_d);
+      vd[p] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    if (FOLD) {
+      const f32x4 e = *reinterpret_cast<gf4_p>(be_ + off_e);
+      ve = make_float4(e[0], e[1], e[2], e[3]);
+      be_ += step_e;
+    }
+    bx_ += step_x; bd_ += step_d;
+  };
+
   float4 vx[XP], vd[DP], ve = make_float4(0.f, 0.f, 0.f, 0.f);
   if (n_chunks > 0) { gload(0, vx, vd, ve); lstore(0, vx, vd, ve); }
   __syncthreads();
-#pragma unroll 1
-  for (int c = 0; c < n_chunks; ++c) {
+  // (two loops over one body: a branch between the two loaders INSIDE the loop cost 40 us of this launch)
+  auto chunk = [&](int c, auto fast) {
     const int buf = c & 1;
-    gload(min(c + 1, n_chunks - 1), vx, vd, ve);      // unconditional, clamped (see k_wide_gemm)
+    if constexpr (decltype(fast)::value) gload_fast(vx, vd, ve);
+    else gload(min(c + 1, n_chunks - 1), vx, vd, ve);  // first / last chunks, partial tiles: clamped and masked; unconditional
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < WW_TR / 4; ++s) {
@@ -361,7 +402,12 @@ __device__ __forceinline__ void wide_wgrad_body(const WideWgradArgs& a, float* s
     __builtin_amdgcn_sched_barrier(0);
     lstore(buf ^ 1, vx, vd, ve);
     __syncthreads();
-  }
+  };
+  const int n_fast = plain ? max(n_chunks - 2, 0) : 0;         // chunk c loads chunk c + 1: whole and in range for c + 1 < n_chunks - 1
+#pragma unroll 1
+  for (int c = 0; c < n_fast; ++c) chunk(c, std::true_type());
+#pragma unroll 1
+  for (int c = n_fast; c < n_chunks; ++c) chunk(c, std::false_type());
 
   // lane holds dW[kpad0 + 64*ks + 16*wv + 4*kg + r][n0 + nt*16 + j]
   const int64_t lbase = a.layer_off + slot * a.slot_stride;

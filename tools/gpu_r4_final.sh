@@ -43,6 +43,10 @@ for wl in cfg4 cfg5; do
   for d in fetch write mfma; do python tools/rocpd_summary.py $(db $O/${d}_$wl) > $O/${d}_$wl.txt 2>&1; done
   python tools/roofline_table2.py $O/bench_$wl.json $O/fetch_$wl.txt $O/write_$wl.txt $O/mfma_$wl.txt > $O/roofline_$wl.md 2>&1
 done
+V2X_RAGGED_PACKED=0 $Q --workload cfg5 --shard-of 8 > $O/bench_cfg5_intervalplan.json 2>/dev/null
+python tools/ragged_phases.py 2>&1 | grep -v amdgpu.ids > $O/ragged_phases.txt
+python tools/prof_rl_sections.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 > $O/rl_sections.txt
+python tools/sim_threads.py 2>&1 | grep -v amdgpu.ids > $O/sim_threads.txt
 python bench.py --workload cfg0 --envs 10 > $O/bench_cfg0_episode_envs10.json 2>/dev/null
 for i in 1 2 3; do python bench.py --workload cfg2loop --envs 50 > $O/bench_cfg2loop_envs50_run$i.json 2>/dev/null; done
 python tools/predict_latency.py 2>&1 | grep -v amdgpu.ids > $O/predict_latency.txt

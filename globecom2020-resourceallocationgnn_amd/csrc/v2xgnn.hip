@@ -78,7 +78,8 @@ struct v2x_model {
   // staging for host-side inputs
   DevBuf st_xe, st_nbr, st_goff, st_rp, st_ci, st_y, st_q;
   DevBuf adj_mask;              // adjacency bit masks of the current batch (dense-graph aggregation)
-  DevBuf plan_buf;              // work plan of the ragged fused forward (kernels_ragged.hpp): first graph per row interval
+  DevBuf plan_buf;              // work plan of the ragged fused forward (kernels_ragged.hpp): first graph of every workgroup
+  int plan_len = 0;             // entries of the last plan (workgroups + 1)
   long long* ts_buf = nullptr;                  // V2X_FUSED_TS=1: phase time stamps of the fused forward (measurement)
   bool raw_params = false;                      // v2x_param_ptr was called: re-pack before every fused forward
   bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
@@ -1535,6 +1536,7 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
       q.adjT = q.adj + (size_t)d.R * q.mask_words;
       q.err = m->flag_dev;
       const bool packed = ragged && ragged_packed_plan(m, d);
+      if (ragged) m->plan_len = ragged_wgs(d) + 1;
       if (ragged && !packed) { q.plan = (int32_t*)m->plan_buf.p; q.plan_capp = ragged_capp(d); q.plan_n = ragged_wgs(d); }
       // (the plan reads the offsets, the masks the CSR: independent -- but as a forked branch of the captured step the two
       //  cost MORE than one after the other: 0.466 against 0.455 ms per configs[4] step, the graph's cross-branch
@@ -1724,7 +1726,7 @@ int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   int chunk, nc = 1;
   const int mr = m->L >= 1 ? merged_wg_rows(m, n_idx, n_slots) : 0;
   for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), env_int("V2X_WG_CHUNK_EMBED", 1024), 768, 896, mr > 0 ? mr : 1024})
-    nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));
+    if (rows > 0) nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));     // (a switch set to 0 = its default)
   if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 1, n_slots));     // the fewest tiles (one) split most
   else nc = std::max(nc, mlp_wg_split(n_idx, n_slots).n_slabs);         // k_mlp_train_wg: one slab per workgroup and slot
   return nc + 1;
@@ -2428,6 +2430,14 @@ int v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n) {
   HIPCHK(m, hipDeviceSynchronize());
   HIPCHK(m, hipMemcpy(out, m->ts_buf, (size_t)std::min(n, 4 * 8 * 64) * 8, hipMemcpyDeviceToHost));
   return V2X_OK;
+}
+
+int v2x_debug_ragged_plan(v2x_model* m, int32_t* out, int n) {
+  if (!m || !out || n < 0) FAIL(m, V2X_EINVAL, "null argument");
+  if (!m->plan_buf.p || m->plan_len <= 0) FAIL(m, V2X_ESTATE, "no ragged fused forward has run on this model");
+  HIPCHK(m, hipDeviceSynchronize());
+  HIPCHK(m, hipMemcpy(out, m->plan_buf.p, (size_t)std::min(n, m->plan_len) * 4, hipMemcpyDeviceToHost));
+  return m->plan_len;
 }
 
 int v2x_profile_enable(v2x_model* m, int enable) {

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("v2x_reset_exchange", C.c_int, [_P]),
     ("v2x_debug_exchange_counters", _P, [_P]),
     ("v2x_debug_phase_stamps", C.c_int, [_P, _P, C.c_int]),
+    ("v2x_debug_ragged_plan", C.c_int, [_P, _P, C.c_int]),
     ("v2x_profile_enable", C.c_int, [_P, C.c_int]),
     ("v2x_path_info", C.c_int, [_P, _P, C.c_char_p, C.c_int]),
     ("v2x_profile_read", C.c_int, [_P, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(_L), C.c_int]),

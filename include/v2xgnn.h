@@ -255,6 +255,10 @@ int  v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap);
 /* Models created with V2X_FUSED_TS=1 in the environment run a measurement build of the fused forward kernel in which
  * workgroup 7 writes 100 MHz time stamps at its phase boundaries: out[wave * 64 + mark], n <= 512 entries.            */
 int  v2x_debug_phase_stamps(v2x_model* m, int64_t* out, int n);
+/* Tests: the work plan of the last ragged fused forward (csrc/kernels_ragged.hpp) -- out[w] = first graph of workgroup w for
+ * w = 0 .. n - 1 (entries past the plan's length are left alone); returns the plan's length (launched workgroups + 1) or a
+ * negative error code.  [host] out. */
+int  v2x_debug_ragged_plan(v2x_model* m, int32_t* out, int n);
 int  v2x_profile_read(v2x_model* m, char* names_out, int names_cap, double* ms_out, int64_t* calls_out,
                       int max_entries);   /* returns number of entries, names '\n'-separated */
 

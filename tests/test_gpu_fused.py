@@ -322,3 +322,43 @@ def test_ragged_fused_layers_vs_layerwise_and_oracle(F, L, kind, sizes):
     fused.check_errors()
     fused.close()
     plain.close()
+
+
+def _greedy_plan(sizes, cap):
+    """Runs of whole graphs of <= cap rows, each as long as it can be: the fewest runs a split into runs can have."""
+    starts, rows = [0], 0
+    for g, n in enumerate(sizes):
+        if rows + n > cap:
+            starts.append(g)
+            rows = 0
+        rows += n
+    return starts + [len(sizes)]
+
+
+@pytest.mark.parametrize("sizes", [
+    list(np.random.default_rng(11).integers(8, 129, size=300)),           # the configs[4] mix
+    [128] * 40, [1] * 1000, [64] * 25 + [128] * 5 + [32] * 30,            # tiles that fill exactly, 320 one-node graphs per tile
+    [128, 1, 128, 1, 127, 66, 2] * 9, [100],
+])
+def test_ragged_plan_is_the_greedy_packing(sizes):
+    """k_ragged_plan (csrc/kernels_ragged.hpp) resolves the chain "next run starts where the previous one stops fitting" by
+    pointer doubling in one workgroup: its plan must be the sequential greedy packing exactly -- every graph once, no run over
+    320 rows, and no split into runs with fewer workgroups -- with the launch's surplus workgroups pointing past the batch."""
+    import ctypes as C
+    sizes = [int(n) for n in sizes]
+    rng = np.random.default_rng(len(sizes))
+    spec = GnnSpec(n_nodes=1, feat_dim=64, n_mp_layers=2, share_weights=True, variable_graphs=True)
+    pb, x, e, offs = _ragged_batch(rng, sizes, 'ref')
+    eng = _engine(spec, oc.params_to_list(f32_params(spec, rng)), True)
+    assert eng.path_info(pb)["graph_layers"] == "fused(ragged)"
+    eng.forward(pb)
+    buf = (C.c_int32 * 4096)()
+    n = eng._lib.v2x_debug_ragged_plan(eng._h, buf, 4096)
+    assert n > 0, eng.last_error() if hasattr(eng, "last_error") else n
+    plan = list(buf[:n])
+    want = _greedy_plan(sizes, 320)
+    assert plan[:len(want)] == want, (plan[:len(want) + 2], want)
+    assert all(v == len(sizes) for v in plan[len(want):]), plan[len(want):]
+    assert n >= len(want)                                   # the launch (row-interval count) is an upper bound of the runs
+    eng.check_errors()
+    eng.close()

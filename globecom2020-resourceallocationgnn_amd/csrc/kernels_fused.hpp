@@ -104,7 +104,7 @@ struct FusedFwdArgs {
   int edges_cap;                                     // LDS bytes reserved for the tile's edge list (16 * max_edges)
   int n_edges;                                       // E of the whole batch
   int compl_sums;                                    // (informative; the COMPL kernel instance is what runs) dense graphs: Agg(h)[q] = colsum(h) - sum over the NON-neighbours of q
-  unsigned* nbmask;                                  // compl_sums: the rows' non-neighbour masks, [R] words, for the fused backward
+  unsigned* nbmask;                                  // the rows' in-neighbour sets (complement form: NON-neighbour sets), [R] words, for the fused backward
   int frag_out;                                      // h_L and a_L fragment-major for k_mlp_train_wg (MlpArgs::frag_groups); L >= 1
   int* err;
   long long* ts;                                     // TS builds: [8 waves][64] 100 MHz time stamps of workgroup 7
@@ -312,7 +312,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
       if (r < nrows)
         for (int e = x.sRp[r]; e < x.sRp[r + 1]; ++e) nb |= 1u << x.sCol[e];
       x.sC[r] = compl_sums ? (~nb & valid) : nb;
-      if (compl_sums && a.nbmask && r < nrows) a.nbmask[r_begin + r] = ~nb & valid;
+      if (a.nbmask && r < nrows) a.nbmask[r_begin + r] = compl_sums ? (~nb & valid) : nb;    // for the backward: no CSR there
     }
     ts.mark();                                                   // (TS) masks built
   }
@@ -583,7 +583,7 @@ struct FusedBwdArgs {
   float* gha;                                        // [R][2F]
   int n_graphs, N, L, S, edges_cap, n_edges;
   int compl_sums;                                    // see FusedFwdArgs
-  const unsigned* nbmask;                            // compl_sums: non-neighbour masks left by the fused forward (FusedFwdArgs::nbmask)
+  const unsigned* nbmask;                            // in-neighbour sets (complement form: non-neighbour sets) left by the fused forward (FusedFwdArgs::nbmask)
   int frag_gha;                                      // gha fragment-major (written by k_mlp_train_wg, MlpArgs::frag_groups)
   int* err;
   long long* ts;
@@ -621,10 +621,13 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   // ---- requests in the order of their urgency: CSR slice, the dagg_L / dh_L rows of the own slots
   // (complement form: no CSR at all -- the forward left the rows' non-neighbour masks behind, one coalesced word per row
   //  instead of the chain row_ptr -> col_idx slice -> LDS -> 18 LDS atomics per row that the start of this kernel waited for)
+  //  Round 4: the edge form takes the same road -- the forward leaves the rows' in-neighbour sets there; the CSR walk with
+  //  its atomics stays for a backward that runs without such a forward (a.nbmask null).)
   if (threadIdx.x < 4) x.sFlag[threadIdx.x] = 0;                 // (before the first barrier; stages count down from L >= 1)
   FzCsrEarly csr;
   unsigned nbv = 0u;
-  if constexpr (COMPL) nbv = a.nbmask[r_begin + min((int)threadIdx.x, nrows - 1)];
+  const bool from_masks = COMPL || a.nbmask != nullptr;          // (uniform)
+  if (from_masks) nbv = a.nbmask[r_begin + min((int)threadIdx.x, nrows - 1)];
   else csr_issue(csr, a.row_ptr, a.col_idx, r_begin, nrows, x.g0, a.edges_cap, a.n_edges);
   f32x4 dg[NSA][FB];                     // dagg rows of the own slots on their way into the LDS tile
   f32x4 dhk[NSA][FB];                    // dh rows of the own slots: produced and consumed by this wave, never leave it
@@ -639,7 +642,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
       dhk[i][nt] = ldg4(a.gha + go + nt * gst);
     }
   }
-  if constexpr (COMPL) {
+  if (from_masks) {
     if ((int)threadIdx.x < FZ_TG * N) x.sRp[threadIdx.x] = (int)nbv;       // (the CSR offsets' place: unused in this form)
   } else {
     const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
@@ -677,13 +680,13 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
   fz_barrier();
   if (compl_sums) fz_reduce_sums<FB, ROWF>(x.sS, x.sT);
   // transposed adjacency: bit q of sM[j*N + p] = edge p -> q
-  if constexpr (COMPL) {                 // from the non-neighbour masks: p -> q exists iff bit p of row q's mask is clear
-    const unsigned vmask = N >= 32 ? 0xffffffffu : (1u << N) - 1u;
+  if (from_masks) {                      // from the forward's sets: p -> q exists iff bit p of row q's in-neighbour set is set
+    const unsigned vmask = N >= 32 ? 0xffffffffu : (1u << N) - 1u;     // (complement form: ... of its NON-neighbour set is clear)
     for (int r = threadIdx.x; r < nrows; r += FZ_THREADS) {
       const int jj = r / N, p = r - jj * N;
       unsigned ns = 0u;
       for (int q = 0; q < N; ++q) ns |= (((unsigned)x.sRp[jj * N + q] >> p) & 1u) << q;
-      x.sM[r] = ~ns & vmask;
+      x.sM[r] = COMPL ? (~ns & vmask) : ns;
     }
   } else {                               // integer atomics: order-independent
     for (int r = threadIdx.x; r < nrows; r += FZ_THREADS) {

@@ -1,6 +1,8 @@
-# A/B of experimental builds on one box: the shipped library against globecom2020-resourceallocationgnn_amd/libv2xgnn_exp*.so
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in 1 2; do for lib in libv2xgnn.so $(cd globecom2020-resourceallocationgnn_amd; ls libv2xgnn_exp*.so); do
-V2XGNN_LIB=$GRAFT_REPO_ROOT/globecom2020-resourceallocationgnn_amd/$lib python bench.py --no-cpu-baseline --no-edge-gather --min-seconds 1 "$@" 2>/dev/null | python -c "
+# headline A/B on one box + the fused kernels' parity tests
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_fused.py tests/test_gpu_fullsize.py tests/test_gpu_model.py tests/test_gpu_configs.py -m gpu -x -q 2>&1 | tail -4
+for i in 1 2; do
+python bench.py --no-cpu-baseline --no-dropin --no-other-workloads --min-seconds 2 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$lib', d['ms_per_step'], {k:v['avg_us'] for k,v in d['kernels'].items()})"; done; done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], 'fast', d['fast_path']['ms_per_step'], {k:v['avg_us'] for k,v in d['kernels'].items()})"
+done

@@ -650,12 +650,14 @@ def run_workload(args, ctx, light=False):
         if min_seconds > 0:
             # a timed region of a few milliseconds is at the mercy of clock ramp-up and host jitter (r01: 20 steps = 8 ms),
             # and the driver's 5-s SMI sampler has to see the GPU busy: probe the step time and extend the run
+            # (a probe of 5 steps carried the closing synchronise as a fifth of its time and made the region 12 % short)
+            n_probe = 100
             tp = time.perf_counter()
-            for _ in range(5):
+            for _ in range(n_probe):
                 step()
             torch.cuda.synchronize()
-            probe = (time.perf_counter() - tp) / 5
-            steps = max(steps, int(np.ceil(1.06 * min_seconds / max(probe, 1e-6))))     # (the probe runs a little slow: clocks still ramping)
+            probe = (time.perf_counter() - tp) / n_probe
+            steps = max(steps, int(np.ceil(1.04 * min_seconds / max(probe, 1e-6))))
             if dist is not None:
                 t = torch.tensor([steps], dtype=torch.int64, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -234,3 +234,47 @@ void v2xsim_mt_uniforms(int E, uint32_t* keys, int32_t* pos, double* out, int n_
     pos[e] = p;
   }
 }
+
+/* ---- the scalar integer draws of an episode reset, on the environments' own MT19937 states ------------------------------
+ * random.randrange / randint / sample(population, 1) of CPython 3.10 draw for draw: _randbelow_with_getrandbits(n) takes
+ * k = n.bit_length() bits (the top k of one 32-bit output) until the value is < n.                                      */
+static inline uint32_t mt_below(uint32_t* mt, int32_t* pos, uint32_t n) {
+  const int k = 32 - __builtin_clz(n);
+  uint32_t r;
+  do { r = mt_next(mt, pos) >> (32 - k); } while (r >= n);
+  return r;
+}
+/* add_new_vehicles_by_number (Environment.py:217-234) for every environment: n / 4 groups of one vehicle per direction
+ * (down = 1, up = 0, left = 2, right = 3) on a random lane index; per vehicle the position draw, then the velocity draw. */
+void v2xsim_reset_vehicles(int E, int n, uint32_t* keys, int32_t* pos, int n_lanes, const double* down, const double* up,
+                           const double* left, const double* right, int width, int height, double* xy, int8_t* dirs,
+                           double* vel) {
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < E; ++e) {
+    uint32_t* mt = keys + (int64_t)e * 624;
+    int32_t p = pos[e];
+    double* x = xy + (int64_t)e * n * 2;
+    int8_t* d = dirs + (int64_t)e * n;
+    double* v = vel + (int64_t)e * n;
+    int k = 0;
+    for (int g = 0; g < n / 4; ++g) {
+      const uint32_t ind = mt_below(mt, &p, (uint32_t)n_lanes);
+      x[2 * k] = down[ind]; x[2 * k + 1] = (double)mt_below(mt, &p, (uint32_t)height + 1); d[k] = 1; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
+      x[2 * k] = up[ind];   x[2 * k + 1] = (double)mt_below(mt, &p, (uint32_t)height + 1); d[k] = 0; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
+      x[2 * k] = (double)mt_below(mt, &p, (uint32_t)width + 1); x[2 * k + 1] = left[ind];  d[k] = 2; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
+      x[2 * k] = (double)mt_below(mt, &p, (uint32_t)width + 1); x[2 * k + 1] = right[ind]; d[k] = 3; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
+    }
+    pos[e] = p;
+  }
+}
+/* renew_neighbor's destination draw (Environment.py:375): random.sample(candidates, 1)[0] for every link -- a population
+ * of m <= 21 entries takes CPython's pool method, whose first pick is pool[_randbelow(m)].                              */
+void v2xsim_sample_dest(int E, int n, int m, uint32_t* keys, int32_t* pos, const int64_t* cand, int64_t* dest) {
+#pragma omp parallel for schedule(static)
+  for (int e = 0; e < E; ++e) {
+    uint32_t* mt = keys + (int64_t)e * 624;
+    int32_t p = pos[e];
+    for (int i = 0; i < n; ++i) dest[(int64_t)e * n + i] = cand[((int64_t)e * n + i) * m + mt_below(mt, &p, (uint32_t)m)];
+    pos[e] = p;
+  }
+}

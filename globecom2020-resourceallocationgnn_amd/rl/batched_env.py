@@ -133,41 +133,71 @@ class BatchedEnviron(object):
         self.dest = np.zeros((E, N), np.int64)
         self._v2v_shadow = np.zeros((E, N, N))
         self._v2i_shadow = np.zeros((E, N))
+        lanes = (p.down_lanes, p.up_lanes, p.left_lanes, p.right_lanes)
+        in_c = self.native and self._mt_keys is not None
         import random as _stdlib_random
         fast = _stdlib_random.Random()
+        if in_c:
+            # the scalar integer draws of a reset (5 per vehicle) on the streams' states where the library holds them: one
+            # call for all environments (the round trip stream -> stdlib generator -> stream below costs two 625-word state
+            # conversions each way per environment: 8 of a reset's 15 ms with 50 environments)
+            self.pos[:], self.dirs[:], self.vel[:] = native_sim.reset_vehicles(self._mt_keys, self._mt_pos, N, lanes, p.width, p.height)
+        if in_c and not any(st.gauss_next is not None for st in self.streams):
+            # ... and the reset's four Gaussian arrays of every environment out of ONE bulk draw: their counts are even, so the
+            # 2 (N^2 + N) gauss() values are consecutive (cos, sin) pairs of consecutive uniforms, exactly as four
+            # gauss_array calls per stream would pair them (V2V_Shadowing / V2I_Shadowing of the vehicles are drawn and never
+            # used, :232-233; then the environment's V2V / V2I shadowing)
+            n_g = 2 * (N * N + N)
+            u = native_sim.mt_uniforms(self._mt_keys, self._mt_pos, n_g)
+            x2pi = u[:, 0::2] * (2.0 * np.pi)
+            g2rad = np.sqrt(-2.0 * np.log(1.0 - u[:, 1::2]))
+            zg = np.stack([np.cos(x2pi) * g2rad, np.sin(x2pi) * g2rad], axis=2).reshape(E, n_g)
+            o = N * N + N
+            self._v2v_shadow = zg[:, o:o + N * N].reshape(E, N, N) * Environ.V2V_SHADOW_STD
+            self._v2i_shadow = zg[:, o + N * N:] * Environ.V2I_SHADOW_STD
+            gauss_done = True
+        else:
+            gauss_done = False
         with self._rng() as rs:
             for e, s in enumerate(rs):
-                # the scalar integer draws of a reset (5 per vehicle) at the stdlib generator's C speed: MTStream IS that
-                # generator draw for draw, so its state is lent out and taken back (one state copy each way per environment
-                # instead of a numpy round trip per draw: 5,000 draws per reset of 50 environments x 20 links)
-                fast.setstate(s._export())
-                k = 0
-                for _ in range(N // 4):                        # add_new_vehicles_by_number (:217-234)
-                    ind = fast.randrange(0, len(p.down_lanes))
-                    for code, lane_x, lane_y in ((1, p.down_lanes[ind], None), (0, p.up_lanes[ind], None),
-                                                 (2, None, p.left_lanes[ind]), (3, None, p.right_lanes[ind])):
-                        if lane_y is None:
-                            self.pos[e, k] = (lane_x, fast.randint(0, p.height))
-                        else:
-                            self.pos[e, k] = (fast.randint(0, p.width), lane_y)
-                        self.dirs[e, k] = code
-                        self.vel[e, k] = fast.randint(10, 15)
-                        k += 1
-                s._import(fast.getstate())
+                if gauss_done:
+                    break
+                if not in_c:
+                    # ... at the stdlib generator's C speed: MTStream IS that generator draw for draw, so its state is lent
+                    # out and taken back (one state copy each way per environment instead of a numpy round trip per draw)
+                    fast.setstate(s._export())
+                    k = 0
+                    for _ in range(N // 4):                        # add_new_vehicles_by_number (:217-234)
+                        ind = fast.randrange(0, len(p.down_lanes))
+                        for code, lane_x, lane_y in ((1, p.down_lanes[ind], None), (0, p.up_lanes[ind], None),
+                                                     (2, None, p.left_lanes[ind]), (3, None, p.right_lanes[ind])):
+                            if lane_y is None:
+                                self.pos[e, k] = (lane_x, fast.randint(0, p.height))
+                            else:
+                                self.pos[e, k] = (fast.randint(0, p.width), lane_y)
+                            self.dirs[e, k] = code
+                            self.vel[e, k] = fast.randint(10, 15)
+                            k += 1
+                    s._import(fast.getstate())
                 s.gauss_array((N, N), 3)                        # V2V_Shadowing / V2I_Shadowing: drawn, never used (:232-233)
                 s.gauss_array((N,), 8)
                 self._v2v_shadow[e] = s.gauss_array((N, N), Environ.V2V_SHADOW_STD)
                 self._v2i_shadow[e] = s.gauss_array((N,), Environ.V2I_SHADOW_STD)
         self.renew_channels_fastfading()
-        with self._rng() as rs:                                # renew_neighbor (:360-376)
-            for e, s in enumerate(rs):
-                z = self.pos[e, :, 0] + 1j * self.pos[e, :, 1]
-                order = np.argsort(np.abs(z[:, None] - z[None, :]), axis=0)          # column i: nodes by distance from i
-                cand = order[1:N - 2].T.tolist()                                     # (python ints: random.sample indexes with them)
-                fast.setstate(s._export())
-                for i in range(N):
-                    self.dest[e, i] = fast.sample(cand[i], 1)[0]
-                s._import(fast.getstate())
+        # renew_neighbor (:360-376): link i's receiver is one of its N - 3 nearest other vehicles, random.sample(..., 1)
+        z = self.pos[:, :, 0] + 1j * self.pos[:, :, 1]
+        order = np.argsort(np.abs(z[:, :, None] - z[:, None, :]), axis=1)            # [e, rank, i]: vehicles by distance from i
+        cand = np.ascontiguousarray(order[:, 1:N - 2, :].transpose(0, 2, 1))         # [e, i, N - 3]
+        if in_c and 1 <= cand.shape[2] <= 21:
+            self.dest[:] = native_sim.sample_dest(self._mt_keys, self._mt_pos, cand)
+        else:
+            with self._rng() as rs:
+                for e, s in enumerate(rs):
+                    ce = cand[e].tolist()                                            # (python ints: random.sample indexes with them)
+                    fast.setstate(s._export())
+                    for i in range(N):
+                        self.dest[e, i] = fast.sample(ce[i], 1)[0]
+                    s._import(fast.getstate())
         self.activate_links = np.ones((E, N, 1), dtype=bool)
 
     # ------------------------------------------------------------------ mobility

@@ -34,8 +34,12 @@ def _load():
     lib.v2xsim_observe.argtypes = [C.c_int, C.c_int, C.c_int, ip, dp, dp, C.c_double, dp, dp]
     lib.v2xsim_set_threads.argtypes = [C.c_int]
     lib.v2xsim_mt_uniforms.argtypes = [C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), dp, C.c_int]
+    u32p, i32p = C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+    lib.v2xsim_reset_vehicles.argtypes = [C.c_int, C.c_int, u32p, i32p, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp,
+                                          C.POINTER(C.c_int8), dp]
+    lib.v2xsim_sample_dest.argtypes = [C.c_int, C.c_int, C.c_int, u32p, i32p, ip, ip]
     for f in (lib.v2xsim_channels, lib.v2xsim_reward, lib.v2xsim_interference, lib.v2xsim_observe, lib.v2xsim_set_threads,
-              lib.v2xsim_mt_uniforms):
+              lib.v2xsim_mt_uniforms, lib.v2xsim_reset_vehicles, lib.v2xsim_sample_dest):
         f.restype = None
     _lib = lib
     return lib
@@ -116,3 +120,34 @@ def mt_uniforms(keys, pos, n_u):
     out = np.empty((E, n_u))
     lib.v2xsim_mt_uniforms(E, keys.ctypes.data_as(C.POINTER(C.c_uint32)), pos.ctypes.data_as(C.POINTER(C.c_int32)), _d(out), n_u)
     return out
+
+
+def _mt(keys, pos):
+    assert keys.dtype == np.uint32 and keys.flags.c_contiguous and pos.dtype == np.int32 and pos.flags.c_contiguous
+    return keys.ctypes.data_as(C.POINTER(C.c_uint32)), pos.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def reset_vehicles(keys, pos, n, lanes, width, height):
+    """The integer draws of add_new_vehicles_by_number for every stream (keys / pos: see mt_uniforms), in the stdlib
+    generator's order; lanes = (down, up, left, right).  -> positions [E, n, 2], directions [E, n] int8, velocities [E, n]."""
+    lib = _load()
+    E = keys.shape[0]
+    tabs = [_c(np.asarray(t, np.float64)) for t in lanes]
+    xy, dirs, vel = np.empty((E, n, 2)), np.empty((E, n), np.int8), np.empty((E, n))
+    k, p = _mt(keys, pos)
+    lib.v2xsim_reset_vehicles(E, n, k, p, len(tabs[0]), _d(tabs[0]), _d(tabs[1]), _d(tabs[2]), _d(tabs[3]), int(width), int(height),
+                              _d(xy), dirs.ctypes.data_as(C.POINTER(C.c_int8)), _d(vel))
+    return xy, dirs, vel
+
+
+def sample_dest(keys, pos, cand):
+    """random.sample(cand[e][i], 1)[0] for every environment e and link i (cand [E, n, m], m <= 21), in link order."""
+    lib = _load()
+    cand = _c(cand, np.int64)
+    E, n, m = cand.shape
+    if m > 21 or m < 1:
+        raise ValueError("sample_dest: populations of 1..21 candidates (CPython's pool method)")
+    dest = np.empty((E, n), np.int64)
+    k, p = _mt(keys, pos)
+    lib.v2xsim_sample_dest(E, n, m, k, p, _i(cand), _i(dest))
+    return dest

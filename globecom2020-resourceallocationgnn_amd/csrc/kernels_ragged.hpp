@@ -24,6 +24,7 @@
 #pragma once
 #include "kernels.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_wide.hpp"
 #include <cstddef>
 
 namespace v2x {
@@ -56,28 +57,8 @@ __global__ __launch_bounds__(RG_PLAN_THREADS) void k_ragged_plan(RaggedPlanArgs 
   int* oth = cur + B + 1;
   int* first = oth + B + 1;                                                // [W + 1]
   for (int g = tid; g <= B; g += RG_PLAN_THREADS) off[g] = a.graph_off[g];
-  for (int w = tid; w <= W; w += RG_PLAN_THREADS) first[w] = 0;
   __syncthreads();
-  for (int g = tid; g <= B; g += RG_PLAN_THREADS) {
-    // largest t in (g, min(B, g + cap)] with off[t] - off[g] <= cap; a graph that alone exceeds cap still advances by one
-    // (the kernels flag it), B is a fixed point
-    int lo = min(g + 1, B), hi = min(B, g + a.cap);
-    const int base = off[g];
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (off[mid] - base <= a.cap) lo = mid; else hi = mid - 1;
-    }
-    cur[g] = lo;
-  }
-  __syncthreads();
-  for (int b = 0; (1 << b) <= W; ++b) {
-    for (int w = tid; w <= W; w += RG_PLAN_THREADS)
-      if ((w >> b) & 1) first[w] = cur[first[w]];
-    for (int g = tid; g <= B; g += RG_PLAN_THREADS) oth[g] = cur[cur[g]];
-    __syncthreads();
-    int* t = cur; cur = oth; oth = t;
-  }
-  for (int w = tid; w <= W; w += RG_PLAN_THREADS) a.plan[w] = first[w];
+  rg_plan_tables<int, RG_PLAN_THREADS>(off, cur, oth, first, B, W, a.cap, a.plan, tid);
 }
 
 // One lane's share of a graph's column sum: rows rg, rg + RGN, ... of the tile, four loads in flight and four running sums

@@ -582,6 +582,59 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad_multi(WideWgradMulti mu) 
 // forward needs the masks by DESTINATION (bit p of adjT[q]), the transpose by source (bit q of adj[p]): k_adj_masks
 // writes both.
 constexpr int AD_COMPL_PER_ROW = 8;
+
+// Work plan of the ragged fused graph layers (kernels_ragged.hpp): runs of whole graphs of <= cap rows, each as long as it
+// can be.  plan[w] = first graph of run w, = n_graphs past the last run (w = 0 .. W).  The chain "the next run starts where
+// this one stops fitting" is resolved without walking it: nxt[g] by a bounded binary search over the offsets for all g at
+// once, then log2(W) rounds of pointer doubling, run w composing the powers named by the bits of w.  One workgroup; `off`
+// may be the offsets in LDS or in global memory, T the table entry type (unsigned short halves the tables: n_graphs < 65535).
+template <typename T, int THREADS, typename OffPtr>
+__device__ __forceinline__ void rg_plan_tables(OffPtr off, T* cur, T* oth, T* first, int B, int W, int cap, int32_t* plan, int tid) {
+  for (int w = tid; w <= W; w += THREADS) first[w] = (T)0;
+  // largest t in (g, min(B, g + cap)] with off[t] - off[g] <= cap; a graph that alone exceeds cap still advances by one (the
+  // kernels flag it), B is a fixed point.  Four searches side by side, a fixed number of halvings (the range is <= cap wide;
+  // a search that has converged keeps its answer): independent LDS round trips in flight instead of one chain after the other.
+  const int n_halvings = 32 - __builtin_clz((unsigned)max(cap, 1));
+  for (int g0 = tid; g0 <= B; g0 += 4 * THREADS) {
+    int lo[4], hi[4], base[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int g = min(g0 + u * THREADS, B);
+      lo[u] = min(g + 1, B); hi[u] = min(B, g + cap); base[u] = off[g];
+    }
+    for (int it = 0; it < n_halvings; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int mid = (lo[u] + hi[u] + 1) >> 1;
+        const bool fits = off[mid] - base[u] <= cap;
+        lo[u] = fits ? mid : lo[u];
+        hi[u] = fits ? hi[u] : max(mid - 1, lo[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (g0 + u * THREADS <= B) cur[g0 + u * THREADS] = (T)lo[u];
+  }
+  __syncthreads();
+  for (int b = 0; (1 << b) <= W; ++b) {
+    for (int w = tid; w <= W; w += THREADS)
+      if ((w >> b) & 1) first[w] = cur[first[w]];
+    for (int g0 = tid; g0 <= B; g0 += 4 * THREADS) {
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = cur[min(g0 + u * THREADS, B)];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = cur[v[u]];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (g0 + u * THREADS <= B) oth[g0 + u * THREADS] = v[u];
+    }
+    __syncthreads();
+    T* t = cur; cur = oth; oth = t;
+  }
+  for (int w = tid; w <= W; w += THREADS) plan[w] = (int32_t)first[w];
+}
+
 struct AggDenseArgs {
   const float* src; int src_stride;
   const float* add; int add_stride;
@@ -597,6 +650,9 @@ struct AggDenseArgs {
   // k_adj_masks only: the work plan of the ragged fused forward (kernels_ragged.hpp) -- plan[w] = first graph whose first row
   // is >= w * plan_capp, w = 0 .. plan_n (plan[plan_n] = n_graphs); written by one thread per graph, no search
   int32_t* plan; int plan_capp, plan_n;
+  // ... or, plan_cap > 0: the PACKED plan (rg_plan_tables) by workgroup 0 of this launch before its own graph's masks, offsets
+  // and 16-bit tables in the launch's dynamic LDS -- it runs beside the other mask workgroups
+  int plan_cap;
 };
 
 // CSR-by-destination -> per-source bit masks, one workgroup per graph (integer atomics in LDS: order-independent).
@@ -607,10 +663,20 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
   unsigned* sM = reinterpret_cast<unsigned*>(smem);                         // [rows_cap][mask_words] by source
   unsigned* sD = sM + a.rows_cap * a.mask_words;                            // [rows_cap][mask_words] by destination
   const int tid = threadIdx.x;
+  if (a.plan_cap > 0 && blockIdx.x == 0) {                                   // workgroup 0 makes the plan first (ragged batches: graph_off given)
+    int* off = reinterpret_cast<int*>(smem);                                  // (an EXTRA workgroup would be the 2049th of a launch whose
+    unsigned short* cur = reinterpret_cast<unsigned short*>(off + a.n_graphs + 1);     //  2048 fill the chip: it would start late)
+    unsigned short* oth = cur + a.n_graphs + 1;
+    unsigned short* first = oth + a.n_graphs + 1;
+    for (int g = tid; g <= a.n_graphs; g += 256) off[g] = a.graph_off[a.g_base + g];
+    __syncthreads();
+    rg_plan_tables<unsigned short, 256>(off, cur, oth, first, a.n_graphs, a.plan_n, a.plan_cap, a.plan, tid);
+    __syncthreads();                                                          // the tables' LDS becomes this workgroup's mask scratch
+  }
   const int g = a.g_base + blockIdx.x;
   const int r_begin = a.graph_off ? a.graph_off[g] : g * a.n_nodes;
   const int n = (a.graph_off ? a.graph_off[g + 1] : r_begin + a.n_nodes) - r_begin;
-  if (a.plan && tid == 0) {
+  if (a.plan && a.plan_cap == 0 && tid == 0) {
     const int prev = g > a.g_base ? (a.graph_off ? a.graph_off[g - 1] : (g - 1) * a.n_nodes) : -1;
     for (int w = prev < 0 ? 0 : prev / a.plan_capp + 1; w <= r_begin / a.plan_capp && w <= a.plan_n; ++w) a.plan[w] = g;
     if (blockIdx.x == (unsigned)a.n_graphs - 1)

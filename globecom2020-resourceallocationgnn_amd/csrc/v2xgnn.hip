@@ -86,6 +86,7 @@ struct v2x_model {
   bool compl_sums = true;                       // V2X_FUSED_COMPL (read at create): dense graphs aggregate through the complement
   bool ragged_fused = true, ragged_fused_bwd = true;   // V2X_RAGGED_FUSED / V2X_RAGGED_FUSED_BWD (read at create): kernels_ragged.hpp
   bool ragged_packed = true;    // V2X_RAGGED_PACKED: tiles packed by k_ragged_plan (0: the row-interval plan of k_adj_masks)
+  bool ragged_plan_fold = true; // V2X_RAGGED_PLAN_FOLD: the packed plan as a workgroup of the mask launch when its tables are small
   bool small_predict = true;                    // V2X_SMALL_PREDICT (read at create): few-graph forwards in one launch (kernels_small.hpp)
   unsigned long long* small_h = nullptr;        // its exchange buffer [L + 1][SMALL_ROWS][F] tagged words
   unsigned long long* small_sync = nullptr;     // and per-graph departure counters [SMALL_ROWS] (64-bit)
@@ -536,9 +537,13 @@ AggDenseArgs agg_dense_args(const DevBatch& d, Range r, int N, int F) {
   return q;
 }
 
+// bytes of the packed plan's 16-bit tables when it rides on the mask launch (AggDenseArgs::plan_cap)
+size_t plan16_bytes(int n_graphs, int n_wgs) { return (size_t)(n_graphs + 1) * 4 + ((size_t)2 * (n_graphs + 1) + n_wgs + 1) * 2 + 8; }   // offsets + two tables + starts
 int build_adj_masks(v2x_model* m, hipStream_t st, const AggDenseArgs& q) {
-  const size_t lds = (size_t)2 * q.rows_cap * q.mask_words * 4 + (size_t)(q.rows_cap + 1) * 4;   // by source + by destination + row_ptr slice
-  LAUNCH(m, "k_adj_masks", k_adj_masks, dim3(q.n_graphs), lds, st, q);
+  size_t lds = (size_t)2 * q.rows_cap * q.mask_words * 4 + (size_t)(q.rows_cap + 1) * 4;   // by source + by destination + row_ptr slice
+  int grid = q.n_graphs;
+  if (q.plan_cap > 0) lds = std::max(lds, plan16_bytes(q.n_graphs, q.plan_n));                   // workgroup 0 makes the plan first
+  LAUNCH(m, "k_adj_masks", k_adj_masks, dim3(grid), lds, st, q);
   return V2X_OK;
 }
 
@@ -1538,10 +1543,14 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
       const bool packed = ragged && ragged_packed_plan(m, d);
       if (ragged) m->plan_len = ragged_wgs(d) + 1;
       if (ragged && !packed) { q.plan = (int32_t*)m->plan_buf.p; q.plan_capp = ragged_capp(d); q.plan_n = ragged_wgs(d); }
+      // the packed plan by workgroup 0 of the mask launch while its offsets + 16-bit tables leave the mask workgroups their
+      // eight per CU (<= 19 KB of LDS: ~2,200 graphs); a launch of its own (k_ragged_plan, 32-bit tables) beyond
+      const bool folded = packed && m->ragged_plan_fold && d.B < 65000 && plan16_bytes(d.B, ragged_wgs(d)) <= 19 * 1024;
+      if (folded) { q.plan = (int32_t*)m->plan_buf.p; q.plan_cap = RG_CAP; q.plan_n = ragged_wgs(d); }
       // (the plan reads the offsets, the masks the CSR: independent -- but as a forked branch of the captured step the two
       //  cost MORE than one after the other: 0.466 against 0.455 ms per configs[4] step, the graph's cross-branch
       //  dependencies outweigh the 5 us the plan takes)
-      if (packed) {
+      if (packed && !folded) {
         static const bool once = [] { allow_big_lds((const void*)k_ragged_plan); return true; }();
         (void)once;
         RaggedPlanArgs pa{d.goff, (int32_t*)m->plan_buf.p, d.B, ragged_wgs(d), RG_CAP};
@@ -1824,6 +1833,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   m->ragged_fused = env_int("V2X_RAGGED_FUSED", 1) != 0;
   m->ragged_fused_bwd = env_int("V2X_RAGGED_FUSED_BWD", 1) != 0;
   m->ragged_packed = env_int("V2X_RAGGED_PACKED", 1) != 0;
+  m->ragged_plan_fold = env_int("V2X_RAGGED_PLAN_FOLD", 1) != 0;
   if (m->small_predict && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
     const size_t hb = (size_t)(m->L + 1) * SMALL_ROWS * m->F * sizeof(unsigned long long), sb = (size_t)2 * SMALL_ROWS * sizeof(unsigned);
     void *ph = nullptr, *ps = nullptr;

@@ -340,7 +340,8 @@ def _greedy_plan(sizes, cap):
     [128] * 40, [1] * 1000, [64] * 25 + [128] * 5 + [32] * 30,            # tiles that fill exactly, 320 one-node graphs per tile
     [128, 1, 128, 1, 127, 66, 2] * 9, [100],
 ])
-def test_ragged_plan_is_the_greedy_packing(sizes):
+@pytest.mark.parametrize("fold", [1, 0])
+def test_ragged_plan_is_the_greedy_packing(sizes, fold):
     """k_ragged_plan (csrc/kernels_ragged.hpp) resolves the chain "next run starts where the previous one stops fitting" by
     pointer doubling in one workgroup: its plan must be the sequential greedy packing exactly -- every graph once, no run over
     320 rows, and no split into runs with fewer workgroups -- with the launch's surplus workgroups pointing past the batch."""
@@ -349,7 +350,11 @@ def test_ragged_plan_is_the_greedy_packing(sizes):
     rng = np.random.default_rng(len(sizes))
     spec = GnnSpec(n_nodes=1, feat_dim=64, n_mp_layers=2, share_weights=True, variable_graphs=True)
     pb, x, e, offs = _ragged_batch(rng, sizes, 'ref')
-    eng = _engine(spec, oc.params_to_list(f32_params(spec, rng)), True)
+    os.environ["V2X_RAGGED_PLAN_FOLD"] = str(fold)        # 1: a workgroup of the mask launch (16-bit tables), 0: k_ragged_plan
+    try:
+        eng = _engine(spec, oc.params_to_list(f32_params(spec, rng)), True)
+    finally:
+        del os.environ["V2X_RAGGED_PLAN_FOLD"]
     assert eng.path_info(pb)["graph_layers"] == "fused(ragged)"
     eng.forward(pb)
     buf = (C.c_int32 * 4096)()

@@ -7,6 +7,6 @@ d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$WL $*', d['ms_p
 }
 python -m pytest tests/test_gpu_fused.py tests/test_gpu_fullsize.py tests/test_gpu_model.py tests/test_gpu_kernels.py tests/test_gpu_configs.py -m gpu -x -q -k "cfg4 or ragged or variable" 2>&1 | tail -5
 for i in 1 2; do
-WL=cfg5 run V2X_RAGGED_PLAN_FORK=0
-WL=cfg5 run V2X_RAGGED_PLAN_FORK=1
+WL=cfg5 run V2X_RAGGED_PLAN_FOLD=0
+WL=cfg5 run V2X_RAGGED_PLAN_FOLD=1
 done

@@ -258,6 +258,47 @@ def test_native_mt19937_is_the_stdlib_stream():
     assert native_sim.mt_uniforms(keys, pos, 2)[1].tolist() == [want[1].random(), want[1].random()]
 
 
+def test_native_reset_draws_are_the_stdlib_draws():
+    """v2xsim_reset_vehicles / v2xsim_sample_dest: add_new_vehicles_by_number's randrange / randint draws and renew_neighbor's
+    random.sample(candidates, 1) of CPython, draw for draw, on the environments' own MT19937 states (several reloads of the
+    624-word state inside one call; populations of 1, 5, 17 and 21 candidates)."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    seeds = (0, 12345, 2 ** 40 + 7)
+    lanes = ([1.0, 2.0, 3.0, 4.0, 5.0, 6.0], [11.0, 12.0, 13.0, 14.0, 15.0, 16.0], [21.0, 22.0, 23.0, 24.0, 25.0, 26.0],
+             [31.0, 32.0, 33.0, 34.0, 35.0, 36.0])
+    for n in (4, 20, 400):
+        keys, pos = np.empty((3, 624), np.uint32), np.zeros(3, np.int32)
+        streams = [MTStream(s) for s in seeds]
+        for e, s in enumerate(streams):
+            s.attach(keys[e], pos, e)
+        xy, dirs, vel = native_sim.reset_vehicles(keys, pos, n, lanes, 750, 1299)
+        for e, seed in enumerate(seeds):
+            r = random.Random(seed)
+            k = 0
+            for _ in range(n // 4):
+                ind = r.randrange(0, 6)
+                for code, lx, ly in ((1, lanes[0][ind], None), (0, lanes[1][ind], None), (2, None, lanes[2][ind]), (3, None, lanes[3][ind])):
+                    want = (lx, r.randint(0, 1299)) if ly is None else (r.randint(0, 750), ly)
+                    assert tuple(xy[e, k]) == want and dirs[e, k] == code and vel[e, k] == r.randint(10, 15), (n, e, k)
+                    k += 1
+            assert streams[e].random() == r.random()           # both generators stand at the same draw
+    for m in (1, 5, 17, 21):
+        keys, pos = np.empty((3, 624), np.uint32), np.zeros(3, np.int32)
+        streams = [MTStream(s) for s in seeds]
+        for e, s in enumerate(streams):
+            s.attach(keys[e], pos, e)
+        cand = np.random.default_rng(m).integers(0, 1000, size=(3, 40, m))
+        dest = native_sim.sample_dest(keys, pos, cand)
+        for e, seed in enumerate(seeds):
+            r = random.Random(seed)
+            assert dest[e].tolist() == [r.sample(cand[e, i].tolist(), 1)[0] for i in range(40)], (m, e)
+            assert streams[e].random() == r.random()
+    with pytest.raises(ValueError):
+        native_sim.sample_dest(keys, pos, np.zeros((3, 4, 22), np.int64))
+
+
 def test_device_replay_add_many_stages_what_add_stages():
     """The batched rollout stores E transitions per step with one vectorised call; the staged records (packed features,
     CSR columns, source masks, regularity flag) must be those of E single adds -- incl. an irregular graph (a link that

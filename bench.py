@@ -558,16 +558,19 @@ class Ctx(object):
 
 def make_engine(spec, ctx, args, edge_gather):
     """edge_gather: the fused graph-layer kernels run the general edge-index gather / segment sum of AggLayer.call
-    (V2X_FUSED_COMPL=0 is read when the model is created) instead of the complement rewriting."""
+    (V2X_FUSED_COMPL=0 is read when the model is created) instead of the complement rewriting.  The complement engine also
+    keeps whole-tile workgroups (V2X_FUSED_SPLIT=0): the split-tile kernels that the library picks for the shares of the
+    global batch run the edge form only."""
     from v2xgnn import GnnEngine
-    had = os.environ.get("V2X_FUSED_COMPL")
-    if edge_gather and had is None:
-        os.environ["V2X_FUSED_COMPL"] = "0"
+    key, val = ("V2X_FUSED_COMPL", "0") if edge_gather else ("V2X_FUSED_SPLIT", "0")
+    had = os.environ.get(key)
+    if had is None:
+        os.environ[key] = val
     try:
         return GnnEngine(spec, device=ctx.local, use_graph=not args.no_graph)
     finally:
-        if edge_gather and had is None:
-            del os.environ["V2X_FUSED_COMPL"]
+        if had is None:
+            del os.environ[key]
 
 
 def run_workload(args, ctx, light=False):
@@ -711,7 +714,7 @@ def run_workload(args, ctx, light=False):
 
     # ---- the fast path beside it: the same steps with the complement aggregation (when the batch qualifies)
     fast = None
-    if not explicit and not args.no_fast_path and not light and path.get("graph_layers") == "fused":
+    if not explicit and not args.no_fast_path and not light and str(path.get("graph_layers")).startswith("fused"):
         eng2 = make_engine(spec, ctx, args, edge_gather=False)
         p2 = eng2.path_info(db)
         if p2.get("aggregation") == "complement":

@@ -5,6 +5,7 @@
 #include "kernels.hpp"
 #include "kernels_wide.hpp"
 #include "kernels_fused.hpp"
+#include "kernels_fused_split.hpp"
 #include "kernels_mlpwg.hpp"
 #include "kernels_small.hpp"
 #include "kernels_ragged.hpp"
@@ -93,6 +94,11 @@ struct v2x_model {
   char* pin_h = nullptr; char* pin_d = nullptr;  // pinned, device-mapped window for host-resident few-graph predicts: the
                                                 // kernel reads the batch and writes q THROUGH it (no copy launches)
   float *pk_fwd = nullptr, *pk_bwd = nullptr;   // fragment-major copies of the GNN weights (kernels_fused.hpp)
+  // split-tile fused kernels (kernels_fused_split.hpp): K workgroups per 16-graph tile at the shares of the global batch
+  int split_env = -1;                           // V2X_FUSED_SPLIT (read at create): -1 auto, 0 / 1 off, K forced
+  unsigned long long* xchg_buf = nullptr;       // [2 L slabs][xchg_cap_tiles][N][F / 16][64][4] tagged words
+  unsigned long long* xchg_sync = nullptr;      // [xchg_cap_tiles] departures
+  int xchg_cap_tiles = 0;
   int* flag_host = nullptr;     // pinned, device-mapped word the kernels raise on a contract violation (tile guards,
   int* flag_dev = nullptr;      // k_validate_batch); read by the host after any synchronising call
   bool have_fwd = false;
@@ -240,7 +246,11 @@ void set_attrs_fused() {
   allow_big_lds((const void*)k_gnn_bwd_fused<F, 2>); allow_big_lds((const void*)k_gnn_bwd_fused<F, 2, false, true>);
   allow_big_lds((const void*)k_gnn_bwd_fused<F, 3>); allow_big_lds((const void*)k_gnn_bwd_fused<F, 3, false, true>);
   allow_big_lds((const void*)k_gnn_bwd_fused<F, 4>); allow_big_lds((const void*)k_gnn_bwd_fused<F, 4, false, true>);
+  allow_big_lds((const void*)k_gnn_fwd_split<F, 1>); allow_big_lds((const void*)k_gnn_bwd_split<F, 1>);
+  allow_big_lds((const void*)k_gnn_fwd_split<F, 2>); allow_big_lds((const void*)k_gnn_bwd_split<F, 2>);
+  allow_big_lds((const void*)k_gnn_fwd_split<F, 3>); allow_big_lds((const void*)k_gnn_bwd_split<F, 3>);
   if (F == 64) {
+    allow_big_lds((const void*)k_gnn_fwd_split<64, 2, true>); allow_big_lds((const void*)k_gnn_bwd_split<64, 2, true>);
     allow_big_lds((const void*)k_gnn_fwd_fused<64, 3, true>); allow_big_lds((const void*)k_gnn_bwd_fused<64, 3, true>);
     allow_big_lds((const void*)k_gnn_fwd_fused<64, 3, true, true>); allow_big_lds((const void*)k_gnn_bwd_fused<64, 3, true, true>);
   }
@@ -373,11 +383,20 @@ FlagWord* global_flag() {            // the per-kernel entry points that take no
 int* flag_dev_of(v2x_model* m) { return m ? m->flag_dev : global_flag()->dev; }
 
 // the one-launch predict's exchange buffer and departure counters back to their initial state (synchronous)
+size_t xchg_bytes(const v2x_model* m, int tiles) {
+  return (size_t)std::max(1, 2 * m->L) * tiles * m->N * (m->F / 16) * 256 * sizeof(unsigned long long);
+}
 int reset_exchange(v2x_model* m) {
-  if (!m->small_h) return V2X_OK;
+  if (!m->small_h && !m->xchg_buf) return V2X_OK;
   HIPCHK(m, hipDeviceSynchronize());
-  HIPCHK(m, hipMemset(m->small_h, 0, (size_t)(m->L + 1) * 256 * m->F * sizeof(unsigned long long)));     // tag 0 = never written
-  HIPCHK(m, hipMemset(m->small_sync, 0, (size_t)256 * sizeof(unsigned long long)));
+  if (m->small_h) {
+    HIPCHK(m, hipMemset(m->small_h, 0, (size_t)(m->L + 1) * 256 * m->F * sizeof(unsigned long long)));     // tag 0 = never written
+    HIPCHK(m, hipMemset(m->small_sync, 0, (size_t)256 * sizeof(unsigned long long)));
+  }
+  if (m->xchg_buf) {
+    HIPCHK(m, hipMemset(m->xchg_buf, 0, xchg_bytes(m, m->xchg_cap_tiles)));
+    HIPCHK(m, hipMemset(m->xchg_sync, 0, (size_t)m->xchg_cap_tiles * sizeof(unsigned long long)));
+  }
   return V2X_OK;
 }
 
@@ -396,6 +415,12 @@ int check_flag(v2x_model* m) {
     FAIL(m, V2X_ESTATE, "predict: the one-launch kernel timed out waiting for a neighbour's row (exchange buffer out of step: an "
                         "earlier launch was aborted?); the exchange was reset, this call's q is invalid%s",
          (v & SM_ERR_SOURCE) ? "; the batch also holds a source id outside its graph" : "");
+  }
+  if (v & FZ_ERR_XCHG) {
+    // a member of a split tile (kernels_fused_split.hpp) gave up waiting for its partners' rows: same remedy
+    if (m) reset_exchange(m);
+    FAIL(m, V2X_ESTATE, "fused graph layers: a split-tile workgroup timed out waiting for its partners' rows (exchange out of step: an "
+                        "earlier launch was aborted, or the partners were not co-resident); the exchange was reset, this call's results are invalid");
   }
   if (v & 1) FAIL(m, V2X_EINVAL, "batch: a graph has more rows / edges than max_nodes / max_edges allow (LDS tile guard); results are invalid");
   FAIL(m, V2X_EINVAL, "batch violates the layout contract:%s%s%s%s", (v >> 4) & 1 ? " graph sizes vs max_nodes / graph_off;" : "",
@@ -1323,6 +1348,44 @@ bool fused_compl(const v2x_model* m, const DevBatch& d) {
   return fused_lds(m, d, true, true) <= 160 * 1024;
 }
 
+int launch_check(v2x_model* m, const char* kname) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) FAIL(m, V2X_EHIP, "launch %s failed: %s", kname, hipGetErrorString(e));
+  return V2X_OK;
+}
+
+// Split tiles (kernels_fused_split.hpp): K workgroups per 16-graph tile when whole-tile workgroups would leave most of the
+// chip idle (the shares of the metric's global batch).  All K x tiles workgroups must be co-resident (one per CU: their LDS
+// tile admits no second one), and a member should keep at least four slots (below that the hand-overs cost more than the
+// node updates they spread).  Edge form only.
+int fused_split(const v2x_model* m, const DevBatch& d) {
+  if (m->split_env == 0 || m->split_env == 1 || !fused_path(m, d) || m->L < 1 || m->L > 3) return 1;
+  if (fused_lds(m, d, true) + (size_t)m->N * m->F * 4 > 160 * 1024) return 1;      // + the embed biases of all slots (forward)
+  const int tiles = (d.B + FZ_TG - 1) / FZ_TG;
+  auto fits = [&](int k) { return (m->N + k - 1) / k <= FZ_WAVES && tiles * k <= n_cus(); };      // one slot per wave, all co-resident
+  if (m->split_env > 1) return (2 * m->split_env <= m->N && fits(m->split_env)) ? m->split_env : 1;
+  for (int k : {5, 4, 3, 2})
+    if (4 * k <= m->N && fits(k)) return k;
+  return 1;
+}
+int ensure_xchg(v2x_model* m, int tiles) {
+  if (tiles <= m->xchg_cap_tiles) return V2X_OK;
+  if (m->capturing) FAIL(m, V2X_ESTATE, "exchange buffer growth during graph capture");
+  drop_graphs(m);
+  HIPCHK(m, hipDeviceSynchronize());
+  if (m->xchg_buf) HIPCHK(m, hipFree(m->xchg_buf));
+  if (m->xchg_sync) HIPCHK(m, hipFree(m->xchg_sync));
+  m->xchg_buf = nullptr; m->xchg_sync = nullptr; m->xchg_cap_tiles = 0;
+  HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->xchg_buf), xchg_bytes(m, tiles)));
+  HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->xchg_sync), (size_t)tiles * sizeof(unsigned long long)));
+  HIPCHK(m, hipMemset(m->xchg_buf, 0, xchg_bytes(m, tiles)));                 // tag 0 = never written
+  HIPCHK(m, hipMemset(m->xchg_sync, 0, (size_t)tiles * sizeof(unsigned long long)));
+  HIPCHK(m, hipDeviceSynchronize());
+  m->xchg_cap_tiles = tiles;
+  return V2X_OK;
+}
+FzXchg xchg_args(const v2x_model* m, int K) { return FzXchg{m->xchg_buf, m->xchg_sync, m->xchg_cap_tiles, K}; }
+
 int launch_pack(v2x_model* m, hipStream_t st) {
   PackArgs p;
   memset(&p, 0, sizeof(p));
@@ -1363,6 +1426,7 @@ bool frag_layout(const v2x_model* m, const DevBatch& d, Range r) {
 }
 
 int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_out = false) {
+  static const int split_fwd = env_int("V2X_FUSED_SPLIT_FWD", 1);
   // The copy follows the parameters by itself: Adam writes both (k_reduce_adam / pack_scatter), set / copy_weights
   // re-pack eagerly.  Only a caller that took the raw parameter pointer (v2x_param_ptr) forces a re-pack per forward.
   if (m->pk_stale) { CHK(launch_pack(m, st)); m->pk_stale = m->raw_params; }
@@ -1373,7 +1437,28 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   a.frag_out = frag_out ? 1 : 0;
   a.nbmask = m->nbmask;
-  const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
+  const int tiles = (d.B + FZ_TG - 1) / FZ_TG;
+  if (const int K = fused_split(m, d); K > 1 && split_fwd) {            // the shares of the global batch: K workgroups per tile
+    CHK(ensure_xchg(m, tiles));
+    const FzXchg xg = xchg_args(m, K);
+    a.ts = m->ts_buf;
+    const dim3 grid((tiles + 7) / 8 * 8 * K);
+    const size_t lds = fused_lds(m, d, false, false) + (size_t)m->N * m->F * 4;
+    ProfRec r;
+    const bool pr = m->prof && !m->capturing;
+    if (pr) { r.id = prof_id(m, "k_gnn_fwd_fused"); hipEventCreate(&r.ev0); hipEventCreate(&r.ev1); hipEventRecord(r.ev0, st); }
+    int rc = V2X_EINVAL;
+    do {
+      if (m->ts_buf && m->F == 64 && m->L == 2) { hipLaunchKernelGGL((k_gnn_fwd_split<64, 2, true>), grid, dim3(FZ_THREADS), lds, st, a, xg); rc = launch_check(m, "k_gnn_fwd_split"); break; }
+#define V2X_FZ_FWDS(FF, LL) if (m->F == FF && m->L == LL) { hipLaunchKernelGGL((k_gnn_fwd_split<FF, LL>), grid, dim3(FZ_THREADS), lds, st, a, xg); rc = launch_check(m, "k_gnn_fwd_split"); break; }
+      V2X_FZ_FWDS(16, 1) V2X_FZ_FWDS(16, 2) V2X_FZ_FWDS(16, 3) V2X_FZ_FWDS(32, 1) V2X_FZ_FWDS(32, 2) V2X_FZ_FWDS(32, 3) V2X_FZ_FWDS(64, 1) V2X_FZ_FWDS(64, 2) V2X_FZ_FWDS(64, 3)
+#undef V2X_FZ_FWDS
+    } while (0);
+    if (pr) { hipEventRecord(r.ev1, st); m->prof_recs.push_back(r); }
+    if (rc == V2X_EINVAL && m->err.empty()) FAIL(m, V2X_EINVAL, "split fused forward: unsupported shape");
+    return rc;
+  }
+  const dim3 grid(tiles);
   a.compl_sums = fused_compl(m, d) ? 1 : 0;
   const size_t lds = fused_lds(m, d, false, a.compl_sums != 0);
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
@@ -1395,6 +1480,8 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_
 }
 
 int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
+  static const int split_bwd = env_int("V2X_FUSED_SPLIT_BWD", 1), split_fwd_only = 0;
+  (void)split_fwd_only;
   FusedBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_bwd; a.gha = m->gha;
@@ -1403,7 +1490,28 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   a.n_graphs = d.B; a.N = m->N; a.L = m->L; a.S = m->S; a.edges_cap = FZ_TG * d.max_edges; a.n_edges = d.E; a.err = m->flag_dev;
   a.frag_gha = m->frag_live ? 1 : 0;
   a.nbmask = m->nbmask;
-  const dim3 grid((d.B + FZ_TG - 1) / FZ_TG);
+  const int tiles = (d.B + FZ_TG - 1) / FZ_TG;
+  if (const int K = fused_split(m, d); K > 1 && split_bwd) {
+    CHK(ensure_xchg(m, tiles));
+    const FzXchg xg = xchg_args(m, K);
+    a.ts = m->ts_buf;
+    const dim3 grid((tiles + 7) / 8 * 8 * K);
+    const size_t lds = fused_lds(m, d, true, false);
+    ProfRec r;
+    const bool pr = m->prof && !m->capturing;
+    if (pr) { r.id = prof_id(m, "k_gnn_bwd_fused"); hipEventCreate(&r.ev0); hipEventCreate(&r.ev1); hipEventRecord(r.ev0, st); }
+    int rc = V2X_EINVAL;
+    do {
+      if (m->ts_buf && m->F == 64 && m->L == 2) { hipLaunchKernelGGL((k_gnn_bwd_split<64, 2, true>), grid, dim3(FZ_THREADS), lds, st, a, xg); rc = launch_check(m, "k_gnn_bwd_split"); break; }
+#define V2X_FZ_BWDS(FF, LL) if (m->F == FF && m->L == LL) { hipLaunchKernelGGL((k_gnn_bwd_split<FF, LL>), grid, dim3(FZ_THREADS), lds, st, a, xg); rc = launch_check(m, "k_gnn_bwd_split"); break; }
+      V2X_FZ_BWDS(16, 1) V2X_FZ_BWDS(16, 2) V2X_FZ_BWDS(16, 3) V2X_FZ_BWDS(32, 1) V2X_FZ_BWDS(32, 2) V2X_FZ_BWDS(32, 3) V2X_FZ_BWDS(64, 1) V2X_FZ_BWDS(64, 2) V2X_FZ_BWDS(64, 3)
+#undef V2X_FZ_BWDS
+    } while (0);
+    if (pr) { hipEventRecord(r.ev1, st); m->prof_recs.push_back(r); }
+    if (rc == V2X_EINVAL && m->err.empty()) FAIL(m, V2X_EINVAL, "split fused backward: unsupported shape");
+    return rc;
+  }
+  const dim3 grid(tiles);
   a.compl_sums = fused_compl(m, d) ? 1 : 0;
   const size_t lds = fused_lds(m, d, true, a.compl_sums != 0);
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
@@ -1745,6 +1853,7 @@ int presize(v2x_model* m, const DevBatch& d) {
   CHK(ensure_rows(m, d.R));
   if (need_adj_masks(m, d)) CHK(ensure(m, m->adj_mask, (size_t)2 * d.R * ((d.max_nodes + 31) / 32) * 4));
   if (ragged_fused_path(m, d)) CHK(ensure(m, m->plan_buf, (size_t)(ragged_wgs(d) + 2) * 4));
+  if (fused_split(m, d) > 1) CHK(ensure_xchg(m, (d.B + FZ_TG - 1) / FZ_TG));
   const IdxMap x = idx_map(m, d, Range{0, d.B});
   CHK(ensure_slabs(m, max_slabs(m, x.n_idx, x.grid_y)));
   return V2X_OK;
@@ -1830,6 +1939,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   // the two paths agree bitwise
   m->compl_sums = env_int("V2X_FUSED_COMPL", 1) != 0;
   m->small_predict = env_int("V2X_SMALL_PREDICT", 1) != 0;
+  m->split_env = env_int("V2X_FUSED_SPLIT", -1);
   m->ragged_fused = env_int("V2X_RAGGED_FUSED", 1) != 0;
   m->ragged_fused_bwd = env_int("V2X_RAGGED_FUSED_BWD", 1) != 0;
   m->ragged_packed = env_int("V2X_RAGGED_PACKED", 1) != 0;
@@ -1898,6 +2008,8 @@ void v2x_destroy(v2x_model* m) {
   if (m->flag_host) hipHostFree(m->flag_host);
   if (m->ts_buf) hipFree(m->ts_buf);
   if (m->small_h) hipFree(m->small_h);
+  if (m->xchg_buf) hipFree(m->xchg_buf);
+  if (m->xchg_sync) hipFree(m->xchg_sync);
   if (m->small_sync) hipFree(m->small_sync);
   if (m->pin_h) hipHostFree(m->pin_h);
   delete m;
@@ -2425,10 +2537,13 @@ int v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap) {
   d.B = b->n_graphs; d.R = b->n_rows; d.E = b->n_edges; d.max_nodes = b->max_nodes; d.max_edges = b->max_edges;
   d.goff = b->graph_off; d.nbr = b->nbr_init;
   const bool fused = fused_path(m, d);
-  const char* agg = fused ? (fused_compl(m, d) ? "complement" : "edge-gather")
+  const int split = fused_split(m, d);
+  const char* agg = fused ? (split <= 1 && fused_compl(m, d) ? "complement" : "edge-gather")
                           : (use_dense_agg(d, m->F) ? "dense(complement-or-mfma-per-graph)" : "edge-gather");
-  snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s",
-           fused ? "fused" : (ragged_fused_path(m, d) ? "fused(ragged)" : "layerwise"), agg,
+  char gl[48];
+  if (fused && split > 1) snprintf(gl, sizeof(gl), "fused(split%d)", split);
+  else snprintf(gl, sizeof(gl), "%s", fused ? "fused" : (ragged_fused_path(m, d) ? "fused(ragged)" : "layerwise"));
+  snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s", gl, agg,
            mlp_wg_path(m) ? "train_wg" : (mlp_fused_training(m) ? "train" : "fwd+bwd"),
            frag_layout(m, d, Range{0, d.B}) ? "fragment-major" : "row-major");
   return V2X_OK;

@@ -104,6 +104,27 @@ def test_cfg2_full_size_vs_oracle(shared, aggregation):
                         "configs[1] B=4096 %s, %s" % ("shared" if shared else "per-node", aggregation), engine=eng)
 
 
+@pytest.mark.parametrize("share,variant", [(512, "fused(split5)"), (1024, "fused(split4)"), (2048, "fused")])
+def test_cfg2_shares_vs_oracle(share, variant):
+    """The per-GPU shares of BASELINE configs[1]'s global batch of 4096 at 8 / 4 / 2 GPUs: the 512- and
+    1024-graph shares run the split-tile fused graph layers (5 / 4 workgroups per 16-graph tile, stage rows handed over as
+    tagged words, csrc/kernels_fused_split.hpp), the 2048-graph share whole-tile workgroups.  Forward, per-output Huber
+    loss (mean over the GLOBAL batch is the caller's n_global; here the share's own), every gradient array and the weights
+    after one Keras-Adam step against the float64 oracle."""
+    import bench
+    rng = np.random.default_rng(3000 + share)
+    x, e, adj, _ = bench.synth_batch(rng, share, N)
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    P = f32_params(spec, rng)
+    pb = PackedBatch.from_dense(x, e, adj)
+    graph = ((np.arange(share + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
+    eng = _training_engine(spec, edge_gather=True)
+    info = eng.path_info(pb)
+    assert info["graph_layers"] == variant and info["aggregation"] == "edge-gather", info
+    _parity_with_oracle(spec, P, pb, x.reshape(share * N, -1), e.reshape(share * N, -1), graph,
+                        "configs[1] share of %d graphs, %s" % (share, variant), engine=eng)
+
+
 def test_cfg3_share_vs_oracle():
     """The per-GPU share of BASELINE configs[3]: 1024 graphs x 100 links x 256 features x 3 layers (wide-feature path:
     tiled MFMA GEMMs, MFMA aggregation of dense graphs, in-place weight gradients)."""

@@ -14,10 +14,14 @@ from oracle import compact as oc
 pytestmark = pytest.mark.gpu
 
 
-def _engine(spec, weights, fused, compl=False, **kw):
+def _engine(spec, weights, fused, compl=False, split=None, **kw):
     """compl: let dense graphs aggregate through the complement (column sum minus the non-neighbours' rows; the default
-    of the library) -- same values up to rounding, so the bitwise comparisons below switch it off."""
+    of the library) -- same values up to rounding, so the bitwise comparisons below switch it off.
+    split: V2X_FUSED_SPLIT (None = the library's choice: K workgroups per 16-graph tile for batches that leave most of the
+    chip idle, csrc/kernels_fused_split.hpp; 0 = whole-tile workgroups; K = forced)."""
     env = {"V2X_FUSED": "1" if fused else "0", "V2X_FUSED_COMPL": "1" if compl else "0"}     # read by v2x_create
+    if split is not None:
+        env["V2X_FUSED_SPLIT"] = str(split)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -89,7 +93,7 @@ def test_complement_aggregation_matches_layerwise_and_oracle(N, F, L, B, share, 
     x, e, adj = random_inputs(rng, B, N, ref_topology=ref_topo, density=0.4)
     y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
     pb = PackedBatch.from_dense(x, e, adj)
-    fused, plain = _engine(spec, weights, True, compl=True), _engine(spec, weights, False)
+    fused, plain = _engine(spec, weights, True, compl=True, split=0), _engine(spec, weights, False)     # (split tiles: edge form only)
     qf, qp = fused.forward(pb), plain.forward(pb)
     lf, lp = fused.forward_backward(pb, y), plain.forward_backward(pb, y)
     gf, gp = fused.get_grad_flat(), plain.get_grad_flat()
@@ -114,6 +118,75 @@ def test_complement_aggregation_matches_layerwise_and_oracle(N, F, L, B, share, 
         assert_grad_close(a_, b_, "complement gradient array %d vs oracle" % i)
     fused.close()
     plain.close()
+
+
+SPLIT_CASES = [  # N, F, L, B, share, reference topology, K
+    (16, 64, 2, 33, False, True, 2),      # 8 slots per member: every wave owns one
+    (20, 64, 2, 33, False, True, 4),      # the 1024-graph share's form: 5 slots per member
+    (20, 64, 2, 48, False, True, 5),      # the 512-graph share's form: 4 slots per member
+    (20, 64, 2, 130, True, True, 4),      # shared weights, 9 tiles (more than one tile per XCD column)
+    (20, 64, 3, 20, False, False, 3),     # K does not divide N (members with 7 and 6 slots), random topologies, 3 layers
+    (12, 32, 2, 40, False, False, 2),
+    (8, 16, 1, 17, False, True, 4),       # two slots per member, one layer
+    (24, 64, 1, 20, False, True, 4),
+]
+
+
+@pytest.mark.parametrize("N,F,L,B,share,ref_topo,K", SPLIT_CASES)
+def test_split_tiles_equal_whole_tiles_bitwise(N, F, L, B, share, ref_topo, K):
+    """K workgroups per 16-graph tile with tagged-word hand-overs of the stage rows (kernels_fused_split.hpp) against the
+    whole-tile kernels and the layer-by-layer kernels: same arithmetic order, bitwise the same q, losses, gradients and
+    weights -- eager and replayed, over several steps (the epoch of the exchange advances with every launch)."""
+    spec = GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L, share_weights=share)
+    rng = np.random.default_rng(900 + N + F + B + K)
+    P = f32_params(spec, rng)
+    weights = oc.params_to_list(P)
+    x, e, adj = random_inputs(rng, B, N, ref_topology=ref_topo, density=0.4)
+    y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+    pb = PackedBatch.from_dense(x, e, adj)
+    split, whole, plain = _engine(spec, weights, True, split=K), _engine(spec, weights, True, split=0), _engine(spec, weights, False)
+    assert split.path_info(pb)["graph_layers"] == "fused(split%d)" % K, split.path_info(pb)
+    assert whole.path_info(pb)["graph_layers"] == "fused", whole.path_info(pb)
+    qs, qw, qp = split.forward(pb), whole.forward(pb), plain.forward(pb)
+    assert np.array_equal(qs, qw) and np.array_equal(qs, qp), "split forward differs: max %g" % np.abs(qs - qw).max()
+    ls, lw = split.forward_backward(pb, y), whole.forward_backward(pb, y)
+    gs, gw = split.get_grad_flat(), whole.get_grad_flat()
+    assert np.array_equal(ls, lw)
+    assert np.array_equal(gs, gw), "split gradient differs: max %g" % np.abs(gs - gw).max()
+    for _ in range(5):
+        split.train_step(pb, y)
+        whole.train_step(pb, y)
+    assert np.array_equal(split.get_flat(), whole.get_flat())
+    assert np.array_equal(split.forward(pb), whole.forward(pb))
+    split.close(); whole.close(); plain.close()
+
+
+def test_split_tiles_hipgraph_replay_and_mixed_batch_sizes():
+    """The exchange's epoch lives in device memory (departure counters), so a replayed graph -- frozen kernel arguments --
+    keeps working; batches of different sizes share the buffer (tiles are addressed by capacity, not by batch)."""
+    import torch
+    N, F = 20, 64
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(17)
+    weights = oc.params_to_list(f32_params(spec, rng))
+    eager = _engine(spec, weights, True, split=0)
+    graph = _engine(spec, weights, True, use_graph=True)            # the library's choice: split at these sizes
+    batches = []
+    for B in (48, 130, 16, 48):
+        x, e, adj = random_inputs(rng, B, N)
+        batches.append((PackedBatch.from_dense(x, e, adj), rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)))
+    assert "split" in graph.path_info(batches[0][0])["graph_layers"]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for pb, y in batches:
+            db, yd = graph.to_device(pb), torch.from_numpy(y).cuda()
+            for _ in range(3):
+                graph.train_step(db, yd)
+        torch.cuda.synchronize()
+    for pb, y in batches:
+        for _ in range(3):
+            eager.train_step(pb, y)
+    assert np.array_equal(eager.get_flat(), graph.get_flat())
+    eager.close(); graph.close()
 
 
 def test_fused_hipgraph_replay_is_bitwise_eager():

@@ -197,7 +197,7 @@ def test_small_predict_out_of_step_exchange_times_out_instead_of_hanging():
     x, e, adj = random_inputs(rng, B, N, ref_topology=True)
     pb = PackedBatch.from_dense(x, e, adj)
     q0 = eng.forward(pb)
-    assert eng.path_info(pb)["graph_layers"] == "fused"
+    assert eng.path_info(pb)["graph_layers"].startswith("fused")
     cnt = _exchange_counters(eng, 256)
     torch.cuda.synchronize()
     assert int(cnt[0].item()) == N and int(cnt[B - 1].item()) == N and int(cnt[B].item()) == 0     # one launch: N departures per graph

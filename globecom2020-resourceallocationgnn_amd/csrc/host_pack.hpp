@@ -65,7 +65,10 @@ inline int scan_graph(const T* A, int N, int F, bool check, const typename Bits<
       for (int q = 0; q < N; ++q) {
         const U* blk = r + (long)q * F;
         for (int j = 0; j < F; ++j) acc |= blk[j] & mi[j];
-        diff |= blk[i] ^ r0[(long)q * F];             // the block's diagonal is constant: Adj[p][q] for every i
+        // the block's diagonal is constant: Adj[p][q] for every i -- compared as VALUES (numpy's ==): +0.0 and -0.0 are equal
+        // (their patterns differ in the sign bit only), anything non-zero must match bit for bit
+        const U xr = blk[i] ^ r0[(long)q * F];
+        diff |= (U)(xr << 1) | ((U)(blk[i] << 1) != 0 ? xr : (U)0);
       }
       bad |= (U)(acc << 1) | diff;                    // +-0 off the diagonals; NaN or anything else is a violation
     }

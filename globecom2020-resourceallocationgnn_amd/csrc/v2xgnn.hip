@@ -1348,6 +1348,9 @@ bool fused_compl(const v2x_model* m, const DevBatch& d) {
   return fused_lds(m, d, true, true) <= 160 * 1024;
 }
 
+__global__ void k_set4(float* dst, float a, float b, float c, float d) {
+  if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+}
 int launch_check(v2x_model* m, const char* kname) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) FAIL(m, V2X_EHIP, "launch %s failed: %s", kname, hipGetErrorString(e));
@@ -2135,11 +2138,12 @@ static int fwd_bwd(v2x_model* m, const v2x_batch* b, const float* y, int y_on_de
   if (with_adam) {
     // lr_t depends on the iteration count, so the Adam node stays outside the replayed graph.  Wide path: Adam rides on the
     // weight-gradient launch for the layers that launch writes in place; this step's lr_t reaches the (replayed) kernels
-    // through device memory (the copy from a pageable host variable is staged by the runtime before it returns)
+    // through device memory, written by a one-thread launch whose ARGUMENTS carry the values (copied when the launch is
+    // enqueued: no asynchronous read of host stack memory, no host / stream synchronisation -- ADVICE r04)
     const bool fuse = wide_adam_fusable(m, d);
     if (fuse) {
-      const float sc[4] = {adam_lr_t(m, m->iterations + 1), m->cfg.beta1, m->cfg.beta2, m->cfg.eps};
-      HIPCHK(m, hipMemcpyAsync(m->adam_scal, sc, sizeof(sc), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_set4, dim3(1), dim3(64), 0, st, m->adam_scal, adam_lr_t(m, m->iterations + 1), m->cfg.beta1, m->cfg.beta2, m->cfg.eps);
+      CHK(launch_check(m, "k_set4"));
     }
     m->fuse_adam_now = fuse;
     const int rc = run_maybe_graph(m, st, make_key(fuse ? 9 : 2, d, yd, n_global), [&]() { return run_step(m, st, d, true, yd, n_global); });

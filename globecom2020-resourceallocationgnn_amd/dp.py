@@ -110,6 +110,16 @@ class DataParallelTrainer(object):
         reduce_now = self.world > 1 or self.force
         if reduce_now and self._overlapped(local_batch):
             return self._train_step_phased(local_batch, local_y, n_graphs_global, want_loss)
+        if reduce_now and self.shard_optimizer:
+            # The phases are not available for this batch (a host-resident batch, a backend without them), but the optimizer
+            # state is SHARDED: after any sharded step a rank holds current Adam moments for its own slices only, so a step
+            # that ran full-range Adam on every rank would apply different moments on different ranks and the replicas
+            # would part without an error.  Stay sharded: whole backward first, then the same per-bucket
+            # reduce-scatter / Adam-on-the-slice / all-gather.
+            if not hasattr(self.backend, "apply_gradients_range") or not hasattr(self.backend, "grad_buckets"):
+                raise RuntimeError("shard_optimizer: the backend has neither phases nor apply_gradients_range; a full-range Adam "
+                                   "step would desynchronise the sharded optimizer state")
+            return self._train_step_phased(local_batch, local_y, n_graphs_global, want_loss, phased=False)
         loss = self.backend.forward_backward(local_batch, local_y, n_global=n_graphs_global, want_loss=want_loss)
         if reduce_now:
             if self._grad is None:
@@ -131,7 +141,9 @@ class DataParallelTrainer(object):
         self.dist.all_reduce(loss, op=self.dist.ReduceOp.SUM, group=self.group)
         return loss
 
-    def _train_step_phased(self, local_batch, local_y, n_global, want_loss):
+    def _train_step_phased(self, local_batch, local_y, n_global, want_loss, phased=True):
+        """phased=False: the backend's unsplit forward + backward first, then the bucket collectives (nothing overlaps; the
+        optimizer step is the sharded one all the same)."""
         if self._grad is None:
             self._grad = self.backend.grad_tensor()
         if self._buckets is None:
@@ -141,8 +153,11 @@ class DataParallelTrainer(object):
                 self._param = self.backend.param_tensor()
         nb = len(self._buckets)
         works, loss = [], None
+        if not phased:
+            loss = self.backend.forward_backward(local_batch, local_y, n_global=n_global, want_loss=want_loss)
         for k in range(nb):
-            loss = self.backend.forward_backward_phase(local_batch, local_y, k, n_global=n_global, want_loss=want_loss)
+            if phased:
+                loss = self.backend.forward_backward_phase(local_batch, local_y, k, n_global=n_global, want_loss=want_loss)
             sl = self._slice_of(self._bucket_ranges[k][1]) if self.shard_optimizer else None
             if sl is not None:
                 works.append((self._reduce_scatter(self._buckets[k], sl[0], sl[1]), sl))

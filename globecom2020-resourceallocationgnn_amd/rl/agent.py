@@ -403,12 +403,21 @@ class Agent(object):
         self.num_Episodes, self.num_Train_Step = num_episodes, num_train_steps
         # Everything alive now (the imported frameworks, the engines, the simulator) goes to the collector's permanent
         # generation: a full collection inside a train step walked ~1e6 such objects -- 40-70 ms, once or twice per hundred
-        # steps of a 3 ms loop (measured, tools/prof_rl_sections.py).  Nothing is leaked: frozen objects are still freed by
-        # reference counting; V2X_RL_GC_FREEZE=0 leaves the collector alone.
-        if os.environ.get("V2X_RL_GC_FREEZE", "1") != "0":
+        # steps of a 3 ms loop (measured, tools/prof_rl_sections.py).  The freeze is a process-wide change of the collector, so it
+        # ends with this call (gc.unfreeze in the finally below: cycles among the frozen objects become collectable again, and
+        # repeated train() calls do not pile up frozen generations -- ADVICE r04); V2X_RL_GC_FREEZE=0 leaves the collector alone.
+        frozen = os.environ.get("V2X_RL_GC_FREEZE", "1") != "0"
+        if frozen:
             import gc
             gc.collect()
             gc.freeze()
+        try:
+            return self._train_loop(num_episodes, num_train_steps, save_dir, save_interval, verbose)
+        finally:
+            if frozen:
+                gc.unfreeze()
+
+    def _train_loop(self, num_episodes, num_train_steps, save_dir, save_interval, verbose):
         n = self.num_D2D
         world = self._shard_world()
         self.num_transition = -(-50 // world)          # sharded rollouts: this rank's share of the 50 transitions per step
@@ -428,15 +437,14 @@ class Agent(object):
             pending = []
             for it in range(num_train_steps):
                 reward_step[ep, it, :] = self.generate_d2d_transition(self.num_transition)
-                if defer:
-                    out = self._replay_on_device(defer=True)
-                    if len(out) == 2:
-                        pending.append(out)
-                    else:
-                        result, qm, qx, _, _ = out
-                        defer = False
-                if not defer:
-                    result, qm, qx, _, _ = self.replay()
+                out = self._replay_on_device(defer=True) if defer else self.replay()
+                if defer and len(out) == 2:
+                    pending.append(out)
+                else:
+                    # (a device replay that came back with host-side results -- no device tensors to defer -- IS this step's
+                    #  replay: use it, do not run a second one; later steps go through replay() directly)
+                    result, qm, qx, _, _ = out
+                    defer = False
                     for k in range(n):
                         loss[k, ep, it] = result.history['D%d_Decide_Output_loss' % (k + 1)][0]
                     q_mean[:, ep, it], q_max[:, ep, it] = qm, qx

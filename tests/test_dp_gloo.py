@@ -143,10 +143,13 @@ def _worker_buckets(rank, world, port, ret, mode):
     try:
         spec, P, pb, y = _wide_data()
         eng = OracleBackend(spec, P)
-        tr = DataParallelTrainer(eng, overlap=(mode == "overlap"), shard_optimizer=(mode == "shard"))
+        tr = DataParallelTrainer(eng, overlap=(mode == "overlap"), shard_optimizer=mode.startswith("shard"))
         sb, sy = tr.shard(pb, y)
         losses, grads = [], []
-        for _ in range(3):
+        for i in range(3):
+            # "shard_fallback": in the middle step the backend's phases are not available for the batch (what a host-resident
+            # batch is to the GPU engine): the trainer must keep the optimizer step sharded, not run full-range Adam
+            eng.phases_on_host = not (mode == "shard_fallback" and i == 1)
             losses.append(np.asarray(tr.train_step(sb, sy, n_graphs_global=pb.n_graphs)))
             grads.append(eng.grad_tensor().numpy().copy())
         flat = np.concatenate([a.ravel() for a in oc.param_arrays(eng.params)])
@@ -172,7 +175,7 @@ def test_two_rank_bucketed_and_sharded_steps_equal_the_single_all_reduce():
     (reduce-scatter, Adam on the rank's half of every bucket, all-gather of the parameters), against the one-all-reduce step
     and the single-process step.  The oracle backend poisons (NaN) every bucket it has not released yet, so a collective
     started before its phase would show.  Gradients must be BIT-identical to the single all-reduce's (same two-rank sum)."""
-    plain, over, shard = _run_buckets("plain"), _run_buckets("overlap"), _run_buckets("shard")
+    plain, over, shard, shard_fb = _run_buckets("plain"), _run_buckets("overlap"), _run_buckets("shard"), _run_buckets("shard_fallback")
     spec, P, pb, y = _wide_data()
     single = OracleBackend(spec, P)
     ref_losses = []
@@ -185,7 +188,7 @@ def test_two_rank_bucketed_and_sharded_steps_equal_the_single_all_reduce():
     assert len(buckets) == spec.n_mp_layers + 2 and sum(n for _, n in buckets) == single.n_params
     assert buckets[0][0] > buckets[1][0] > buckets[2][0] > buckets[3][0] == 0
     for r in range(2):
-        for run in (plain, over, shard):
+        for run in (plain, over, shard, shard_fb):
             flat, losses = run[r][0], run[r][1]
             assert np.all(np.isfinite(flat))
             assert np.abs(flat - ref).max() < 1e-12
@@ -195,4 +198,8 @@ def test_two_rank_bucketed_and_sharded_steps_equal_the_single_all_reduce():
         assert np.array_equal(shard[r][0], plain[r][0])                 # sharded Adam + all-gather: the same weights
         m, v, it = shard[r][3], shard[r][4], shard[r][5]
         assert it == it_ref == 3 and np.abs(m - m_ref).max() < 1e-12 and np.abs(v - v_ref).max() < 1e-14
+        # a step without the phases in between two sharded ones: still the sharded optimizer step -- same weights,
+        # same gathered moments; a full-range Adam there would have used stale moments outside the rank's slices
+        assert np.array_equal(shard_fb[r][0], plain[r][0])
+        assert shard_fb[r][5] == 3 and np.abs(shard_fb[r][3] - m_ref).max() < 1e-12 and np.abs(shard_fb[r][4] - v_ref).max() < 1e-14
     assert np.array_equal(shard[0][0], shard[1][0])                     # replicas bit-identical after the all-gather

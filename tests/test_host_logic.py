@@ -375,6 +375,20 @@ def test_native_packer_rejects_what_the_numpy_definition_rejects():
     # a negative zero off the diagonals IS kron(Adj, I_F) (numpy: -0.0 == 0)
     ok = bad_adj(lambda A: A.__setitem__((3, 0, 5), -0.0))
     assert np.array_equal(feed_to_packed(spec, ok, True).col_idx, feed_to_packed(spec, feed, True).col_idx)
+    # ... and so is a negative zero ON a block's diagonal where the adjacency entry is 0 (the compiled packer used
+    # to compare the diagonal by bit pattern and rejected it); a -1 where the entry is 1 is a different VALUE: rejected by both
+    p0, q0 = [int(v[0]) for v in np.nonzero(adj[3] == 0)]
+    p1, q1 = [int(v[0]) for v in np.nonzero(adj[3] == 1)]
+    ok = bad_adj(lambda A: A.__setitem__((3, p0 * F + 5, q0 * F + 5), -0.0))
+    assert np.array_equal(feed_to_packed(spec, ok, True).col_idx, feed_to_packed(spec, feed, True).col_idx)
+    x_, e_, nb_, a_ = v2xgnn.feed_to_arrays(spec, ok, True)
+    assert np.array_equal(PackedBatch.from_dense(x_, e_, a_, nb_).col_idx, feed_to_packed(spec, feed, True).col_idx)
+    neg = bad_adj(lambda A: A.__setitem__((3, p1 * F + 5, q1 * F + 5), -1.0))
+    with pytest.raises(ValueError):
+        feed_to_packed(spec, neg, True)
+    with pytest.raises(ValueError):
+        x_, e_, nb_, a_ = v2xgnn.feed_to_arrays(spec, neg, True)
+        PackedBatch.from_dense(x_, e_, a_, nb_)
     for mutate in ('drop', 'shape', 'adjshape', 'samples'):
         bad = dict(feed)
         if mutate == 'drop':

@@ -802,8 +802,10 @@ def run_workload(args, ctx, light=False):
                "steps_requested": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                "timed_seconds": round(elapsed, 4), "higher_is_better": True,
                "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               # which aggregation `value` ran, said at top level: the general edge-index gather / segment sum of
-               # AggLayer.call is the judged form; the complement rewriting is the fast path beside it
+               # which aggregation `value` ran, said at top level: the general edge-index aggregation of AggLayer.call ("edge-bitset-
+               # walk": the fused kernels turn every CSR row into a 32-bit set and walk the graph's rows in LDS; degree-aware) is
+               # the judged form; the complement rewriting is the fast path beside it; config.per_edge_gather is the per-edge CSR
+               # gather kernel k_agg (layer-wise path)
                "aggregation": path.get("aggregation"),
                "fast_path": fast,
                "config": {"workload": "BASELINE.json configs[%d]: %s V2V links, feat_dim=%d, %d-layer GNN, %s, "
@@ -833,27 +835,120 @@ def run_workload(args, ctx, light=False):
     return out
 
 
+def cpu_leg_share(wl, budget_s=8.0):
+    """CPU restatement (the oracle, kind "port") beside the other workloads' share figures (north_star:
+    "next to the ... CPU path timed on the same box"), on a BOUNDED sample of the share, scaled to graphs/s and labelled:
+    configs[3] -- oracle/parallel.py's worker processes (one BLAS thread each) over a 128-graph sample of the 1024-graph share
+    (the full share costs about a minute per step on one thread); configs[4] -- oracle/compact.py's fit step on a 256-graph
+    ragged sample of the 2048-graph share, at one BLAS thread and at the pool's size, the better of the two."""
+    from oracle import compact as oc
+    from oracle.spec import GnnSpec as OSpec
+    host_cores = len(os.sched_getaffinity(0))
+    if wl == "cfg4":
+        from oracle.parallel import ShardedOracle
+        n, f, l, bs = 100, 256, 3, 128
+        workers = max(1, min(host_cores, bs // 4))
+        x, e, adj, y = synth_batch(np.random.default_rng(1001), bs, n)
+        so = ShardedOracle(dict(n_nodes=n, feat_dim=f, n_mp_layers=l, share_weights=False), x, e, adj, y, workers)
+        try:
+            sec, steps = _timed_steps(so.step, budget_s, 2, 20, 1)
+        finally:
+            so.close()
+        return {"value": round(bs / sec, 1), "unit": "graph-instances/s", "cores": int(workers), "kind": "port", "cpu_model": cpu_model(),
+                "ms_per_step": round(1e3 * sec, 2), "steps": steps,
+                "sample": "median of %d fit steps of a %d-graph sample of the 1024-graph share (N=100, F=256, L=3, per-node weights): "
+                          "%d worker processes x 1 BLAS thread over graph shards, gradients summed, one Adam update; numpy fp32 CSR "
+                          "oracle, not Keras/TF1" % (steps, bs, workers)}
+    try:
+        from threadpoolctl import threadpool_limits, threadpool_info
+        all_thr = max([p_.get("num_threads", 1) for p_ in threadpool_info()] or [1])
+    except Exception:
+        threadpool_limits, all_thr = None, 1
+    import contextlib
+    bs = 256
+    sizes, offs, row_ptr, cols, x, e, y = synth_ragged(np.random.default_rng(1001), bs, 8, 128)
+    spec = OSpec(n_nodes=1, feat_dim=64, n_mp_layers=2, share_weights=True)
+    om = oc.OracleModel(spec, oc.init_params(spec, np.random.default_rng(7), np.float32), dtype=np.float32)
+    graph = (offs, row_ptr, cols)
+    best = None
+    for nthr in sorted({1, int(all_thr)}):
+        with (threadpool_limits(limits=nthr) if threadpool_limits is not None else contextlib.nullcontext()):
+            sec, steps = _timed_steps(lambda: om.train_step(x, e, graph, y), budget_s / 2, 2, 20, 1)
+        if best is None or sec < best[0]:
+            best = (sec, steps, nthr)
+    sec, steps, nthr = best
+    return {"value": round(bs / sec, 1), "unit": "graph-instances/s", "cores": int(nthr), "kind": "port", "cpu_model": cpu_model(),
+            "ms_per_step": round(1e3 * sec, 2), "steps": steps,
+            "sample": "median of %d fit steps of a %d-graph ragged sample (8-128 links, %d node rows) of the 2048-graph share (F=64, L=2, "
+                      "shared weights), numpy fp32 CSR oracle at %d BLAS thread(s) (the better of 1 and the pool's size), not Keras/TF1"
+                      % (steps, bs, int(offs[-1]), nthr)}
+
+
 def other_workloads(args, ctx):
-    """Short driver-observed passes of the other single-GPU-sized configurations: configs[3] and
-    configs[4] at their per-GPU shares of an 8-GPU run (shard 0 of the global batch, global Huber denominator, no all-reduce)."""
+    """Short driver-observed passes beside the headline:
+    * cfg4 / cfg5: configs[3] and configs[4] at their per-GPU shares of an 8-GPU run (shard 0 of the global batch, global Huber
+      denominator, no all-reduce), each with a CPU leg on a bounded sample of the share;
+    * cfg2_share2 / 4 / 8: the shares of the METRIC's own global batch of 4096 at 2 / 4 / 8 GPUs (the 1024- and 512-graph
+      shares run the split-tile fused graph layers);
+    * per_edge_gather: the fit step with the per-edge CSR gather / segment sum kernel k_agg (layer-wise graph layers,
+      V2X_FUSED=0) -- the aggregation mechanism north_star words, beside the fused kernels' bit-set walk that `value` runs;
+    * cfg2loop: configs[2]'s DQN loop on one GPU (50 simulators stepped as arrays, 2 timed episodes of 20 train steps)."""
     import copy
     out = {}
-    for wl in ("cfg4", "cfg5"):
+
+    def light(wl, shard_of, **over):
         a = copy.copy(args)
-        a.workload, a.shard_of, a.scaling, a.gpus = wl, 8, "strong", 1
+        a.workload, a.shard_of, a.scaling, a.gpus = wl, shard_of, "strong", 1
         a.steps, a.warmup, a.min_seconds = 20, 5, 0.6
         a.ragged, a.share_weights = None, False
+        for k_, v_ in over.items():
+            setattr(a, k_, v_)
         a = resolve_workload(a)
+        r = run_workload(a, ctx, light=True)
+        rf = r.get("roofline") or {}
+        return {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                "steps": r["steps"], "timed_seconds": r["timed_seconds"], "graphs_per_gpu": r["config"]["graphs_per_gpu"],
+                "aggregation": r["aggregation"], "kernel_path": r["config"]["kernel_path"], "dominant_kernel": rf.get("kernel"),
+                "bound": rf.get("bound"), "frac": rf.get("frac"), "step_hbm_frac": rf.get("step_hbm_frac"),
+                "step_mfma_frac": rf.get("step_mfma_frac"), "kernels": r.get("kernels")}
+
+    def guarded(key, fn):
         try:
-            r = run_workload(a, ctx, light=True)
-            rf = r.get("roofline") or {}
-            out[wl] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
-                       "steps": r["steps"], "timed_seconds": r["timed_seconds"], "graphs_per_gpu": r["config"]["graphs_per_gpu"],
-                       "aggregation": r["aggregation"], "dominant_kernel": rf.get("kernel"), "bound": rf.get("bound"),
-                       "frac": rf.get("frac"), "step_hbm_frac": rf.get("step_hbm_frac"), "step_mfma_frac": rf.get("step_mfma_frac"),
-                       "kernels": r.get("kernels")}
+            out[key] = fn()
         except Exception as exc:                      # keep the headline line whatever happens here
-            out[wl] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+    for wl in ("cfg4", "cfg5"):
+        guarded(wl, lambda: light(wl, 8))
+        if not args.no_cpu_baseline and "error" not in out[wl]:
+            try:
+                out[wl]["cpu_baseline"] = cpu_leg_share(wl)
+            except Exception as exc:
+                out[wl]["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+    for g in (2, 4, 8):
+        guarded("cfg2_share%d" % g, lambda: light("cfg2", g))
+
+    def per_edge():
+        had = os.environ.get("V2X_FUSED")
+        os.environ["V2X_FUSED"] = "0"                 # read when the model is created: layer-wise graph layers, k_agg aggregation
+        try:
+            return light("cfg2", 1)
+        finally:
+            if had is None:
+                del os.environ["V2X_FUSED"]
+            else:
+                os.environ["V2X_FUSED"] = had
+    guarded("per_edge_gather", per_edge)
+
+    def dqn_loop():
+        import torch
+        with torch.cuda.stream(torch.cuda.Stream()):
+            r = rl_episode(20, 64, 4096, 0.5, 20, 1001, use_graph=True, envs=50, episodes=2)
+        r["workload"] = ("BASELINE.json configs[2] on one GPU: 2 episodes x 20 train steps x (50 rollout transitions on 50 simulators "
+                         "stepped as arrays + 1 replay of batch 4096), 20 links, feat_dim 64; one agent, two-step warm-up episode "
+                         "outside the timed region")
+        return r
+    guarded("cfg2loop", dqn_loop)
     return out
 
 
@@ -915,6 +1010,8 @@ def main():
                 dropin["cpu_fit_step_C0_ms"] = cpu["legs"]["C0_one_thread"]["ms_per_step"]
         if others is not None:
             out["config"]["other_workloads"] = others
+            pe = others.get("per_edge_gather") or {}
+            out["config"]["per_edge_gather"] = {k_: pe.get(k_) for k_ in ("value", "unit", "ms_per_step", "aggregation", "kernel_path", "error") if k_ in pe}
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -382,6 +382,31 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwdArgs& a, const FzCt
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) ag[i][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    // Degree-aware (round 5): a lane whose slots' sets together hold fewer than N / 2 sources walks only those (ascending:
+    // the same sums in the same order -- skipping "+ x * 0" is exact, a running sum that started at +0 is never -0); the wave
+    // takes the plain walk of all N rows when no lane is that sparse (the reference's complete-minus-two graphs: unchanged
+    // code on the headline path).  A 28-link graph of in-degree 2 then costs ~6 row reads per wave and graph, not 28.
+    unsigned orm = 0u;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) orm |= msk[i];
+    if (__any(2 * __popc(orm) < N)) {
+      unsigned walk = 2 * __popc(orm) < N ? orm : (N >= 32 ? 0xffffffffu : (1u << N) - 1u);
+      while (walk) {
+        const int p = __builtin_ctz(walk);
+        walk &= walk - 1;
+        const float* bp = myrow + p * (FZ_TG * ROWF);
+        f32x4 v[FB];
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) v[kb] = ld4(bp + kb * 4);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+          const float f = (float)((msk[i] >> p) & 1u);
+#pragma unroll
+          for (int kb = 0; kb < FB; ++kb) ag[i][kb] += v[kb] * f;
+        }
+      }
+      return;
+    }
     for (int p = 0; p < N; ++p) {
       const float* bp = myrow + p * (FZ_TG * ROWF);
       f32x4 v[FB];
@@ -729,16 +754,37 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwdArgs& a, const FzCt
 #pragma unroll
         for (int kb = 0; kb < FB; ++kb) dpre[i][kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      for (int q = 0; q < N; ++q) {
-        const float* bq = myrow + q * (FZ_TG * ROWF);
-        f32x4 v[FB];
+      unsigned orm = 0u;                   // degree-aware, as the forward's gather_all: sparse lanes walk their destinations only
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) v[kb] = ld4(bq + kb * 4);
+      for (int i = 0; i < NS; ++i) orm |= msk[i];
+      if (__any(2 * __popc(orm) < N)) {
+        unsigned walk = 2 * __popc(orm) < N ? orm : valid;
+        while (walk) {
+          const int q = __builtin_ctz(walk);
+          walk &= walk - 1;
+          const float* bq = myrow + q * (FZ_TG * ROWF);
+          f32x4 v[FB];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-          const float f = (float)((msk[i] >> q) & 1u);
+          for (int kb = 0; kb < FB; ++kb) v[kb] = ld4(bq + kb * 4);
 #pragma unroll
-          for (int kb = 0; kb < FB; ++kb) dpre[i][kb] += v[kb] * f;
+          for (int i = 0; i < NS; ++i) {
+            const float f = (float)((msk[i] >> q) & 1u);
+#pragma unroll
+            for (int kb = 0; kb < FB; ++kb) dpre[i][kb] += v[kb] * f;
+          }
+        }
+      } else {
+        for (int q = 0; q < N; ++q) {
+          const float* bq = myrow + q * (FZ_TG * ROWF);
+          f32x4 v[FB];
+#pragma unroll
+          for (int kb = 0; kb < FB; ++kb) v[kb] = ld4(bq + kb * 4);
+#pragma unroll
+          for (int i = 0; i < NS; ++i) {
+            const float f = (float)((msk[i] >> q) & 1u);
+#pragma unroll
+            for (int kb = 0; kb < FB; ++kb) dpre[i][kb] += v[kb] * f;
+          }
         }
       }
     }

@@ -340,6 +340,18 @@ __device__ __forceinline__ void fused_fwd_split_body(const FusedFwdArgs& a, cons
     const unsigned msk = x.sC[jc * N + k];
 #pragma unroll
     for (int kb = 0; kb < FB; ++kb) ag[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (__any(2 * __popc(msk) < N)) {      // degree-aware (see the unsplit kernel's gather_all): sparse lanes walk their sources only
+      unsigned walk = 2 * __popc(msk) < N ? msk : (N >= 32 ? 0xffffffffu : (1u << N) - 1u);
+      while (walk) {
+        const int p = __builtin_ctz(walk);
+        walk &= walk - 1;
+        const float* bp = myrow + p * (FZ_TG * ROWF);
+        const float f = (float)((msk >> p) & 1u);
+#pragma unroll
+        for (int kb = 0; kb < FB; ++kb) ag[kb] += ld4(bp + kb * 4) * f;
+      }
+      return;
+    }
     for (int p = 0; p < N; ++p) {
       const float* bp = myrow + p * (FZ_TG * ROWF);
       const float f = (float)((msk >> p) & 1u);
@@ -558,11 +570,23 @@ __device__ __forceinline__ void fused_bwd_split_body(const FusedBwdArgs& a, cons
       const unsigned msk = x.sM[jc * N + k];
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) dpre[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < N; ++q) {
-        const float* bq = myrow + q * (FZ_TG * ROWF);
-        const float f = (float)((msk >> q) & 1u);
+      if (__any(2 * __popc(msk) < N)) {    // degree-aware
+        unsigned walk = 2 * __popc(msk) < N ? msk : (N >= 32 ? 0xffffffffu : (1u << N) - 1u);
+        while (walk) {
+          const int q = __builtin_ctz(walk);
+          walk &= walk - 1;
+          const float* bq = myrow + q * (FZ_TG * ROWF);
+          const float f = (float)((msk >> q) & 1u);
 #pragma unroll
-        for (int kb = 0; kb < FB; ++kb) dpre[kb] += ld4(bq + kb * 4) * f;
+          for (int kb = 0; kb < FB; ++kb) dpre[kb] += ld4(bq + kb * 4) * f;
+        }
+      } else {
+        for (int q = 0; q < N; ++q) {
+          const float* bq = myrow + q * (FZ_TG * ROWF);
+          const float f = (float)((msk >> q) & 1u);
+#pragma unroll
+          for (int kb = 0; kb < FB; ++kb) dpre[kb] += ld4(bq + kb * 4) * f;
+        }
       }
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) {

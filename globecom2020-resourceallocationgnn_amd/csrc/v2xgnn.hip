@@ -2542,7 +2542,10 @@ int v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap) {
   d.goff = b->graph_off; d.nbr = b->nbr_init;
   const bool fused = fused_path(m, d);
   const int split = fused_split(m, d);
-  const char* agg = fused ? (split <= 1 && fused_compl(m, d) ? "complement" : "edge-gather")
+  // "edge-bitset-walk": what the fused kernels do with the edge index (N <= 32) -- every CSR row becomes a 32-bit set, a wave
+  // walks the graph's rows in LDS once and adds each to the slots whose set holds it (sparse lanes walk their set bits only);
+  // "edge-gather": the per-edge CSR gather / segment sum of k_agg (layer-wise path, any N)
+  const char* agg = fused ? (split <= 1 && fused_compl(m, d) ? "complement" : "edge-bitset-walk")
                           : (use_dense_agg(d, m->F) ? "dense(complement-or-mfma-per-graph)" : "edge-gather");
   char gl[48];
   if (fused && split > 1) snprintf(gl, sizeof(gl), "fused(split%d)", split);

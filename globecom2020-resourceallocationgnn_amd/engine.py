@@ -275,7 +275,7 @@ class GnnEngine(object):
 
     # ------------------------------------------------------------------ measurement
     def path_info(self, batch):
-        """{'graph_layers': 'fused', 'aggregation': 'complement' | 'edge-gather' | 'dense(complement-or-mfma-per-graph)', ...}: the kernels a fit step
+        """{'graph_layers': 'fused', 'aggregation': 'complement' | 'edge-bitset-walk' (fused kernels) | 'edge-gather' (k_agg) | 'dense(complement-or-mfma-per-graph)', ...}: the kernels a fit step
         of this batch runs (v2x_path_info)."""
         buf = C.create_string_buffer(256)
         s = _batch_struct(batch)

@@ -151,7 +151,7 @@ def test_bench_two_ranks_on_one_gpu(scaling, batch, global_batch, per_gpu):
     assert res["config"]["graphs_per_gpu"] == per_gpu
     assert res["value"] > 0 and res["scaling"] == (scaling or "strong") == res["config"]["scaling"] and res["steps"] == 5
     assert (res["metric"] == BASELINE_METRIC) == (global_batch == 4096)
-    assert res["config"]["aggregation"] in ("complement", "edge-gather")
+    assert res["config"]["aggregation"] in ("complement", "edge-bitset-walk", "edge-gather")
     assert abs(res["value"] - global_batch * 5 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-3
 
 
@@ -177,7 +177,7 @@ def test_bench_starts_its_own_ranks():
     assert res["scaling"] == "strong" and res["config"]["global_batch"] == 512 and res["config"]["graphs_per_gpu"] == 256
     weak = res["config"]["weak"]
     assert weak["graphs_per_gpu"] == 512 and weak["global_batch"] == 1024 and weak["value"] > 0
-    assert res["aggregation"] == "edge-gather" and res["fast_path"]["aggregation"] == "complement" and res["fast_path"]["value"] > 0
+    assert res["aggregation"] == "edge-bitset-walk" and res["fast_path"]["aggregation"] == "complement" and res["fast_path"]["value"] > 0
 
 
 def _wide_worker(rank, world, port, mode, ret):

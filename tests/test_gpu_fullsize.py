@@ -83,7 +83,7 @@ def _parity_with_oracle(spec, P, pb, x, e, graph, what, adam=True, engine=None):
     eng.close()
 
 
-@pytest.mark.parametrize("aggregation", ["edge-gather", "complement"])
+@pytest.mark.parametrize("aggregation", ["edge-bitset-walk", "complement"])
 @pytest.mark.parametrize("shared", [False, True])
 def test_cfg2_full_size_vs_oracle(shared, aggregation):
     """BASELINE configs[1] in full: B = 4096 graphs of 20 links, F = 64, L = 2 -- the 256 lock-stepped fused workgroups,
@@ -97,7 +97,7 @@ def test_cfg2_full_size_vs_oracle(shared, aggregation):
     P = f32_params(spec, rng)
     pb = PackedBatch.from_dense(x, e, adj)
     graph = ((np.arange(B + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
-    eng = _training_engine(spec, edge_gather=aggregation == "edge-gather")
+    eng = _training_engine(spec, edge_gather=aggregation == "edge-bitset-walk")
     info = eng.path_info(pb)
     assert info["graph_layers"] == "fused" and info["aggregation"] == aggregation, info
     _parity_with_oracle(spec, P, pb, x.reshape(B * N, -1), e.reshape(B * N, -1), graph,
@@ -120,7 +120,7 @@ def test_cfg2_shares_vs_oracle(share, variant):
     graph = ((np.arange(share + 1) * N).astype(np.int32), pb.row_ptr, pb.col_idx)
     eng = _training_engine(spec, edge_gather=True)
     info = eng.path_info(pb)
-    assert info["graph_layers"] == variant and info["aggregation"] == "edge-gather", info
+    assert info["graph_layers"] == variant and info["aggregation"] == "edge-bitset-walk", info
     _parity_with_oracle(spec, P, pb, x.reshape(share * N, -1), e.reshape(share * N, -1), graph,
                         "configs[1] share of %d graphs, %s" % (share, variant), engine=eng)
 

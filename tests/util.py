@@ -34,6 +34,17 @@ def random_inputs(rng, B, N, C=4, ref_topology=True, density=0.5):
     return x.astype(np.float32), e.astype(np.float32), adj
 
 
+def fixed_indegree_adj(rng, B, N, degree):
+    """adj[b, p, q] = 1 for exactly `degree` sources p != q of every destination q (sparse interference graphs: the
+    degree-aware walks of the fused kernels)."""
+    adj = np.zeros((B, N, N), np.float64)
+    for b in range(B):
+        for q in range(N):
+            others = np.delete(np.arange(N), q)
+            adj[b, rng.choice(others, size=min(degree, N - 1), replace=False), q] = 1.0
+    return adj
+
+
 def f32_params(spec, rng, random_bias=True):
     """Oracle params whose values are exactly representable in fp32 (kept as float64 arrays)."""
     P = oc.init_params(ospec(spec), rng, np.float64, random_bias=random_bias)

@@ -45,7 +45,7 @@ def _training_engine(spec, edge_gather=False):
         os.environ.pop("V2X_FUSED_COMPL", None)
 
 
-def _parity_with_oracle(spec, P, pb, x, e, graph, what, adam=True, engine=None):
+def _parity_with_oracle(spec, P, pb, x, e, graph, what, adam=True, engine=None, one_call_step=False):
     """forward / loss / every gradient array / (one Adam step's weights) of the engine against the float64 oracle on the
     same fp32-rounded inputs and weights.  x, e: node rows [R, 9], [R, 4].  Targets: the engine's own q + N(0, 1.2), so
     that both branches of the Huber loss are taken whatever the magnitude of q (random weights and up to 126-neighbour
@@ -67,9 +67,18 @@ def _parity_with_oracle(spec, P, pb, x, e, graph, what, adam=True, engine=None):
     assert n_flip <= MAX_GATE_FLIPS, (what, "the checker resolved %d ReLU gates the kernels' way (of %d candidates): too many "
                                             "to be rounding at the gate" % (n_flip, n_cand))
     if adam:
-        eng.apply_gradients()
+        if one_call_step:
+            # the weights after ONE fit call (v2x_train_step) from the same start: on the wide path Adam then runs in the
+            # weight-gradient launch's epilogue (WideWgradArgs::adam), with the merged launch's row split, XCD map and grid of
+            # THIS batch size -- not the Adam launch that apply_gradients() is
+            assert eng.get_optimizer_state()[2] == 0
+            eng.set_weights(w0)
+            eng.train_step(pb, y, n_global=n_den)
+        else:
+            eng.apply_gradients()
         params = oc.cast_params(P, np.float64)
         KerasAdam().step(oc.param_arrays(params), oc.param_arrays(g_ref))
+        n_loose = n_two_steps = 0
         for i, (a, b, g) in enumerate(zip(eng.get_weights(), oc.params_to_list(params), oc.params_to_list(g_ref))):
             # Adam's first step is sign-like (lr_t * m / sqrt(v) = +-1e-3 whatever |g|): where |g| is at rounding-noise
             # level its direction is not determined by fp32 arithmetic -- those entries are compared to within one full
@@ -78,7 +87,13 @@ def _parity_with_oracle(spec, P, pb, x, e, graph, what, adam=True, engine=None):
             tight = np.abs(g) > 1e-4 * scale
             err = np.abs(a.astype(np.float64) - b)
             assert (err[tight] <= 2e-5 + 2e-4 * np.abs(b[tight])).all(), (what, "weights", i, err[tight].max())
-            assert (err[~tight] <= 1.1e-3).all(), (what, "weights (sign of g undetermined)", i, err[~tight].max())
+            # (a noise-level gradient whose SIGN the two summation orders disagree on moves the weight by lr either way: two
+            #  full steps apart at most, and only for a vanishing share of the noise-level entries)
+            loose = err[~tight]
+            assert (loose <= 2.1e-3).all(), (what, "weights (sign of g undetermined)", i, loose.max())
+            n_loose += loose.size
+            n_two_steps += int((loose > 1.1e-3).sum())
+        assert n_two_steps <= max(8, 1e-3 * n_loose), (what, "noise-level gradients with the other sign", n_two_steps, n_loose)
         assert eng.get_optimizer_state()[2] == 1
     eng.close()
 
@@ -127,7 +142,8 @@ def test_cfg2_shares_vs_oracle(share, variant):
 
 def test_cfg3_share_vs_oracle():
     """The per-GPU share of BASELINE configs[3]: 1024 graphs x 100 links x 256 features x 3 layers (wide-feature path:
-    tiled MFMA GEMMs, MFMA aggregation of dense graphs, in-place weight gradients)."""
+    tiled MFMA GEMMs, MFMA aggregation of dense graphs, in-place weight gradients), incl. the weights after one fit call
+    whose Adam runs in the merged weight-gradient launch's epilogue, against Keras Adam on the oracle's gradients."""
     import bench
     n, f, l, b = 100, 256, 3, 1024
     rng = np.random.default_rng(43)
@@ -137,7 +153,7 @@ def test_cfg3_share_vs_oracle():
     pb = PackedBatch.from_dense(x, e, adj)
     del adj
     graph = ((np.arange(b + 1) * n).astype(np.int32), pb.row_ptr, pb.col_idx)
-    _parity_with_oracle(spec, P, pb, x.reshape(b * n, -1), e.reshape(b * n, -1), graph, "configs[3] share", adam=False)
+    _parity_with_oracle(spec, P, pb, x.reshape(b * n, -1), e.reshape(b * n, -1), graph, "configs[3] share", adam=True, one_call_step=True)
 
 
 def test_cfg4_share_vs_oracle():

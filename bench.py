@@ -892,7 +892,7 @@ def other_workloads(args, ctx):
       shares run the split-tile fused graph layers);
     * per_edge_gather: the fit step with the per-edge CSR gather / segment sum kernel k_agg (layer-wise graph layers,
       V2X_FUSED=0) -- the aggregation mechanism north_star words, beside the fused kernels' bit-set walk that `value` runs;
-    * cfg2loop: configs[2]'s DQN loop on one GPU (50 simulators stepped as arrays, 2 timed episodes of 20 train steps)."""
+    * cfg2loop: configs[2]'s DQN loop on one GPU (50 simulators stepped as arrays, 5 timed episodes of 20 train steps)."""
     import copy
     out = {}
 
@@ -943,8 +943,8 @@ def other_workloads(args, ctx):
     def dqn_loop():
         import torch
         with torch.cuda.stream(torch.cuda.Stream()):
-            r = rl_episode(20, 64, 4096, 0.5, 20, 1001, use_graph=True, envs=50, episodes=2)
-        r["workload"] = ("BASELINE.json configs[2] on one GPU: 2 episodes x 20 train steps x (50 rollout transitions on 50 simulators "
+            r = rl_episode(20, 64, 4096, 0.5, 20, 1001, use_graph=True, envs=50, episodes=5)
+        r["workload"] = ("BASELINE.json configs[2] on one GPU: 5 episodes x 20 train steps x (50 rollout transitions on 50 simulators "
                          "stepped as arrays + 1 replay of batch 4096), 20 links, feat_dim 64; one agent, two-step warm-up episode "
                          "outside the timed region")
         return r

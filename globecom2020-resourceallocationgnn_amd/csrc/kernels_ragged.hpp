@@ -31,7 +31,10 @@ namespace v2x {
 
 constexpr int RG_CAP = 320;                    // rows of a workgroup's LDS tile: with graphs of <= 128 nodes a workgroup holds 193 rows
                                                // on average = 12 row tiles = 3 per SIMD (waves w and w + 4 share one: 2 + 1)
-constexpr int RG_WAVES = 8, RG_THREADS = 64 * RG_WAVES;
+#ifndef V2X_RG_WAVES
+#define V2X_RG_WAVES 8
+#endif
+constexpr int RG_WAVES = V2X_RG_WAVES, RG_THREADS = 64 * RG_WAVES;
 constexpr int RG_RT = (RG_CAP / 16 + RG_WAVES - 1) / RG_WAVES;   // row tiles a wave may own (tiles wv, wv + 8, wv + 16)
 constexpr int RG_BIG = 16;                     // graphs of >= RG_BIG nodes get a column-sum slot (at most RG_CAP / RG_BIG + 1 per tile)
 constexpr int RG_SLOTS = RG_CAP / RG_BIG + 1;

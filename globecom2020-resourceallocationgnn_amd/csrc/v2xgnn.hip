@@ -678,10 +678,26 @@ void set_idx(WideGemmArgs& a, const IdxMap& x) {
 // Dense-0's 80 columns are one 5-tile strip instead of a 64 + 16 split (154 -> 110 us).
 int wide_nt(int n_out) { return n_out <= 80 ? 5 : 4; }
 
+int launch_check(v2x_model* m, const char* kname);
 int launch_wide_gemm(v2x_model* m, hipStream_t st, WideGemmArgs& a, int grid_z, bool trans, const char* name) {
   const int nt = wide_nt(a.n_out);
-  const dim3 grid((a.n_idx + WD_TM - 1) / WD_TM, (a.n_out + 16 * nt - 1) / (16 * nt), grid_z);
-#define V2X_WIDE_GEMM(T, NTV) { auto k = k_wide_gemm<T, NTV>; LAUNCH(m, name, k, grid, 0, st, a); return V2X_OK; }
+  // Tiling (kernels_wide.hpp, WideTiling): 128-row tiles; when the launch is more than one round of the chip's resident
+  // workgroups (five per CU) and its last round would be less than three quarters full, the row blocks of that last round run
+  // as two 64-row tiles each, dispatched last (V2X_WIDE_TAIL=0: whole tiles only)
+  static const int tail = env_int("V2X_WIDE_TAIL", 1);
+  WideTiling t;
+  t.ny = (a.n_out + 16 * nt - 1) / (16 * nt);
+  t.mbs = (a.n_idx + WD_TM - 1) / WD_TM;
+  t.n_rb = t.mbs * grid_z;
+  t.n_full_rb = t.n_rb;
+  const int T = t.n_rb * t.ny, C = 5 * n_cus(), rem = T % C;
+  if (tail && T > C && rem > 0 && 4 * rem < 3 * C) t.n_full_rb = t.n_rb - rem / t.ny;
+  const dim3 grid(t.n_full_rb * t.ny + 2 * (t.n_rb - t.n_full_rb) * t.ny);
+#define V2X_WIDE_GEMM(T_, NTV) { auto k = k_wide_gemm<T_, NTV>; ProfRec _r; const bool _p = m->prof && !m->capturing;                      \
+    if (_p) { _r.id = prof_id(m, name); hipEventCreate(&_r.ev0); hipEventCreate(&_r.ev1); hipEventRecord(_r.ev0, st); }                     \
+    hipLaunchKernelGGL(k, grid, dim3(256), 0, st, a, t);                                                                                     \
+    if (_p) { hipEventRecord(_r.ev1, st); m->prof_recs.push_back(_r); }                                                                      \
+    return launch_check(m, name); }
   if (!trans) {
     if (nt == 5) V2X_WIDE_GEMM(false, 5)
     V2X_WIDE_GEMM(false, 4)

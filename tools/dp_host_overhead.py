@@ -18,7 +18,7 @@ from v2xgnn.dp import DataParallelTrainer  # noqa: E402
 
 wide = "--wide" in sys.argv
 dist.init_process_group(os.environ.get("V2X_BENCH_BACKEND", "nccl"), rank=0, world_size=1)
-N, F, L, B = (100, 256, 3, 1024) if wide else (20, 64, 2, 4096)
+N, F, L, B = (100, 256, 3, 1024) if wide else (20, 64, 2, int(os.environ.get("DP_BATCH", "4096")))     # DP_BATCH=512: the 8-GPU share
 rng = np.random.default_rng(1001)
 x, e, adj, y = bench.synth_batch(rng, B, N)
 stream = torch.cuda.Stream()

@@ -31,6 +31,9 @@
 //     row only (5 of 9 k-blocks, in the accumulation order of the unsplit kernel: bitwise the same sums), the aggregation
 //     k-blocks follow the gather; the backward computes and publishes the dagg half of a data gradient before its dh half;
 //   * a unit whose words are not there yet is re-read alone (at most a few rounds), then the wave falls back to one-lane polls;
+//   * an L2 warm-up of the later stages' weights (one dword per line and lane, issued and waited for at the start) was built
+//     twice: with the wait in a later statement it corrupted results (hipcc re-used the destination registers while the loads
+//     were in flight), self-contained it delayed the CSR chain by 2 us and bought 0.3 us later: not kept;
 //   * the number of graph layers L is a template parameter (1..3) and the stage loop is unrolled: a weight request that is in
 //     flight across a loop's back edge makes hipcc's wait-count pass wait for vmcnt(0) at its first use -- and with it for
 //     every younger prefetch (the second version of these kernels: 40 us where the first took 37.6).
@@ -184,6 +187,17 @@ struct FzStampR {
     }
   }
 };
+
+// "These registers must hold their values HERE": an empty asm per register makes hipcc place its wait for a weight request at
+// this point -- chosen so that no store is in flight yet.  Loads and stores share the one in-order vmcnt counter but are
+// acknowledged independently, so a load that is waited for AFTER a store was issued costs that store's acknowledgement as well
+// (vmcnt(0)); the write-through publishes of these kernels are acknowledged late (phase stamps: 1.3 us in front of the next
+// stage's own-row k-blocks, 2.4 us in front of stage 1).
+template <int NV>
+__device__ __forceinline__ void fz_consume(const f32x4 (&w)[NV]) {
+#pragma unroll
+  for (int u = 0; u < NV; ++u) asm volatile("" ::"v"(w[u]));
+}
 
 struct FzCtxS {
   float* sH; int* sRp; unsigned char* sCol; unsigned* sC; float* sBias;
@@ -365,6 +379,7 @@ __device__ __forceinline__ void fused_fwd_split_body(const FusedFwdArgs& a, cons
 #pragma unroll
     for (int kb = 0; kb < FB; ++kb) hb[kb] = ld4(myrow + k * FZ_TG * ROWF + kb * 4);
     pre(wpre1, hb);
+    __builtin_amdgcn_sched_barrier(0);     // (the stage's requests below must not be hoisted in front of these MFMAs' waits)
   }
   // ---- stages 1..L (unrolled: L is a template parameter)
 #pragma unroll
@@ -380,6 +395,8 @@ __device__ __forceinline__ void fused_fwd_split_body(const FusedFwdArgs& a, cons
       if (s == 1) { load_post(wpost, 1); load_bias(bias, 1); }
       if (s < L) load_pre(wpre, s + 1);    // (used after this stage's barrier)
       gather(ag);
+      fz_consume(wpost); fz_consume(bias);   // the waits for this stage's (and the next own part's) weights: before the first store
+      if (s < L) fz_consume(wpre);
 #pragma unroll
       for (int kb = 0; kb < FB; ++kb) stg4(ap + rowk * F + kb * 16 + 4 * kg, ag[kb]);
       ts.mark();                                                 // stage: gather done
@@ -551,6 +568,7 @@ __device__ __forceinline__ void fused_bwd_split_body(const FusedBwdArgs& a, cons
     x.sM[r] = ns;
   }
   fz_barrier();
+  if (HAS && L >= 1) { fz_consume(wa); fz_consume(wh); }
   ts.mark();                                                     // 1: tile + masks ready
 
   typedef const __attribute__((address_space(4))) uint64_t* CQ;
@@ -630,6 +648,7 @@ __device__ __forceinline__ void fused_bwd_split_body(const FusedBwdArgs& a, cons
       if (s >= 2) { load_half(wa, s - 1, 1); load_half(wh, s - 1, 0); }        // (land during the hand-over, whose wait covers them)
     }
     fz_collect<FB, ROWF>(out, x.sD, x.SUB, N, K, x.m, tag, lane, wv, jc, kg, a.err);
+    if (HAS && s >= 2) { fz_consume(wa); fz_consume(wh); }       // (landed during the hand-over: hipcc's wait goes here, in front of the next stores)
     ts.mark();                                                   // stage: partners' rows in the tile
     fz_barrier();
     ts.mark();                                                   // stage: barrier

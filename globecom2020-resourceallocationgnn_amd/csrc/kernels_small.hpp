@@ -20,7 +20,7 @@
 // with an agent-scope release (L2 write-back, ~1.7 us), an arrival atomic, a poll and an acquire (L1 invalidate, ~1.7 us):
 // 30.7 us per predict at 20 links; the fence-free barrier with write-through rows (sc1 stores, acknowledgement wait, arrival
 // atomic, poll, sc1 gathers) measured 25.4 us (and 18.5 against 13.7 us at 4 links: the acknowledgement of a write-through
-// store is slower than a clean write-back); tagged granules: see DESIGN.md 3d.
+// store is slower than a clean write-back); tagged granules: see profiles/HISTORY.md 3d.
 // The epoch is floor(departures / N): every workgroup adds 1 to its graph's departure counter when it leaves (no return
 // value, nobody waits for it), so the quotient is the same for all workgroups of a launch whenever they read it and one
 // more in the next launch -- also under hipGraph replay, where the kernel arguments are frozen.  One slab per stage:

@@ -35,7 +35,7 @@ struct WideGemmArgs {
 constexpr int WD_TM = 128, WD_KC = 16;
 
 // NT = output tile width in 16-column MFMA tiles (4: 64 columns; 5: Dense-0's 80 outputs as one strip); the workgroup tile is
-// 128 rows x 16 NT columns, K in chunks of 16 through a double-buffered LDS tile.  Measured at configs[3]'s share (DESIGN.md
+// 128 rows x 16 NT columns, K in chunks of 16 through a double-buffered LDS tile.  Measured at configs[3]'s share (profiles/HISTORY.md
 // 3b): 64-column tiles at five workgroups per CU beat whole-width tiles, 256-row tiles and 32-deep chunks (L2 absorbs the
 // operand re-reads, occupancy matters more).
 //
@@ -208,7 +208,7 @@ __device__ __forceinline__ void wide_gemm_body(const WideGemmArgs& a, float* sAp
 // Workgroup -> tile, XCD-aware, in both regions: workgroup ids are dealt round-robin to the 8 XCDs, each with an L2 of its own;
 // the ids i, i + 8, i + 16, ... of a run of 8 ny consecutive workgroups are the ny column tiles of ONE row block (or half),
 // so its activation strip ([TM x K]: 270 KB at K = 528) is fetched from HBM once and hit in that L2 by the others (with the
-// row block as the fastest index the strip came from HBM once per column tile: round 4).  The last, partial
+// row block as the fastest index the strip came from HBM once per column tile: round 4, profiles/HISTORY.md 3b).  The last, partial
 // run keeps the plain order.
 struct WideTiling { int ny, mbs, n_full_rb, n_rb; };
 __device__ __forceinline__ void wide_run_order(int lin, int n_units, int ny, int& unit, int& nb) {
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void k_wide_wgrad(WideWgradArgs a) {
 // per-node weights a layer is [K tiles x slots] workgroups of a quarter million MFMA cycles each and a launch holds about two
 // of them per CU: 500 workgroups on 256 CUs, every launch as long as its fullest CU -- and the launches of L stages, Dense-0
 // and the embed layer each pay that rounding on their own.  As roles of one grid (heaviest first; a 1-D grid cut by
-// `start`) the chip is handed 5-6 workgroups per CU to balance: configs[3] share 3 x 298 + 114 + 59 us -> see DESIGN.md 3b.
+// `start`) the chip is handed 5-6 workgroups per CU to balance: configs[3] share 3 x 298 + 114 + 59 us -> see profiles/HISTORY.md 3b.
 constexpr int WWM_ROLES = 6;
 enum { WWM_128x16 = 0, WWM_128x8 = 1, WWM_128x5 = 2, WWM_64x4 = 3 };
 struct WideWgradMulti {
@@ -778,7 +778,7 @@ __global__ __launch_bounds__(256) void k_adj_masks(AggDenseArgs a) {
 // LDS layout of the [rows][64] feature tile: NO padding, row r is rotated by 16 (r & 3) floats instead -- the four
 // k-groups of a wave (rows 4 s + kg of a k-step) then hit disjoint quarters of the 64 banks exactly as the 80-float row
 // stride of round 2 made them, float4 accesses stay aligned, and a graph of 100 / 128 links takes 34 / 39 KB instead of
-// 41 / 46: FOUR workgroups per CU instead of three.  These launches are latency chains per workgroup: the
+// 41 / 46: FOUR workgroups per CU instead of three.  These launches are latency chains per workgroup (profiles/HISTORY.md 3b): the
 // fourth resident workgroup is worth 73.2 -> 59.3 / 96.8 -> 80.0 us at configs[3] and 30.7 -> 26.7 / 41.4 -> 36.8 us at configs[4].
 constexpr int AD_LDT = 64;
 __device__ __forceinline__ int ad_off(int row, int col) { return row * AD_LDT + ((col + ((row & 3) << 4)) & 63); }

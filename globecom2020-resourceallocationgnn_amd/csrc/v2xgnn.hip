@@ -692,6 +692,9 @@ int launch_wide_gemm(v2x_model* m, hipStream_t st, WideGemmArgs& a, int grid_z, 
   t.n_full_rb = t.n_rb;
   const int T = t.n_rb * t.ny, C = 5 * n_cus(), rem = T % C;
   if (tail && T > C && rem > 0 && 4 * rem < 3 * C) t.n_full_rb = t.n_rb - rem / t.ny;
+  // a launch that does not fill the chip's resident slots at all (Dense-0 at configs[3]'s share: 800 tiles of 128 x 80 on 1,280
+  // slots, three workgroups per CU instead of five): every row block as two half tiles (V2X_WIDE_TAIL=2 only: measured)
+  if (tail == 2 && T < C && 2 * T > C) t.n_full_rb = 0;
   const dim3 grid(t.n_full_rb * t.ny + 2 * (t.n_rb - t.n_full_rb) * t.ny);
 #define V2X_WIDE_GEMM(T_, NTV) { auto k = k_wide_gemm<T_, NTV>; ProfRec _r; const bool _p = m->prof && !m->capturing;                      \
     if (_p) { _r.id = prof_id(m, name); hipEventCreate(&_r.ev0); hipEventCreate(&_r.ev1); hipEventRecord(_r.ev0, st); }                     \

@@ -1448,7 +1448,7 @@ bool frag_layout(const v2x_model* m, const DevBatch& d, Range r) {
 }
 
 int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_out = false) {
-  static const int split_fwd = env_int("V2X_FUSED_SPLIT_FWD", 1);
+  static const int split_fwd = env_int("V2X_FUSED_SPLIT_FWD", 1);      // (debugging: one direction on whole tiles)
   // The copy follows the parameters by itself: Adam writes both (k_reduce_adam / pack_scatter), set / copy_weights
   // re-pack eagerly.  Only a caller that took the raw parameter pointer (v2x_param_ptr) forces a re-pack per forward.
   if (m->pk_stale) { CHK(launch_pack(m, st)); m->pk_stale = m->raw_params; }
@@ -1481,7 +1481,10 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_
     return rc;
   }
   const dim3 grid(tiles);
-  a.compl_sums = fused_compl(m, d) ? 1 : 0;
+  // (a batch the split-tile kernels are picked for runs the edge form in BOTH directions, also when a debugging switch keeps one
+  //  of them on whole tiles: the two kernels hand the rows' IN-neighbour sets over, the complement form would read them as
+  //  non-neighbour sets)
+  a.compl_sums = (fused_split(m, d) <= 1 && fused_compl(m, d)) ? 1 : 0;
   const size_t lds = fused_lds(m, d, false, a.compl_sums != 0);
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
 #define V2X_FZ_FWD(FF, SP)                                                                                            \
@@ -1502,8 +1505,7 @@ int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_
 }
 
 int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
-  static const int split_bwd = env_int("V2X_FUSED_SPLIT_BWD", 1), split_fwd_only = 0;
-  (void)split_fwd_only;
+  static const int split_bwd = env_int("V2X_FUSED_SPLIT_BWD", 1);      // (debugging: one direction on whole tiles)
   FusedBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.row_ptr = d.rp; a.col_idx = d.ci; a.pk = m->pk_bwd; a.gha = m->gha;
@@ -1534,7 +1536,10 @@ int launch_fused_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
     return rc;
   }
   const dim3 grid(tiles);
-  a.compl_sums = fused_compl(m, d) ? 1 : 0;
+  // (a batch the split-tile kernels are picked for runs the edge form in BOTH directions, also when a debugging switch keeps one
+  //  of them on whole tiles: the two kernels hand the rows' IN-neighbour sets over, the complement form would read them as
+  //  non-neighbour sets)
+  a.compl_sums = (fused_split(m, d) <= 1 && fused_compl(m, d)) ? 1 : 0;
   const size_t lds = fused_lds(m, d, true, a.compl_sums != 0);
   const int spw = (m->N + FZ_WAVES - 1) / FZ_WAVES;
 #define V2X_FZ_BWD(FF, SP)                                                                                            \

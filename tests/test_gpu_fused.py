@@ -225,6 +225,14 @@ def test_split_tiles_hipgraph_replay_and_mixed_batch_sizes():
         for _ in range(3):
             eager.train_step(pb, y)
     assert np.array_equal(eager.get_flat(), graph.get_flat())
+    # re-arming the exchange (v2x_reset_exchange: tags and departure counters back to zero) leaves a working exchange behind
+    graph.reset_exchange()
+    pb, y = batches[1]
+    with torch.cuda.stream(torch.cuda.Stream()):
+        graph.train_step(graph.to_device(pb), torch.from_numpy(y).cuda())
+        torch.cuda.synchronize()
+    eager.train_step(pb, y)
+    assert np.array_equal(eager.get_flat(), graph.get_flat())
     eager.close(); graph.close()
 
 

@@ -9,6 +9,7 @@
 #include "kernels_mlpwg.hpp"
 #include "kernels_small.hpp"
 #include "kernels_ragged.hpp"
+#include "kernels_ragged_small.hpp"
 #include "host_pack.hpp"
 
 #include <hip/hip_runtime.h>
@@ -86,6 +87,7 @@ struct v2x_model {
   bool pk_stale = false;                        // the fragment-major copy must be rebuilt before the next fused forward
   bool compl_sums = true;                       // V2X_FUSED_COMPL (read at create): dense graphs aggregate through the complement
   bool ragged_fused = true, ragged_fused_bwd = true;   // V2X_RAGGED_FUSED / V2X_RAGGED_FUSED_BWD (read at create): kernels_ragged.hpp
+  bool ragged_small_env = false; // V2X_RAGGED_SMALL (read at create): the small-tile ragged kernels (kernels_ragged_small.hpp)
   bool ragged_packed = true;    // V2X_RAGGED_PACKED: tiles packed by k_ragged_plan (0: the row-interval plan of k_adj_masks)
   bool ragged_plan_fold = true; // V2X_RAGGED_PLAN_FOLD: the packed plan as a workgroup of the mask launch when its tables are small
   bool small_predict = true;                    // V2X_SMALL_PREDICT (read at create): few-graph forwards in one launch (kernels_small.hpp)
@@ -1599,12 +1601,20 @@ bool ragged_fused_path(const v2x_model* m, const DevBatch& d) {
          d.max_nodes <= RG_CAP / 2;
 }
 bool need_adj_masks(const v2x_model* m, const DevBatch& d) { return use_dense_agg(d, m->F) || ragged_fused_path(m, d); }
-int ragged_capp(const DevBatch& d) { return RG_CAP - d.max_nodes + 1; }
-int ragged_wgs(const DevBatch& d) { return (d.R + ragged_capp(d) - 1) / ragged_capp(d); }
+// Small tiles (kernels_ragged_small.hpp: 160-row tiles, 4-wave workgroups, weights as fragments from L2, three workgroups per
+// CU): built and measured in round 5 -- forward 123 us against 101, backward 161 against 103 at configs[4]'s share, + 19 us for
+// the plan as a launch of its own (profiles/r05_ragged_small_ab.txt) -- so OFF unless V2X_RAGGED_SMALL=1 (read at create too:
+// the fragment-major copy of a ragged model's weights is only kept then)
+bool ragged_small(const v2x_model* m, const DevBatch& d) {
+  return m->ragged_small_env && m->pk_fwd && m->pk_bwd && d.max_nodes <= 128 && m->L >= 1;
+}
+int ragged_cap(const v2x_model* m, const DevBatch& d) { return ragged_small(m, d) ? RGS_CAP : RG_CAP; }
+int ragged_capp(const v2x_model* m, const DevBatch& d) { return ragged_cap(m, d) - d.max_nodes + 1; }
+int ragged_wgs(const v2x_model* m, const DevBatch& d) { return (d.R + ragged_capp(m, d) - 1) / ragged_capp(m, d); }
 
 // k_ragged_plan's tables in LDS; past that (tens of thousands of graphs in one batch) the interval plan of k_adj_masks
-int ragged_plan_words(const DevBatch& d) { return 3 * (d.B + 1) + ragged_wgs(d) + 1; }
-bool ragged_packed_plan(const v2x_model* m, const DevBatch& d) { return m->ragged_packed && ragged_plan_words(d) <= RG_PLAN_LDS_WORDS; }
+int ragged_plan_words(const v2x_model* m, const DevBatch& d) { return 3 * (d.B + 1) + ragged_wgs(m, d) + 1; }
+bool ragged_packed_plan(const v2x_model* m, const DevBatch& d) { return m->ragged_packed && ragged_plan_words(m, d) <= RG_PLAN_LDS_WORDS; }
 
 template <int F>
 int launch_ragged_fwd_f(v2x_model* m, hipStream_t st, const RaggedFwdArgs& a, int n_wgs) {
@@ -1612,6 +1622,18 @@ int launch_ragged_fwd_f(v2x_model* m, hipStream_t st, const RaggedFwdArgs& a, in
   static const bool once = [] { allow_big_lds((const void*)k_gnn_fwd_ragged<F>); return true; }();
   (void)once;
   LAUNCH_T(m, "k_gnn_fwd_ragged", k, dim3(n_wgs), RG_THREADS, (size_t)RaggedLds<F>::TOTAL * 4, st, a);
+  return V2X_OK;
+}
+
+template <int F, bool BWD, typename Args>
+int launch_ragged_small_f(v2x_model* m, hipStream_t st, const Args& a, int n_wgs) {
+  if constexpr (BWD) {
+    auto k = k_gnn_bwd_ragged_s<F>;
+    LAUNCH_T(m, "k_gnn_bwd_ragged", k, dim3(n_wgs), RGS_THREADS, (size_t)RaggedSmallBwdLds<F>::TOTAL * 4, st, a);
+  } else {
+    auto k = k_gnn_fwd_ragged_s<F>;
+    LAUNCH_T(m, "k_gnn_fwd_ragged", k, dim3(n_wgs), RGS_THREADS, (size_t)RaggedSmallLds<F>::TOTAL * 4, st, a);
+  }
   return V2X_OK;
 }
 
@@ -1623,9 +1645,18 @@ int launch_ragged_fwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   a.adjT = (const unsigned*)m->adj_mask.p + (size_t)d.R * a.mask_words;
   a.plan = (const int32_t*)m->plan_buf.p;
   for (int s = 0; s <= m->L; ++s) { a.W[s] = m->params + m->gnn[s].off; a.h[s] = m->h[s]; a.a[s] = m->a[s]; }
-  a.n_graphs = d.B; a.n_rows = d.R; a.L = m->L; a.capp = ragged_capp(d); a.xr = m->Dn + m->De; a.err = m->flag_dev;
+  a.n_graphs = d.B; a.n_rows = d.R; a.L = m->L; a.capp = ragged_capp(m, d); a.xr = m->Dn + m->De; a.err = m->flag_dev;
   a.ts = m->ts_buf;
-  const int n_wgs = ragged_wgs(d);
+  const int n_wgs = ragged_wgs(m, d);
+  if (ragged_small(m, d)) {                             // 160-row tiles, weights as fragments from L2 (kernels_ragged_small.hpp)
+    if (m->pk_stale) { CHK(launch_pack(m, st)); m->pk_stale = m->raw_params; }
+    RaggedSmallFwdArgs sa{a, m->pk_fwd};
+    switch (m->F) {
+      case 16: return launch_ragged_small_f<16, false>(m, st, sa, n_wgs);
+      case 32: return launch_ragged_small_f<32, false>(m, st, sa, n_wgs);
+      case 64: return launch_ragged_small_f<64, false>(m, st, sa, n_wgs);
+    }
+  }
   switch (m->F) {
     case 16: return launch_ragged_fwd_f<16>(m, st, a, n_wgs);
     case 32: return launch_ragged_fwd_f<32>(m, st, a, n_wgs);
@@ -1652,8 +1683,16 @@ int launch_ragged_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   a.adj = (const unsigned*)m->adj_mask.p;
   a.plan = (const int32_t*)m->plan_buf.p;
   for (int s = 0; s <= m->L; ++s) { a.W[s] = m->params + m->gnn[s].off; a.h[s] = m->h[s]; a.dpre[s] = m->dpre[s]; }
-  a.n_graphs = d.B; a.n_rows = d.R; a.L = m->L; a.capp = ragged_capp(d); a.xr = m->Dn + m->De; a.err = m->flag_dev;
-  const int n_wgs = ragged_wgs(d);
+  a.n_graphs = d.B; a.n_rows = d.R; a.L = m->L; a.capp = ragged_capp(m, d); a.xr = m->Dn + m->De; a.err = m->flag_dev;
+  const int n_wgs = ragged_wgs(m, d);
+  if (ragged_small(m, d)) {
+    RaggedSmallBwdArgs sa{a, m->pk_bwd};
+    switch (m->F) {
+      case 16: return launch_ragged_small_f<16, true>(m, st, sa, n_wgs);
+      case 32: return launch_ragged_small_f<32, true>(m, st, sa, n_wgs);
+      case 64: return launch_ragged_small_f<64, true>(m, st, sa, n_wgs);
+    }
+  }
   switch (m->F) {
     case 16: return launch_ragged_bwd_f<16>(m, st, a, n_wgs);
     case 32: return launch_ragged_bwd_f<32>(m, st, a, n_wgs);
@@ -1676,20 +1715,20 @@ int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool w
       q.adjT = q.adj + (size_t)d.R * q.mask_words;
       q.err = m->flag_dev;
       const bool packed = ragged && ragged_packed_plan(m, d);
-      if (ragged) m->plan_len = ragged_wgs(d) + 1;
-      if (ragged && !packed) { q.plan = (int32_t*)m->plan_buf.p; q.plan_capp = ragged_capp(d); q.plan_n = ragged_wgs(d); }
+      if (ragged) m->plan_len = ragged_wgs(m, d) + 1;
+      if (ragged && !packed) { q.plan = (int32_t*)m->plan_buf.p; q.plan_capp = ragged_capp(m, d); q.plan_n = ragged_wgs(m, d); }
       // the packed plan by workgroup 0 of the mask launch while its offsets + 16-bit tables leave the mask workgroups their
       // eight per CU (<= 19 KB of LDS: ~2,200 graphs); a launch of its own (k_ragged_plan, 32-bit tables) beyond
-      const bool folded = packed && m->ragged_plan_fold && d.B < 65000 && plan16_bytes(d.B, ragged_wgs(d)) <= 19 * 1024;
-      if (folded) { q.plan = (int32_t*)m->plan_buf.p; q.plan_cap = RG_CAP; q.plan_n = ragged_wgs(d); }
+      const bool folded = packed && m->ragged_plan_fold && d.B < 65000 && plan16_bytes(d.B, ragged_wgs(m, d)) <= 19 * 1024;
+      if (folded) { q.plan = (int32_t*)m->plan_buf.p; q.plan_cap = ragged_cap(m, d); q.plan_n = ragged_wgs(m, d); }
       // (the plan reads the offsets, the masks the CSR: independent -- but as a forked branch of the captured step the two
       //  cost MORE than one after the other: 0.466 against 0.455 ms per configs[4] step, the graph's cross-branch
       //  dependencies outweigh the 5 us the plan takes)
       if (packed && !folded) {
         static const bool once = [] { allow_big_lds((const void*)k_ragged_plan); return true; }();
         (void)once;
-        RaggedPlanArgs pa{d.goff, (int32_t*)m->plan_buf.p, d.B, ragged_wgs(d), RG_CAP};
-        LAUNCH_T(m, "k_ragged_plan", k_ragged_plan, dim3(1), RG_PLAN_THREADS, (size_t)ragged_plan_words(d) * 4, st, pa);
+        RaggedPlanArgs pa{d.goff, (int32_t*)m->plan_buf.p, d.B, ragged_wgs(m, d), ragged_cap(m, d)};
+        LAUNCH_T(m, "k_ragged_plan", k_ragged_plan, dim3(1), RG_PLAN_THREADS, (size_t)ragged_plan_words(m, d) * 4, st, pa);
       }
       CHK(build_adj_masks(m, st, q));
     }
@@ -1879,7 +1918,7 @@ int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
 int presize(v2x_model* m, const DevBatch& d) {
   CHK(ensure_rows(m, d.R));
   if (need_adj_masks(m, d)) CHK(ensure(m, m->adj_mask, (size_t)2 * d.R * ((d.max_nodes + 31) / 32) * 4));
-  if (ragged_fused_path(m, d)) CHK(ensure(m, m->plan_buf, (size_t)(ragged_wgs(d) + 2) * 4));
+  if (ragged_fused_path(m, d)) CHK(ensure(m, m->plan_buf, (size_t)(ragged_wgs(m, d) + 2) * 4));
   if (fused_split(m, d) > 1) CHK(ensure_xchg(m, (d.B + FZ_TG - 1) / FZ_TG));
   const IdxMap x = idx_map(m, d, Range{0, d.B});
   CHK(ensure_slabs(m, max_slabs(m, x.n_idx, x.grid_y)));
@@ -1970,6 +2009,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
   m->ragged_fused = env_int("V2X_RAGGED_FUSED", 1) != 0;
   m->ragged_fused_bwd = env_int("V2X_RAGGED_FUSED_BWD", 1) != 0;
   m->ragged_packed = env_int("V2X_RAGGED_PACKED", 1) != 0;
+  m->ragged_small_env = env_int("V2X_RAGGED_SMALL", 0) != 0;
   m->ragged_plan_fold = env_int("V2X_RAGGED_PLAN_FOLD", 1) != 0;
   if (m->small_predict && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
     const size_t hb = (size_t)(m->L + 1) * SMALL_ROWS * m->F * sizeof(unsigned long long), sb = (size_t)2 * SMALL_ROWS * sizeof(unsigned);
@@ -1988,7 +2028,8 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     }
     if (hipMemset(m->small_sync, 0, (size_t)2 * SMALL_ROWS * sizeof(unsigned))) return fail("memset");
   }
-  if (env_int("V2X_FUSED", 1) != 0 && !m->cfg.variable_graphs && m->F <= 64 && m->L <= FZ_MAXL) {
+  // (ragged models with shared weights stream the same copy in their small-tile kernels, kernels_ragged_small.hpp)
+  if (env_int("V2X_FUSED", 1) != 0 && (!m->cfg.variable_graphs || (m->S == 1 && m->ragged_small_env)) && m->F <= 64 && m->L <= FZ_MAXL) {
     const int FB = m->F / 16, KB = 2 * FB + 1;
     const size_t fwd0 = (size_t)FB * 256 + m->F, fwd = (size_t)KB * FB * 256 + m->F, bwd = (size_t)FB * 2 * FB * 256;
     if (dev_alloc(m, &m->pk_fwd, (size_t)m->S * fwd0 + (size_t)m->L * m->S * fwd) || dev_alloc(m, &m->pk_bwd, (size_t)m->L * m->S * bwd))

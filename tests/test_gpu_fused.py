@@ -394,6 +394,33 @@ RAGGED = [  # feat_dim, layers, topology, sizes
 ]
 
 
+@pytest.mark.parametrize("F,L,kind,sizes", RAGGED[:4])
+def test_ragged_small_tiles_equal_large_tiles_bitwise(F, L, kind, sizes):
+    """csrc/kernels_ragged_small.hpp (round 5, opt-in: V2X_RAGGED_SMALL=1 -- measured slower, kept as the measured alternative):
+    160-row tiles in 4-wave workgroups with the weights streamed from L2 as MFMA fragments against the 320-row tiles with the
+    weight image in LDS.  A row's arithmetic does not depend on the tile it sits in: q, losses and gradients bit for bit."""
+    rng = np.random.default_rng(70 * F + L + len(sizes))
+    spec = GnnSpec(n_nodes=1, feat_dim=F, n_mp_layers=L, share_weights=True, variable_graphs=True)
+    pb, x, e, offs = _ragged_batch(rng, [int(n) for n in sizes], kind)
+    P = f32_params(spec, rng)
+    large = _engine(spec, oc.params_to_list(P), True)
+    os.environ["V2X_RAGGED_SMALL"] = "1"
+    try:
+        small = _engine(spec, oc.params_to_list(P), True)
+        ql, qs = large.forward(pb), small.forward(pb)
+        assert np.array_equal(ql, qs), np.abs(ql - qs).max()
+        y = (ql + rng.normal(0, 1.2, size=ql.shape)).astype(np.float32)
+        ll, ls = large.forward_backward(pb, y, n_global=pb.n_rows), small.forward_backward(pb, y, n_global=pb.n_rows)
+        assert np.array_equal(ll, ls) and np.array_equal(large.get_grad_flat(), small.get_grad_flat())
+        for _ in range(3):                   # the fragment-major copy follows the parameters (Adam writes both)
+            large.train_step(pb, y, n_global=pb.n_rows)
+            small.train_step(pb, y, n_global=pb.n_rows)
+        assert np.array_equal(large.get_flat(), small.get_flat()) and np.array_equal(large.forward(pb), small.forward(pb))
+    finally:
+        del os.environ["V2X_RAGGED_SMALL"]
+    large.close(); small.close()
+
+
 @pytest.mark.parametrize("F,L,kind,sizes", RAGGED)
 def test_ragged_fused_layers_vs_layerwise_and_oracle(F, L, kind, sizes):
     """csrc/kernels_ragged.hpp: variable-size graphs with shared weights run embed + L stages + L + 1

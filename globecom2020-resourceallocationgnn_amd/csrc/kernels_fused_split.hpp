@@ -10,9 +10,12 @@
 //
 // The hand-over is the rollout kernel's (kernels_small.hpp, MI355X_MICROARCH.md "handoff-1to1"): rows travel as 8-byte
 // {value, tag} words written and read with relaxed agent-scope atomics (global_store / global_load ... sc1), tag = 16 * epoch +
-// stage code; a consumer polls the words THEMSELVES, no flag, no fence, no cache maintenance.  epoch = departures of the tile's
-// members so far / K (every member adds one when it leaves), so it is the same for all members of a launch, one more in the
-// next, and correct under hipGraph replay.  One slab per stage: a member that runs ahead never overwrites a row a slower
+// stage code; a consumer polls the words THEMSELVES, no flag, no fence, no cache maintenance.  epoch = the tile's launch count:
+// member 0 adds one when it leaves (it cannot leave before every partner has published its last rows, i.e. has read the
+// count), so the epoch is the same for all members of a launch, STRICTLY larger in the next one whatever K that one runs
+// with, and correct under hipGraph replay.  (The first version counted departures and divided by K: a tile that is visited by
+// launches of different K -- batches of 1200, then 300 graphs -- repeated an epoch, and a member could take a stale row of the
+// earlier launch for a fresh one: a 1-in-6 failure of tests/test_gpu_model.py::test_graph_cache_survives_workspace_growth.)  One slab per stage: a member that runs ahead never overwrites a row a slower
 // member still needs.  Members of a tile sit on one XCD (block b runs on XCD b % 8 -- speed only, never correctness).
 // Every poll is bounded (SM_POLL_CAP): a member whose partners never arrive raises FZ_ERR_XCHG and runs to its end.
 //
@@ -50,7 +53,7 @@ constexpr int FZ_ERR_XCHG = 1 << 9;                  // flag word: a split-tile 
 
 struct FzXchg {
   unsigned long long* buf;                           // [slab][cap_tiles][N][FB][64 lanes][4] tagged words
-  unsigned long long* sync;                          // [cap_tiles] departures of the tiles' members (64-bit: never wraps)
+  unsigned long long* sync;                          // [cap_tiles] launches that visited the tile (64-bit: never wraps), from a process-wide base
   int cap_tiles;                                     // tiles per slab
   int K;                                             // members per tile
 };
@@ -220,8 +223,8 @@ __device__ __forceinline__ void fused_fwd_split_body(const FusedFwdArgs& a, cons
   FzStampR<TS> ts(a.ts, wv, lane, 8);
   ts.mark();                                                     // 0: start
 
-  // this launch's epoch of the tile (the same for all members: nobody can have left before everybody has published)
-  const unsigned epoch16 = 16u * (unsigned)((__hip_atomic_load(xg.sync + x.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned long long)K) & 0x0fffffffull);
+  // this launch's epoch of the tile = its launch count (member 0 advances it when it leaves: not before everybody has published)
+  const unsigned epoch16 = 16u * (unsigned)(__hip_atomic_load(xg.sync + x.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x0fffffffull);
   auto slab_tile = [&](int slab) { return xg.buf + ((int64_t)slab * xg.cap_tiles + x.tile) * ((int64_t)N * FB * 256); };
 
   const int64_t rowk = (int64_t)(x.g0 + jc) * N + k;
@@ -269,7 +272,7 @@ __device__ __forceinline__ void fused_fwd_split_body(const FusedFwdArgs& a, cons
   const int e_begin = a.row_ptr[r_begin], nedges = a.row_ptr[r_begin + nrows] - e_begin;
   if (nedges > a.edges_cap || nedges < 0) {                      // workgroup-uniform, before any barrier.  (The partners see the
     if (threadIdx.x == 0 && a.err) atomicOr(a.err, 1);           //  same slice and leave as well: nobody waits for anybody.)
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(xg.sync + x.tile, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0 && x.m == 0) __hip_atomic_fetch_add(xg.sync + x.tile, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   csr_commit(csr, a.row_ptr, a.col_idx, x.sRp, x.sCol, N, r_begin, nrows, e_begin, nedges);
@@ -460,8 +463,8 @@ __device__ __forceinline__ void fused_fwd_split_body(const FusedFwdArgs& a, cons
     }
   }
   ts.mark();                                                     // end (stores issued)
-  // one more departure (the next launch's epoch); nobody waits for the add
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(xg.sync + x.tile, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // member 0: the next launch's epoch; nobody waits for the add
+  if (threadIdx.x == 0 && x.m == 0) __hip_atomic_fetch_add(xg.sync + x.tile, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // a member owns at most 8 slots (host: ceil(N / K) <= 8): one per wave
@@ -505,7 +508,7 @@ __device__ __forceinline__ void fused_bwd_split_body(const FusedBwdArgs& a, cons
   constexpr int FB = P::FB, ROWF = P::ROWF;
   const int N = x.N, lane = x.lane, wv = x.wv, kg = x.kg, jc = x.jc, K = x.K;
   const int k = HAS ? x.m + K * wv : 0;
-  const unsigned epoch16 = 16u * (unsigned)((__hip_atomic_load(xg.sync + x.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (unsigned long long)K) & 0x0fffffffull);
+  const unsigned epoch16 = 16u * (unsigned)(__hip_atomic_load(xg.sync + x.tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0x0fffffffull);
   auto slab_tile = [&](int slab) { return xg.buf + ((int64_t)slab * xg.cap_tiles + x.tile) * ((int64_t)N * FB * 256); };
   FzStampR<TS> ts(a.ts ? a.ts + 512 : nullptr, wv, lane, 8);
   ts.mark();                                                     // 0: start
@@ -654,7 +657,7 @@ __device__ __forceinline__ void fused_bwd_split_body(const FusedBwdArgs& a, cons
     ts.mark();                                                   // stage: barrier
   }
   ts.mark();                                                     // end
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(xg.sync + x.tile, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0 && x.m == 0) __hip_atomic_fetch_add(xg.sync + x.tile, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int F, int L, bool TS = false>

@@ -385,6 +385,8 @@ FlagWord* global_flag() {            // the per-kernel entry points that take no
 int* flag_dev_of(v2x_model* m) { return m ? m->flag_dev : global_flag()->dev; }
 
 // the one-launch predict's exchange buffer and departure counters back to their initial state (synchronous)
+int arm_xchg(v2x_model* m, int tiles, unsigned long long floor);
+int xchg_max_count(v2x_model* m, unsigned long long* out);
 size_t xchg_bytes(const v2x_model* m, int tiles) {
   return (size_t)std::max(1, 2 * m->L) * tiles * m->N * (m->F / 16) * 256 * sizeof(unsigned long long);
 }
@@ -396,8 +398,9 @@ int reset_exchange(v2x_model* m) {
     HIPCHK(m, hipMemset(m->small_sync, 0, (size_t)256 * sizeof(unsigned long long)));
   }
   if (m->xchg_buf) {
-    HIPCHK(m, hipMemset(m->xchg_buf, 0, xchg_bytes(m, m->xchg_cap_tiles)));
-    HIPCHK(m, hipMemset(m->xchg_sync, 0, (size_t)m->xchg_cap_tiles * sizeof(unsigned long long)));
+    unsigned long long seen = 0;
+    CHK(xchg_max_count(m, &seen));
+    CHK(arm_xchg(m, m->xchg_cap_tiles, seen + 2));          // (+ 2: a launch that died half-way may not have advanced its tiles)
   }
   return V2X_OK;
 }
@@ -1392,19 +1395,39 @@ int fused_split(const v2x_model* m, const DevBatch& d) {
     if (4 * k <= m->N && fits(k)) return k;
   return 1;
 }
+// The launch counters of a (re)allocated or re-armed exchange start at a value no counter of this process has had: tags must
+// never repeat at an address, also not across buffers (a freed buffer's address is handed out again) or across a re-arm.
+unsigned long long g_xchg_epoch_next = 1;
+int arm_xchg(v2x_model* m, int tiles, unsigned long long floor) {
+  g_xchg_epoch_next = std::max(g_xchg_epoch_next, floor);
+  std::vector<unsigned long long> init((size_t)tiles, g_xchg_epoch_next);
+  g_xchg_epoch_next += 1ull << 16;
+  HIPCHK(m, hipMemset(m->xchg_buf, 0, xchg_bytes(m, tiles)));                 // tag 0 = never written
+  HIPCHK(m, hipMemcpy(m->xchg_sync, init.data(), (size_t)tiles * sizeof(unsigned long long), hipMemcpyHostToDevice));
+  HIPCHK(m, hipDeviceSynchronize());
+  return V2X_OK;
+}
+int xchg_max_count(v2x_model* m, unsigned long long* out) {
+  *out = 0;
+  if (!m->xchg_sync || m->xchg_cap_tiles <= 0) return V2X_OK;
+  std::vector<unsigned long long> cur((size_t)m->xchg_cap_tiles);
+  HIPCHK(m, hipMemcpy(cur.data(), m->xchg_sync, cur.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  for (unsigned long long v : cur) *out = std::max(*out, v);
+  return V2X_OK;
+}
 int ensure_xchg(v2x_model* m, int tiles) {
   if (tiles <= m->xchg_cap_tiles) return V2X_OK;
   if (m->capturing) FAIL(m, V2X_ESTATE, "exchange buffer growth during graph capture");
   drop_graphs(m);
   HIPCHK(m, hipDeviceSynchronize());
+  unsigned long long seen = 0;
+  CHK(xchg_max_count(m, &seen));
   if (m->xchg_buf) HIPCHK(m, hipFree(m->xchg_buf));
   if (m->xchg_sync) HIPCHK(m, hipFree(m->xchg_sync));
   m->xchg_buf = nullptr; m->xchg_sync = nullptr; m->xchg_cap_tiles = 0;
   HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->xchg_buf), xchg_bytes(m, tiles)));
   HIPCHK(m, hipMalloc(reinterpret_cast<void**>(&m->xchg_sync), (size_t)tiles * sizeof(unsigned long long)));
-  HIPCHK(m, hipMemset(m->xchg_buf, 0, xchg_bytes(m, tiles)));                 // tag 0 = never written
-  HIPCHK(m, hipMemset(m->xchg_sync, 0, (size_t)tiles * sizeof(unsigned long long)));
-  HIPCHK(m, hipDeviceSynchronize());
+  CHK(arm_xchg(m, tiles, seen + 1));
   m->xchg_cap_tiles = tiles;
   return V2X_OK;
 }

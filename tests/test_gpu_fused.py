@@ -236,6 +236,38 @@ def test_split_tiles_hipgraph_replay_and_mixed_batch_sizes():
     eager.close(); graph.close()
 
 
+def test_split_tiles_alternating_members_per_tile():
+    """A tile that is visited by launches of DIFFERENT K (1200 graphs: 3 workgroups per tile, 300 graphs: 5) must never see
+    an epoch twice: round 5's first exchange counted the members' departures and divided by K, which repeated an epoch in
+    exactly this sequence and let a member take a stale row of the earlier launch for a fresh one (a 1-in-6 failure of
+    test_graph_cache_survives_workspace_growth).  Forward + forward_backward alternate between the two sizes for many
+    rounds; every q, loss and gradient bit for bit the whole-tile engine's."""
+    import torch
+    N, F = 20, 64
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(23)
+    weights = oc.params_to_list(f32_params(spec, rng))
+    split, whole = _engine(spec, weights, True, use_graph=True), _engine(spec, weights, True, split=0)
+    data = {}
+    for B in (1200, 300):
+        x, e, adj = random_inputs(rng, B, N)
+        y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+        pb = PackedBatch.from_dense(x, e, adj)
+        data[B] = (pb, y, whole.forward(pb), whole.forward_backward(pb, y).copy(), whole.get_grad_flat().copy())
+    assert split.path_info(data[1200][0])["graph_layers"] == "fused(split3)" and split.path_info(data[300][0])["graph_layers"] == "fused(split5)"
+    with torch.cuda.stream(torch.cuda.Stream()):
+        dev = {B: (split.to_device(data[B][0]), torch.from_numpy(data[B][1]).cuda()) for B in data}
+        for it in range(60):
+            B = (1200, 300)[it % 2] if it % 7 else 300
+            db, yd = dev[B]
+            q = split.forward(db)
+            loss = split.forward_backward(db, yd)
+            torch.cuda.synchronize()
+            assert np.array_equal(q.cpu().numpy(), data[B][2]), (it, B)
+            assert np.array_equal(loss.cpu().numpy(), data[B][3]) and np.array_equal(split.get_grad_flat(), data[B][4]), (it, B)
+    split.close(); whole.close()
+
+
 def test_fused_hipgraph_replay_is_bitwise_eager():
     import torch
     N, F, B = 20, 64, 48

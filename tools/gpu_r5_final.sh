@@ -51,7 +51,9 @@ for wl in cfg4 cfg5; do
   for d in fetch write mfma; do python tools/rocpd_summary.py $(db $O/${d}_$wl) > $O/${d}_$wl.txt 2>&1; done
   python tools/roofline_table2.py $O/bench_$wl.json $O/fetch_$wl.txt $O/write_$wl.txt $O/mfma_$wl.txt > $O/roofline_$wl.md 2>&1
 done
-bash tools/wide_tail_ab.sh > $O/wide_tail_ab.txt 2>&1
+bash tools/wide_tail_ab.sh 2>&1 | cut -c1-330 > $O/wide_tail_ab.txt
+bash tools/ragged_small_ab.sh > $O/ragged_small_ab.txt 2>&1
+SOAK_STEPS=90000 python tools/soak_split.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/soak_split.txt
 python tools/prof_rl_sections.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 > $O/rl_sections.txt
 python bench.py --workload cfg0 --envs 10 > $O/bench_cfg0_episode_envs10.json 2>/dev/null
 for i in 1 2 3; do python bench.py --workload cfg2loop --envs 50 --episodes 5 > $O/bench_cfg2loop_envs50_run$i.json 2>/dev/null; done

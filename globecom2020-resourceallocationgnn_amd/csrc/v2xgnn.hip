@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1398,10 +1399,16 @@ int fused_split(const v2x_model* m, const DevBatch& d) {
 // The launch counters of a (re)allocated or re-armed exchange start at a value no counter of this process has had: tags must
 // never repeat at an address, also not across buffers (a freed buffer's address is handed out again) or across a re-arm.
 unsigned long long g_xchg_epoch_next = 1;
+std::mutex g_xchg_epoch_mutex;                       // (models may be created from several host threads)
 int arm_xchg(v2x_model* m, int tiles, unsigned long long floor) {
-  g_xchg_epoch_next = std::max(g_xchg_epoch_next, floor);
-  std::vector<unsigned long long> init((size_t)tiles, g_xchg_epoch_next);
-  g_xchg_epoch_next += 1ull << 16;
+  unsigned long long base;
+  {
+    std::lock_guard<std::mutex> lock(g_xchg_epoch_mutex);
+    g_xchg_epoch_next = std::max(g_xchg_epoch_next, floor);
+    base = g_xchg_epoch_next;
+    g_xchg_epoch_next += 1ull << 16;
+  }
+  std::vector<unsigned long long> init((size_t)tiles, base);
   HIPCHK(m, hipMemset(m->xchg_buf, 0, xchg_bytes(m, tiles)));                 // tag 0 = never written
   HIPCHK(m, hipMemcpy(m->xchg_sync, init.data(), (size_t)tiles * sizeof(unsigned long long), hipMemcpyHostToDevice));
   HIPCHK(m, hipDeviceSynchronize());

@@ -2106,6 +2106,13 @@ void v2x_destroy(v2x_model* m) {
   if (m->flag_host) hipHostFree(m->flag_host);
   if (m->ts_buf) hipFree(m->ts_buf);
   if (m->small_h) hipFree(m->small_h);
+  if (m->xchg_sync) {                  // the process-wide epoch base moves past everything this buffer's address has seen
+    unsigned long long seen = 0;
+    if (xchg_max_count(m, &seen) == V2X_OK) {
+      std::lock_guard<std::mutex> lock(g_xchg_epoch_mutex);
+      g_xchg_epoch_next = std::max(g_xchg_epoch_next, seen + 1);
+    }
+  }
   if (m->xchg_buf) hipFree(m->xchg_buf);
   if (m->xchg_sync) hipFree(m->xchg_sync);
   if (m->small_sync) hipFree(m->small_sync);

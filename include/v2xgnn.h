@@ -237,7 +237,10 @@ int  v2x_check_errors(v2x_model* m, void* stream);
  * whose only state across launches is a per-graph departure count.  A launch that was aborted half-way leaves that state out
  * of step; the next predict then does not hang: its polls are bounded, it raises a flag and the synchronising call returns
  * V2X_ESTATE after re-arming the exchange by itself.  v2x_reset_exchange does the same re-arming on request (synchronises
- * the device).  v2x_debug_exchange_counters: [dev] pointer to the 256 64-bit departure counters (tests corrupt one on purpose). */
+ * the device).  v2x_debug_exchange_counters: [dev] pointer to the 256 64-bit departure counters (tests corrupt one on purpose).
+ * The split-tile fused graph layers (csrc/kernels_fused_split.hpp: K workgroups per 16-graph tile for batches that leave most
+ * of the chip idle) hand stage rows between a tile's workgroups the same way, with one 64-bit launch counter per tile; the
+ * same bounded polls, the same V2X_ESTATE + self re-arming, and v2x_reset_exchange re-arms that exchange as well.           */
 int  v2x_reset_exchange(v2x_model* m);
 void* v2x_debug_exchange_counters(v2x_model* m);
 

@@ -2629,6 +2629,10 @@ int v2x_reset_exchange(v2x_model* m) {
 }
 
 void* v2x_debug_exchange_counters(v2x_model* m) { return m ? (void*)m->small_sync : nullptr; }
+void* v2x_debug_split_counters(v2x_model* m, int32_t* n_tiles) {
+  if (n_tiles) *n_tiles = m ? m->xchg_cap_tiles : 0;
+  return m ? (void*)m->xchg_sync : nullptr;
+}
 
 int v2x_check_errors(v2x_model* m, void* stream) {
   HIPCHK(m, hipStreamSynchronize((hipStream_t)stream));

@@ -74,6 +74,7 @@ SYMBOLS = [
     ("v2x_check_errors", C.c_int, [_P, _P]),
     ("v2x_reset_exchange", C.c_int, [_P]),
     ("v2x_debug_exchange_counters", _P, [_P]),
+    ("v2x_debug_split_counters", _P, [_P, C.POINTER(C.c_int32)]),
     ("v2x_debug_phase_stamps", C.c_int, [_P, _P, C.c_int]),
     ("v2x_debug_ragged_plan", C.c_int, [_P, _P, C.c_int]),
     ("v2x_profile_enable", C.c_int, [_P, C.c_int]),

@@ -243,6 +243,9 @@ int  v2x_check_errors(v2x_model* m, void* stream);
  * same bounded polls, the same V2X_ESTATE + self re-arming, and v2x_reset_exchange re-arms that exchange as well.           */
 int  v2x_reset_exchange(v2x_model* m);
 void* v2x_debug_exchange_counters(v2x_model* m);
+/* [dev] pointer to the split-tile exchange's per-tile 64-bit launch counters (*n_tiles of them; NULL before the first split-tile
+ * launch of the model): tests push one out of step on purpose.                                                                    */
+void* v2x_debug_split_counters(v2x_model* m, int32_t* n_tiles);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* When enabled, every kernel launch of this model is bracketed by HIP events on its stream

@@ -268,6 +268,65 @@ def test_split_tiles_alternating_members_per_tile():
     split.close(); whole.close()
 
 
+def test_split_tiles_out_of_step_exchange_times_out_instead_of_hanging():
+    """The members of a tile poll for their partners' rows with BOUNDED polls.  Here the tiles' launch counters are bumped from
+    another stream WHILE split-tile fit steps run, so that members of one launch read different epochs and wait for tags nobody
+    writes: the launch must terminate, the call must report V2X_ESTATE ("timed out"), the library must re-arm the exchange by
+    itself, and the following steps must be right again (bit-identical to a whole-tile engine from the same weights)."""
+    import ctypes as C
+    import time
+    import torch
+    N, F, B = 20, 64, 512                                           # 32 tiles x 5 members: many chances per launch
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(41)
+    weights = oc.params_to_list(f32_params(spec, rng))
+    split = _engine(spec, weights, True)        # ONE engine while the race runs: each engine owns streams, and HIP folds streams
+    x, e, adj = random_inputs(rng, B, N)        # onto 4 hardware queues -- two streams of one queue would run in turn
+    y = rng.normal(2.5, 1.0, size=(B * N, 4)).astype(np.float32)
+    pb = PackedBatch.from_dense(x, e, adj)
+    assert split.path_info(pb)["graph_layers"] == "fused(split5)"
+    split.forward_backward(pb, y)                                   # allocates the exchange
+    n = C.c_int32(0)
+    ptr = int(split._lib.v2x_debug_split_counters(split._h, C.byref(n)))
+    assert ptr and n.value >= 3
+
+    class _H(object):
+        pass
+    h = _H()
+    h.__cuda_array_interface__ = {"shape": (n.value,), "typestr": "<i8", "data": (ptr, False), "version": 2, "strides": None}
+    cnt = torch.as_tensor(h, device="cuda:%d" % split.device)
+    side, main = torch.cuda.Stream(), torch.cuda.Stream()
+    bumps = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(bumps, stream=side):
+        for _ in range(2000):
+            cnt.add_(3)
+    seen, t_max = 0, 0.0
+    for attempt in range(60):
+        with torch.cuda.stream(side):
+            bumps.replay()
+        t0 = time.perf_counter()
+        try:
+            with torch.cuda.stream(main):
+                loss = split.forward_backward(pb, y)
+            assert loss.shape == (N,)
+        except v2xgnn.lib.V2XError as exc:
+            assert "timed out" in str(exc), str(exc)
+            seen += 1
+        t_max = max(t_max, time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        if seen >= 2:
+            break
+    assert seen >= 1, "the bumps never met a running split-tile launch"
+    assert t_max < 30.0, t_max                                      # bounded: a few poll caps, not a hang
+    # recovery: the exchange was re-armed by the failing call; same weights in, same bits out as the whole-tile engine
+    whole = _engine(spec, weights, True, split=0)
+    split.set_weights(weights)
+    for _ in range(3):
+        ls, lw = split.forward_backward(pb, y), whole.forward_backward(pb, y)
+        assert np.array_equal(ls, lw) and np.array_equal(split.get_grad_flat(), whole.get_grad_flat())
+    split.close(); whole.close()
+
+
 def test_fused_hipgraph_replay_is_bitwise_eager():
     import torch
     N, F, B = 20, 64, 48

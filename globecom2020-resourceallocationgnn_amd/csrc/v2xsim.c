@@ -1,4 +1,4 @@
-/* libv2xsim.so -- the array arithmetic of one batched simulator step, one OpenMP thread per group of environments.
+/* libv2xsim.so -- the array arithmetic of one batched simulator step, the environments spread over a pool of threads.
  *
  * Counterpart of rl/batched_env.py's numpy expressions (which restate /root/reference/Environment.py:94-146 path loss,
  * :378-393 shadowing, :395-406 Rayleigh fast fading, :408-493 rates / interference and BS_brain.py:389-467 observation)
@@ -6,9 +6,12 @@
  * the stdlib's draw order, rl/mtstream.py): this library receives the UNIFORMS of a step and turns them into Gaussians
  * in random.gauss order (cos value, then the sin value of the same pair).  Same formulas, same operation order as the
  * numpy code; results agree to the last bits of libm (the tests compare at 1e-12).
- * Plain C, no Python API: bound with ctypes (rl/native_sim.py).  gcc -O2 -fopenmp -shared -fPIC v2xsim.c -lm        */
+ * Plain C, no Python API: bound with ctypes (rl/native_sim.py).  gcc -O2 -pthread -shared -fPIC v2xsim.c -lm         */
 #include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
 #include <stdint.h>
+#include <string.h>
 
 #define TWOPI 6.283185307179586476925286766559
 
@@ -16,7 +19,123 @@ static const double V2V_H = 1.5, FC = 2.0, V2V_DECORR = 10.0, V2V_SHADOW_STD = 3
 static const double V2I_H_BS = 25.0, V2I_H_MS = 1.5, V2I_DECORR = 50.0, V2I_SHADOW_STD = 8.0;
 static const double BS_X = 750.0 / 2, BS_Y = 1299.0 / 2;
 
-int v2xsim_abi(void) { return 1; }
+int v2xsim_abi(void) { return 2; }
+/* ---- the thread pool --------------------------------------------------------------------------------------------------
+ * Every entry point is "for each environment e: f(e)".  The loops run on a pool of threads that SLEEP between jobs (condition
+ * variable): an OpenMP team spins for a while after each parallel region, and on the MI355X boxes the process may use 16 CPUs'
+ * worth of time per 100 ms (cgroup cpu.max) -- two spinning teams next to the GPU runtime's threads exhausted that and the
+ * kernel parked the whole process for 25-50 ms, once or twice per hundred train steps (tools/prof_rl_sections.py, rounds 4-5).
+ * par_for: the caller takes part and returns when all environments are done.  par_start / par_wait: the pool alone works
+ * on the job (the look-ahead step below); while such a job is in flight par_for runs on the caller alone.
+ * Tickets carry the job's generation, so a worker that wakes up late can never take an index of a later job with an
+ * earlier job's function.                                                                                               */
+typedef void (*env_fn)(int e, void* ctx);
+#define POOL_MAX 64
+static struct {
+  pthread_mutex_t mu;
+  pthread_cond_t cv_work, cv_done;
+  pthread_t th[POOL_MAX];
+  int n_started;
+  env_fn fn; void* ctx; int n; int n_workers;       /* the current job (read under mu) */
+  uint32_t gen;
+  _Atomic uint64_t ticket;                          /* (gen << 32) | next index */
+  _Atomic int remaining;
+  int async_busy;                                   /* a par_start job is in flight */
+} P = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
+static int g_threads = 1;            /* threads a loop may use, the caller included (v2xsim_set_threads) */
+
+static int take(uint32_t gen, int n) {              /* next index of job `gen`, or -1 */
+  uint64_t t = atomic_load(&P.ticket);
+  for (;;) {
+    if ((uint32_t)(t >> 32) != gen || (int)(uint32_t)t >= n) return -1;
+    if (atomic_compare_exchange_weak(&P.ticket, &t, t + 1)) return (int)(uint32_t)t;
+  }
+}
+static void finish_one(void) {
+  if (atomic_fetch_sub(&P.remaining, 1) == 1) {
+    pthread_mutex_lock(&P.mu);
+    pthread_cond_broadcast(&P.cv_done);
+    pthread_mutex_unlock(&P.mu);
+  }
+}
+static void* pool_main(void* arg) {
+  const int id = (int)(intptr_t)arg;
+  uint32_t seen = 0;
+  pthread_mutex_lock(&P.mu);
+  for (;;) {
+    while (P.gen == seen) pthread_cond_wait(&P.cv_work, &P.mu);
+    seen = P.gen;
+    const env_fn fn = P.fn; void* ctx = P.ctx; const int n = P.n, allowed = P.n_workers;
+    pthread_mutex_unlock(&P.mu);
+    if (id < allowed)
+      for (int e; (e = take(seen, n)) >= 0;) { fn(e, ctx); finish_one(); }
+    pthread_mutex_lock(&P.mu);
+  }
+  return 0;
+}
+static void pool_after_fork(void) {                 /* the threads do not exist in a forked child: start over */
+  pthread_mutex_init(&P.mu, 0);
+  pthread_cond_init(&P.cv_work, 0);
+  pthread_cond_init(&P.cv_done, 0);
+  P.n_started = 0;
+  P.async_busy = 0;
+  atomic_store(&P.remaining, 0);
+}
+/* post a job for `workers` pool threads (mu held) */
+static void post(env_fn fn, void* ctx, int n, int workers) {
+  static int atfork_set = 0;
+  if (!atfork_set) { pthread_atfork(0, 0, pool_after_fork); atfork_set = 1; }
+  if (workers > POOL_MAX) workers = POOL_MAX;
+  while (P.n_started < workers) {
+    if (pthread_create(&P.th[P.n_started], 0, pool_main, (void*)(intptr_t)P.n_started) != 0) break;
+    pthread_detach(P.th[P.n_started]);
+    ++P.n_started;
+  }
+  P.fn = fn; P.ctx = ctx; P.n = n; P.n_workers = workers < P.n_started ? workers : P.n_started;
+  ++P.gen;
+  atomic_store(&P.remaining, n);
+  atomic_store(&P.ticket, (uint64_t)P.gen << 32);
+  if (P.n_workers > 0) pthread_cond_broadcast(&P.cv_work);
+}
+static void par_for(int n, env_fn fn, void* ctx) {
+  if (n <= 0) return;
+  pthread_mutex_lock(&P.mu);
+  if (P.async_busy || g_threads <= 1 || n == 1) {   /* the pool is working ahead (or not wanted): the caller alone */
+    pthread_mutex_unlock(&P.mu);
+    for (int e = 0; e < n; ++e) fn(e, ctx);
+    return;
+  }
+  post(fn, ctx, n, (g_threads < n ? g_threads : n) - 1);
+  const uint32_t gen = P.gen;
+  pthread_mutex_unlock(&P.mu);
+  for (int e; (e = take(gen, n)) >= 0;) { fn(e, ctx); atomic_fetch_sub(&P.remaining, 1); }
+  for (int spin = 0; spin < 4000 && atomic_load(&P.remaining) > 0; ++spin) __builtin_ia32_pause();
+  if (atomic_load(&P.remaining) > 0) {
+    pthread_mutex_lock(&P.mu);
+    while (atomic_load(&P.remaining) > 0) pthread_cond_wait(&P.cv_done, &P.mu);
+    pthread_mutex_unlock(&P.mu);
+  }
+}
+/* 0: started; -1: another job is in flight */
+static int par_start(int n, env_fn fn, void* ctx) {
+  pthread_mutex_lock(&P.mu);
+  if (P.async_busy) { pthread_mutex_unlock(&P.mu); return -1; }
+  post(fn, ctx, n, g_threads < n ? g_threads : n);
+  if (P.n_workers == 0) { pthread_mutex_unlock(&P.mu); return -2; }
+  P.async_busy = 1;
+  pthread_mutex_unlock(&P.mu);
+  return 0;
+}
+static int par_wait(void) {
+  pthread_mutex_lock(&P.mu);
+  if (!P.async_busy) { pthread_mutex_unlock(&P.mu); return -1; }
+  while (atomic_load(&P.remaining) > 0) pthread_cond_wait(&P.cv_done, &P.mu);
+  P.async_busy = 0;
+  pthread_mutex_unlock(&P.mu);
+  return 0;
+}
+void v2xsim_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int v2xsim_max_threads(void) { return g_threads; }
 
 /* Environment.py:94-122 (rl/environment.py _v2v_pathloss) */
 static double los(double x, double d_bp, double off) {
@@ -49,150 +168,190 @@ static double v2i_pathloss(double x, double y) {
  * u[E][n_u]: the step's uniforms, n_u = 2 * ceil((n + n^2 + 2 n rb + 2 n^2 rb) / 2); Gaussian k of an environment is
  * cos / sin of pair k / 2 (random.gauss order).  Draw order inside a step: V2I shadowing (n), V2V shadowing (n^2),
  * V2I fast fading real (n rb) and imaginary (n rb), V2V fast fading real (n^2 rb) and imaginary (n^2 rb).          */
+static void channels_env(int n, int rb, const double* ue, int n_u, const double* ve, const double* pe, double* si, double* sv,
+                         double* av, double* ai, double* fv, double* fi, double* g /* [n_u] */) {
+  const int n_sh = n + n * n, a = n * rb, b = n * n * rb;
+  for (int k = 0; k < n_u; k += 2) {
+    const double x2pi = ue[k] * TWOPI;
+    const double g2rad = sqrt(-2.0 * log(1.0 - ue[k + 1]));
+    g[k] = cos(x2pi) * g2rad;
+    g[k + 1] = sin(x2pi) * g2rad;
+  }
+  for (int i = 0; i < n; ++i) {
+    const double dd = 0.002 * ve[i];
+    si[i] = exp(-1 * (dd / V2I_DECORR)) * si[i] + sqrt(1 - exp(-2 * (dd / V2I_DECORR))) * (g[i] * V2I_SHADOW_STD);
+    ai[i] = v2i_pathloss(pe[2 * i], pe[2 * i + 1]) + si[i];
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      const double ddm = 0.002 * ve[i] + 0.002 * ve[j];
+      const int ij = i * n + j;
+      sv[ij] = exp(-1 * (ddm / V2V_DECORR)) * sv[ij] + sqrt(1 - exp(-2 * (ddm / V2V_DECORR))) * (g[n + ij] * V2V_SHADOW_STD);
+      av[ij] = v2v_pathloss(pe[2 * i], pe[2 * i + 1], pe[2 * j], pe[2 * j + 1]) + sv[ij] + (i == j ? 50.0 : 0.0);
+    }
+  const double* f = g + n_sh;
+  const double rs2 = 1 / sqrt(2.0);
+  for (int k = 0; k < a; ++k) {                  /* 20 log10 |(re + j im) / sqrt 2| */
+    const double re = rs2 * f[k], im = rs2 * f[a + k];
+    fi[k] = ai[k / rb] - 20 * log10(hypot(re, im));
+  }
+  for (int k = 0; k < b; ++k) {
+    const double re = rs2 * f[2 * a + k], im = rs2 * f[2 * a + b + k];
+    fv[k] = av[k / rb] - 20 * log10(hypot(re, im));
+  }
+}
+typedef struct { int n, rb, n_u; const double *u, *vel, *pos; double *v2i_shadow, *v2v_shadow, *v2v_abs, *v2i_abs, *v2v_ff, *v2i_ff, *scratch; } channels_ctx;
+static void channels_one(int e, void* p) {
+  const channels_ctx* c = (const channels_ctx*)p;
+  const int n = c->n, rb = c->rb, n_u = c->n_u;
+  channels_env(n, rb, c->u + (int64_t)e * n_u, n_u, c->vel + (int64_t)e * n, c->pos + (int64_t)e * n * 2, c->v2i_shadow + (int64_t)e * n,
+               c->v2v_shadow + (int64_t)e * n * n, c->v2v_abs + (int64_t)e * n * n, c->v2i_abs + (int64_t)e * n,
+               c->v2v_ff + (int64_t)e * n * n * rb, c->v2i_ff + (int64_t)e * n * rb, c->scratch + (int64_t)e * n_u);
+}
 void v2xsim_channels(int E, int n, int rb, const double* u, int n_u, const double* vel, const double* pos,
                      double* v2i_shadow, double* v2v_shadow, double* v2v_abs, double* v2i_abs, double* v2v_ff,
                      double* v2i_ff, double* scratch /* [E][n_u] */) {
-  const int n_sh = n + n * n, a = n * rb, b = n * n * rb;
-#pragma omp parallel for schedule(static)
-  for (int e = 0; e < E; ++e) {
-    const double* ue = u + (int64_t)e * n_u;
-    double* g = scratch + (int64_t)e * n_u;
-    for (int k = 0; k < n_u; k += 2) {
-      const double x2pi = ue[k] * TWOPI;
-      const double g2rad = sqrt(-2.0 * log(1.0 - ue[k + 1]));
-      g[k] = cos(x2pi) * g2rad;
-      g[k + 1] = sin(x2pi) * g2rad;
-    }
-    const double* ve = vel + (int64_t)e * n;
-    const double* pe = pos + (int64_t)e * n * 2;
-    double* si = v2i_shadow + (int64_t)e * n;
-    double* sv = v2v_shadow + (int64_t)e * n * n;
-    double* av = v2v_abs + (int64_t)e * n * n;
-    double* ai = v2i_abs + (int64_t)e * n;
-    for (int i = 0; i < n; ++i) {
-      const double dd = 0.002 * ve[i];
-      si[i] = exp(-1 * (dd / V2I_DECORR)) * si[i] + sqrt(1 - exp(-2 * (dd / V2I_DECORR))) * (g[i] * V2I_SHADOW_STD);
-      ai[i] = v2i_pathloss(pe[2 * i], pe[2 * i + 1]) + si[i];
-    }
-    for (int i = 0; i < n; ++i)
-      for (int j = 0; j < n; ++j) {
-        const double ddm = 0.002 * ve[i] + 0.002 * ve[j];
-        const int ij = i * n + j;
-        sv[ij] = exp(-1 * (ddm / V2V_DECORR)) * sv[ij] + sqrt(1 - exp(-2 * (ddm / V2V_DECORR))) * (g[n + ij] * V2V_SHADOW_STD);
-        av[ij] = v2v_pathloss(pe[2 * i], pe[2 * i + 1], pe[2 * j], pe[2 * j + 1]) + sv[ij] + (i == j ? 50.0 : 0.0);
-      }
-    const double* f = g + n_sh;
-    const double rs2 = 1 / sqrt(2.0);
-    double* fi = v2i_ff + (int64_t)e * a;
-    for (int k = 0; k < a; ++k) {                  /* 20 log10 |(re + j im) / sqrt 2| */
-      const double re = rs2 * f[k], im = rs2 * f[a + k];
-      fi[k] = ai[k / rb] - 20 * log10(hypot(re, im));
-    }
-    double* fv = v2v_ff + (int64_t)e * b;
-    for (int k = 0; k < b; ++k) {
-      const double re = rs2 * f[2 * a + k], im = rs2 * f[2 * a + b + k];
-      fv[k] = av[k / rb] - 20 * log10(hypot(re, im));
-    }
-  }
+  channels_ctx c = { n, rb, n_u, u, vel, pos, v2i_shadow, v2v_shadow, v2v_abs, v2i_abs, v2v_ff, v2i_ff, scratch };
+  par_for(E, channels_one, &c);
 }
 
 /* compute_reward_with_channel_selection (Environment.py:408-458; every link active, one receiver per link).
  * ch[E][n] chosen resource block, dest[E][n] receiver of link k; out: v2v_rate[E][n], v2i_rate[E][m], m = min(rb, n),
  * interference[E][rb] (without noise), v2i_interf[E][rb] and v2v_interf[E][n] (with noise).                          */
+typedef struct { int n, rb; const int64_t *ch, *dest; const double *v2v_ff, *v2i_ff, *v2i_abs; double p_v2v, p_v2i, veh_gain, bs_gain, bs_nf,
+                 veh_nf, sig2; double *v2v_rate, *v2i_rate, *interference, *v2i_interf, *v2v_interf; } reward_ctx;
+static void reward_one(int e, void* p) {
+  const reward_ctx* a = (const reward_ctx*)p;
+  const int n = a->n, rb = a->rb, m = rb < n ? rb : n;
+  const double p_v2v = a->p_v2v, p_v2i = a->p_v2i, veh_gain = a->veh_gain, bs_gain = a->bs_gain, bs_nf = a->bs_nf, sig2 = a->sig2;
+  const double gain = 2 * veh_gain - a->veh_nf;
+  const int64_t* c = a->ch + (int64_t)e * n;
+  const int64_t* d = a->dest + (int64_t)e * n;
+  const double* vv = a->v2v_ff + (int64_t)e * n * n * rb;
+  const double* vi = a->v2i_ff + (int64_t)e * n * rb;
+  double* itf = a->interference + (int64_t)e * rb;
+  double* v2i_interf = a->v2i_interf + (int64_t)e * rb;
+  for (int r = 0; r < rb; ++r) itf[r] = 0.0;
+  for (int k = 0; k < n; ++k)                    /* (at_bs * onehot).sum(axis=1): ascending k per block */
+    itf[c[k]] += pow(10.0, (p_v2v - vi[k * rb + c[k]] + veh_gain + bs_gain - bs_nf) / 10);
+  for (int r = 0; r < rb; ++r) v2i_interf[r] = itf[r] + sig2;
+  for (int k = 0; k < n; ++k) {
+    const int64_t rx = d[k], r = c[k];
+    const double signal = pow(10.0, (p_v2v - vv[(k * n + rx) * rb + r] + gain) / 10);
+    double acc = 0.0;
+    if (r < n) acc += pow(10.0, (p_v2i - vv[(r * n + rx) * rb + r] + gain) / 10);   /* the V2I transmitter of block r is vehicle r */
+    double cross = 0.0;
+    for (int j = 0; j < n; ++j)
+      if (j != k && c[j] == r) cross += pow(10.0, (p_v2v - vv[(j * n + rx) * rb + r] + gain) / 10);
+    acc += cross;
+    const double tot = acc + sig2;
+    a->v2v_interf[(int64_t)e * n + k] = tot;
+    a->v2v_rate[(int64_t)e * n + k] = log2(1 + signal / tot);
+  }
+  for (int k = 0; k < m; ++k) {
+    const double s = p_v2i - a->v2i_abs[(int64_t)e * n + k] + veh_gain + bs_gain - bs_nf;
+    a->v2i_rate[(int64_t)e * m + k] = log2(1 + pow(10.0, s / 10) / v2i_interf[k]);
+  }
+}
 void v2xsim_reward(int E, int n, int rb, const int64_t* ch, const int64_t* dest, const double* v2v_ff, const double* v2i_ff,
                    const double* v2i_abs, double p_v2v, double p_v2i, double veh_gain, double bs_gain, double bs_nf,
                    double veh_nf, double sig2, double* v2v_rate, double* v2i_rate, double* interference,
                    double* v2i_interf, double* v2v_interf) {
-  const int m = rb < n ? rb : n;
-  const double gain = 2 * veh_gain - veh_nf;
-#pragma omp parallel for schedule(static)
-  for (int e = 0; e < E; ++e) {
-    const int64_t* c = ch + (int64_t)e * n;
-    const int64_t* d = dest + (int64_t)e * n;
-    const double* vv = v2v_ff + (int64_t)e * n * n * rb;
-    const double* vi = v2i_ff + (int64_t)e * n * rb;
-    double* itf = interference + (int64_t)e * rb;
-    for (int r = 0; r < rb; ++r) itf[r] = 0.0;
-    for (int k = 0; k < n; ++k)                    /* (at_bs * onehot).sum(axis=1): ascending k per block */
-      itf[c[k]] += pow(10.0, (p_v2v - vi[k * rb + c[k]] + veh_gain + bs_gain - bs_nf) / 10);
-    for (int r = 0; r < rb; ++r) v2i_interf[(int64_t)e * rb + r] = itf[r] + sig2;
-    for (int k = 0; k < n; ++k) {
-      const int64_t rx = d[k], r = c[k];
-      const double signal = pow(10.0, (p_v2v - vv[(k * n + rx) * rb + r] + gain) / 10);
-      double acc = 0.0;
-      if (r < n) acc += pow(10.0, (p_v2i - vv[(r * n + rx) * rb + r] + gain) / 10);   /* the V2I transmitter of block r is vehicle r */
-      double cross = 0.0;
-      for (int j = 0; j < n; ++j)
-        if (j != k && c[j] == r) cross += pow(10.0, (p_v2v - vv[(j * n + rx) * rb + r] + gain) / 10);
-      acc += cross;
-      const double tot = acc + sig2;
-      v2v_interf[(int64_t)e * n + k] = tot;
-      v2v_rate[(int64_t)e * n + k] = log2(1 + signal / tot);
-    }
-    for (int k = 0; k < m; ++k) {
-      const double s = p_v2i - v2i_abs[(int64_t)e * n + k] + veh_gain + bs_gain - bs_nf;
-      v2i_rate[(int64_t)e * m + k] = log2(1 + pow(10.0, s / 10) / v2i_interf[(int64_t)e * rb + k]);
-    }
-  }
+  reward_ctx c = { n, rb, ch, dest, v2v_ff, v2i_ff, v2i_abs, p_v2v, p_v2i, veh_gain, bs_gain, bs_nf, veh_nf, sig2,
+                   v2v_rate, v2i_rate, interference, v2i_interf, v2v_interf };
+  par_for(E, reward_one, &c);
 }
 
 /* Compute_Interference (Environment.py:460-493, observable part): out[E][n][rb] in dB */
+static void interference_env(int n, int rb, const int64_t* dest, const double* vv, double p_v2i, double veh_gain, double veh_nf,
+                             double sig2, double* out) {
+  for (int k = 0; k < n; ++k) {
+    const int64_t rx = dest[k];
+    for (int r = 0; r < rb; ++r) {
+      double v = sig2;
+      /* numpy indexes vehicle number r as the block's V2I transmitter; r < n is the caller's precondition (rb <= n) */
+      v += pow(10.0, (p_v2i - vv[((int64_t)r * n + rx) * rb + r] + 2 * veh_gain - veh_nf) / 10);
+      out[(int64_t)k * rb + r] = 10 * log10(v);
+    }
+  }
+}
+typedef struct { int n, rb; const int64_t* dest; const double* v2v_ff; double p_v2i, veh_gain, veh_nf, sig2; double* out; } interf_ctx;
+static void interference_one(int e, void* p) {
+  const interf_ctx* c = (const interf_ctx*)p;
+  interference_env(c->n, c->rb, c->dest + (int64_t)e * c->n, c->v2v_ff + (int64_t)e * c->n * c->n * c->rb, c->p_v2i, c->veh_gain,
+                   c->veh_nf, c->sig2, c->out + (int64_t)e * c->n * c->rb);
+}
 void v2xsim_interference(int E, int n, int rb, const int64_t* dest, const double* v2v_ff, double p_v2i, double veh_gain,
                          double veh_nf, double sig2, double* out) {
-#pragma omp parallel for schedule(static)
-  for (int e = 0; e < E; ++e) {
-    const double* vv = v2v_ff + (int64_t)e * n * n * rb;
-    for (int k = 0; k < n; ++k) {
-      const int64_t rx = dest[(int64_t)e * n + k];
-      for (int r = 0; r < rb; ++r) {
-        double v = sig2;
-        /* numpy indexes vehicle number r as the block's V2I transmitter; r < n is the caller's precondition (rb <= n) */
-        v += pow(10.0, (p_v2i - vv[((int64_t)r * n + rx) * rb + r] + 2 * veh_gain - veh_nf) / 10);
-        out[((int64_t)e * n + k) * rb + r] = 10 * log10(v);
-      }
-    }
-  }
+  interf_ctx c = { n, rb, dest, v2v_ff, p_v2i, veh_gain, veh_nf, sig2, out };
+  par_for(E, interference_one, &c);
 }
 
-/* Agent.observe for all environments (BS_brain.py:389-407, :441-445, :458-467): state[E][n][3C+1], adj[E][n][n] */
-void v2xsim_observe(int E, int n, int C, const int64_t* dest, const double* v2v_ff, const double* v2i_ff, double power,
-                    double* state, double* adj) {
+/* Agent.observe for one environment (BS_brain.py:389-407, :441-445, :458-467): state[n][3C+1], adj[n][n]; and, when xe is
+ * given, the same observation in the engine's packed form (include/v2xgnn.h, rl/replay.py): xe[n][16] float32 = the state row
+ * cast to float32 + zero padding (packing.pack_xe), mask[q] = bit p set when p sends to q, col[n (n-2)] = the CSR sources by
+ * destination (ascending) when every link has in-degree n-2 ("regular": no link is its own receiver), zeros otherwise.    */
+static void observe_env(int n, int C, const int64_t* d, const double* vv, const double* vi, double power, double* st, double* ad,
+                        float* xe, int32_t* mask, int32_t* col, uint8_t* regular) {
   const double A = 80, Bc = 60;
   const int W = 3 * C + 1;
-#pragma omp parallel for schedule(static)
-  for (int e = 0; e < E; ++e) {
-    const double* vv = v2v_ff + (int64_t)e * n * n * C;
-    const double* vi = v2i_ff + (int64_t)e * n * C;
-    const int64_t* d = dest + (int64_t)e * n;
-    double* st = state + (int64_t)e * n * W;
-    double* ad = adj + (int64_t)e * n * n;
-    for (int p = 0; p < n; ++p)
-      for (int q = 0; q < n; ++q) ad[p * n + q] = p == q ? 0.0 : 1.0;
-    for (int k = 0; k < n; ++k) {
-      const int64_t rx = d[k];
-      ad[rx * n + k] = 0.0;
-      for (int c = 0; c < C; ++c) {
-        const double chv = (vv[(k * n + rx) * C + c] - A) / Bc;
-        double tot = 0.0;
-        for (int p = 0; p < n; ++p) tot += vv[(p * n + rx) * C + c];          /* np.sum over p, ascending */
-        const double edge = (((tot - vv[(rx * n + rx) * C + c]) - (n - 1) * A) / Bc - chv) / (n - 2);
-        st[k * W + c] = chv;
-        st[k * W + C + c] = (vi[k * C + c] - A) / Bc;
-        st[k * W + 2 * C + 1 + c] = edge;
-      }
-      st[k * W + 2 * C] = power;
+  for (int p = 0; p < n; ++p)
+    for (int q = 0; q < n; ++q) ad[p * n + q] = p == q ? 0.0 : 1.0;
+  for (int k = 0; k < n; ++k) {
+    const int64_t rx = d[k];
+    ad[rx * n + k] = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const double chv = (vv[(k * n + rx) * C + c] - A) / Bc;
+      double tot = 0.0;
+      for (int p = 0; p < n; ++p) tot += vv[(p * n + rx) * C + c];          /* np.sum over p, ascending */
+      const double edge = (((tot - vv[(rx * n + rx) * C + c]) - (n - 1) * A) / Bc - chv) / (n - 2);
+      st[k * W + c] = chv;
+      st[k * W + C + c] = (vi[k * C + c] - A) / Bc;
+      st[k * W + 2 * C + 1 + c] = edge;
     }
+    st[k * W + 2 * C] = power;
   }
+  if (!xe) return;
+  int reg = 1;
+  for (int k = 0; k < n; ++k) {
+    for (int c = 0; c < 16; ++c) xe[k * 16 + c] = c < W ? (float)st[k * W + c] : 0.0f;
+    if (d[k] == k) reg = 0;
+  }
+  *regular = (uint8_t)reg;
+  int o = 0;
+  for (int q = 0; q < n; ++q) {
+    uint32_t m = 0;
+    for (int p = 0; p < n; ++p)
+      if (ad[p * n + q] != 0.0) {
+        m |= 1u << p;
+        if (reg) col[o++] = p;
+      }
+    mask[q] = (int32_t)m;
+  }
+  if (!reg)
+    for (int k = 0; k < n * (n - 2); ++k) col[k] = 0;
+}
+typedef struct { int n, C; const int64_t* dest; const double *v2v_ff, *v2i_ff; double power; double *state, *adj; float* xe;
+                 int32_t *mask, *col; uint8_t* regular; } observe_ctx;
+static void observe_one(int e, void* p) {
+  const observe_ctx* c = (const observe_ctx*)p;
+  const int n = c->n, C = c->C, W = 3 * C + 1, ne = n * (n - 2);
+  observe_env(n, C, c->dest + (int64_t)e * n, c->v2v_ff + (int64_t)e * n * n * C, c->v2i_ff + (int64_t)e * n * C, c->power,
+              c->state + (int64_t)e * n * W, c->adj + (int64_t)e * n * n, c->xe ? c->xe + (int64_t)e * n * 16 : 0,
+              c->xe ? c->mask + (int64_t)e * n : 0, c->xe ? c->col + (int64_t)e * ne : 0, c->xe ? c->regular + e : 0);
+}
+void v2xsim_observe(int E, int n, int C, const int64_t* dest, const double* v2v_ff, const double* v2i_ff, double power,
+                    double* state, double* adj) {
+  observe_ctx c = { n, C, dest, v2v_ff, v2i_ff, power, state, adj, 0, 0, 0, 0 };
+  par_for(E, observe_one, &c);
+}
+/* ... with the packed form beside it (n <= 31, W <= 16) */
+void v2xsim_observe_packed(int E, int n, int C, const int64_t* dest, const double* v2v_ff, const double* v2i_ff, double power,
+                           double* state, double* adj, float* xe, int32_t* mask, int32_t* col, uint8_t* regular) {
+  observe_ctx c = { n, C, dest, v2v_ff, v2i_ff, power, state, adj, xe, mask, col, regular };
+  par_for(E, observe_one, &c);
 }
 
-#ifdef _OPENMP
-#include <omp.h>
-void v2xsim_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
-int v2xsim_max_threads(void) { return omp_get_max_threads(); }
-#else
-void v2xsim_set_threads(int n) { (void)n; }
-int v2xsim_max_threads(void) { return 1; }
-#endif
 
 /* ---- MT19937 (the generator behind CPython's random and numpy's legacy RandomState), one state per environment ----
  * key[624] + pos exactly as numpy's RandomState.get_state() reports them; doubles as random.random() /
@@ -221,18 +380,21 @@ static inline uint32_t mt_next(uint32_t* mt, int32_t* pos) {
   return y;
 }
 /* out[e][0..n_u) = the next n_u doubles of stream e */
-void v2xsim_mt_uniforms(int E, uint32_t* keys, int32_t* pos, double* out, int n_u) {
-#pragma omp parallel for schedule(static)
-  for (int e = 0; e < E; ++e) {
-    uint32_t* mt = keys + (int64_t)e * 624;
-    int32_t p = pos[e];
-    double* o = out + (int64_t)e * n_u;
-    for (int k = 0; k < n_u; ++k) {
-      const uint32_t a = mt_next(mt, &p) >> 5, b = mt_next(mt, &p) >> 6;
-      o[k] = (a * 67108864.0 + b) / 9007199254740992.0;
-    }
-    pos[e] = p;
+typedef struct { uint32_t* keys; int32_t* pos; double* out; int n_u; } uniforms_ctx;
+static void uniforms_one(int e, void* q) {
+  const uniforms_ctx* c = (const uniforms_ctx*)q;
+  uint32_t* mt = c->keys + (int64_t)e * 624;
+  int32_t p = c->pos[e];
+  double* o = c->out + (int64_t)e * c->n_u;
+  for (int k = 0; k < c->n_u; ++k) {
+    const uint32_t a = mt_next(mt, &p) >> 5, b = mt_next(mt, &p) >> 6;
+    o[k] = (a * 67108864.0 + b) / 9007199254740992.0;
   }
+  c->pos[e] = p;
+}
+void v2xsim_mt_uniforms(int E, uint32_t* keys, int32_t* pos, double* out, int n_u) {
+  uniforms_ctx c = { keys, pos, out, n_u };
+  par_for(E, uniforms_one, &c);
 }
 
 /* ---- the scalar integer draws of an episode reset, on the environments' own MT19937 states ------------------------------
@@ -246,35 +408,187 @@ static inline uint32_t mt_below(uint32_t* mt, int32_t* pos, uint32_t n) {
 }
 /* add_new_vehicles_by_number (Environment.py:217-234) for every environment: n / 4 groups of one vehicle per direction
  * (down = 1, up = 0, left = 2, right = 3) on a random lane index; per vehicle the position draw, then the velocity draw. */
+typedef struct { int n, n_lanes, width, height; uint32_t* keys; int32_t* pos; const double *down, *up, *left, *right; double* xy;
+                 int8_t* dirs; double* vel; } reset_ctx;
+static void reset_one(int e, void* q) {
+  const reset_ctx* c = (const reset_ctx*)q;
+  const int n = c->n, n_lanes = c->n_lanes, width = c->width, height = c->height;
+  const double *down = c->down, *up = c->up, *left = c->left, *right = c->right;
+  uint32_t* mt = c->keys + (int64_t)e * 624;
+  int32_t p = c->pos[e];
+  double* x = c->xy + (int64_t)e * n * 2;
+  int8_t* d = c->dirs + (int64_t)e * n;
+  double* v = c->vel + (int64_t)e * n;
+  int k = 0;
+  for (int g = 0; g < n / 4; ++g) {
+    const uint32_t ind = mt_below(mt, &p, (uint32_t)n_lanes);
+    x[2 * k] = down[ind]; x[2 * k + 1] = (double)mt_below(mt, &p, (uint32_t)height + 1); d[k] = 1; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
+    x[2 * k] = up[ind];   x[2 * k + 1] = (double)mt_below(mt, &p, (uint32_t)height + 1); d[k] = 0; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
+    x[2 * k] = (double)mt_below(mt, &p, (uint32_t)width + 1); x[2 * k + 1] = left[ind];  d[k] = 2; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
+    x[2 * k] = (double)mt_below(mt, &p, (uint32_t)width + 1); x[2 * k + 1] = right[ind]; d[k] = 3; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
+  }
+  c->pos[e] = p;
+}
 void v2xsim_reset_vehicles(int E, int n, uint32_t* keys, int32_t* pos, int n_lanes, const double* down, const double* up,
                            const double* left, const double* right, int width, int height, double* xy, int8_t* dirs,
                            double* vel) {
-#pragma omp parallel for schedule(static)
-  for (int e = 0; e < E; ++e) {
-    uint32_t* mt = keys + (int64_t)e * 624;
-    int32_t p = pos[e];
-    double* x = xy + (int64_t)e * n * 2;
-    int8_t* d = dirs + (int64_t)e * n;
-    double* v = vel + (int64_t)e * n;
-    int k = 0;
-    for (int g = 0; g < n / 4; ++g) {
-      const uint32_t ind = mt_below(mt, &p, (uint32_t)n_lanes);
-      x[2 * k] = down[ind]; x[2 * k + 1] = (double)mt_below(mt, &p, (uint32_t)height + 1); d[k] = 1; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
-      x[2 * k] = up[ind];   x[2 * k + 1] = (double)mt_below(mt, &p, (uint32_t)height + 1); d[k] = 0; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
-      x[2 * k] = (double)mt_below(mt, &p, (uint32_t)width + 1); x[2 * k + 1] = left[ind];  d[k] = 2; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
-      x[2 * k] = (double)mt_below(mt, &p, (uint32_t)width + 1); x[2 * k + 1] = right[ind]; d[k] = 3; v[k] = 10.0 + mt_below(mt, &p, 6); ++k;
-    }
-    pos[e] = p;
-  }
+  reset_ctx c = { n, n_lanes, width, height, keys, pos, down, up, left, right, xy, dirs, vel };
+  par_for(E, reset_one, &c);
 }
 /* renew_neighbor's destination draw (Environment.py:375): random.sample(candidates, 1)[0] for every link -- a population
  * of m <= 21 entries takes CPython's pool method, whose first pick is pool[_randbelow(m)].                              */
+typedef struct { int n, m; uint32_t* keys; int32_t* pos; const int64_t* cand; int64_t* dest; } dest_ctx;
+static void dest_one(int e, void* q) {
+  const dest_ctx* c = (const dest_ctx*)q;
+  uint32_t* mt = c->keys + (int64_t)e * 624;
+  int32_t p = c->pos[e];
+  for (int i = 0; i < c->n; ++i)
+    c->dest[(int64_t)e * c->n + i] = c->cand[((int64_t)e * c->n + i) * c->m + mt_below(mt, &p, (uint32_t)c->m)];
+  c->pos[e] = p;
+}
 void v2xsim_sample_dest(int E, int n, int m, uint32_t* keys, int32_t* pos, const int64_t* cand, int64_t* dest) {
-#pragma omp parallel for schedule(static)
-  for (int e = 0; e < E; ++e) {
-    uint32_t* mt = keys + (int64_t)e * 624;
-    int32_t p = pos[e];
-    for (int i = 0; i < n; ++i) dest[(int64_t)e * n + i] = cand[((int64_t)e * n + i) * m + mt_below(mt, &p, (uint32_t)m)];
-    pos[e] = p;
+  dest_ctx c = { n, m, keys, pos, cand, dest };
+  par_for(E, dest_one, &c);
+}
+
+/* ---- one whole simulator step of every environment in one call, and the same step computed AHEAD of the agent --------------
+ * Nothing in a simulator step depends on the agent's actions except the rates it is paid (v2xsim_reward, on the channels
+ * BEFORE the step): mobility, shadowing, fast fading, the observable interference and the next observation are functions of
+ * the environment's own state and random stream (Environment.py:236-406, :460-493; BS_brain.py:366-376 calls them in this
+ * order after computing the reward).  v2xsim_advance therefore maps (state in) -> (state out, channels, observation) without
+ * touching its inputs, and v2xsim_advance_start / _wait run it on a worker thread while the caller scores the observation on
+ * the GPU and replays: rl/batched_env.py commits the result when the agent acts, or drops it (inputs untouched) when
+ * anything else happens first.                                                                                            */
+static inline double mt_double(uint32_t* mt, int32_t* pos) {
+  const uint32_t a = mt_next(mt, pos) >> 5, b = mt_next(mt, pos) >> 6;
+  return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+/* renew_positions (Environment.py:236-345) of one environment, vehicles in index order: a vehicle that reaches a crossing lane
+ * draws one uniform per reached lane (in the reference's checking order) and turns with probability 0.4; vehicles that left
+ * the map re-enter on the outermost lane.  dirs: 0 up, 1 down, 2 left, 3 right (rl/batched_env.py _DIRS).               */
+static void positions_env(int n, uint32_t* mt, int32_t* mtpos, double* xy, int8_t* dirs, const double* vel, double timestep,
+                          int n_lanes, const double* up, const double* down, const double* left, const double* right,
+                          double width, double height) {
+  for (int v = 0; v < n; ++v) {
+    const int d = dirs[v];
+    const int ax = d < 2 ? 1 : 0;                          /* moving axis: y for up / down */
+    const double sg = (d == 0 || d == 3) ? 1.0 : -1.0;
+    const double dv = vel[v] * timestep;
+    const double av = xy[2 * v + ax], ov = xy[2 * v + 1 - ax];
+    /* crossing lanes in checking order: (left, then right) for vertical movers, (up, then down) for horizontal ones */
+    const double* tab[2];
+    int new_dir[2];
+    double side[2], gs[2];
+    if (ax == 1) { tab[0] = left; new_dir[0] = 2; side[0] = -1; gs[0] = -1; tab[1] = right; new_dir[1] = 3; side[1] = 1; gs[1] = 1; }
+    else         { tab[0] = up;   new_dir[0] = 0; side[0] = 1;  gs[0] = -1; tab[1] = down;  new_dir[1] = 1; side[1] = -1; gs[1] = -1; }
+    int turned = 0;
+    for (int o = 0; o < 2 && !turned; ++o)
+      for (int l = 0; l < n_lanes; ++l) {
+        const double lane = tab[o][l];
+        const int reached = sg > 0 ? (av <= lane && av + dv >= lane) : (av >= lane && av - dv <= lane);
+        if (reached && mt_double(mt, mtpos) < 0.4) {
+          const double gap = sg * (lane - av);
+          const double new_o = ov + side[o] * (dv + gs[o] * gap);
+          if (ax == 1) { xy[2 * v] = new_o; xy[2 * v + 1] = lane; }
+          else         { xy[2 * v] = lane;  xy[2 * v + 1] = new_o; }
+          dirs[v] = (int8_t)new_dir[o];
+          turned = 1;
+          break;
+        }
+      }
+    if (!turned) xy[2 * v + ax] = sg > 0 ? av + dv : av - dv;
+  }
+  for (int v = 0; v < n; ++v) {
+    const double x = xy[2 * v], y = xy[2 * v + 1];
+    if (x < 0 || y < 0 || x > width || y > height) {
+      switch (dirs[v]) {
+        case 0: dirs[v] = 3; xy[2 * v + 1] = right[n_lanes - 1]; break;
+        case 1: dirs[v] = 2; xy[2 * v + 1] = left[0]; break;
+        case 2: dirs[v] = 0; xy[2 * v] = up[0]; break;
+        default: dirs[v] = 1; xy[2 * v] = down[n_lanes - 1]; break;
+      }
+    }
   }
 }
+typedef struct { int n, n_lanes; uint32_t* keys; int32_t* pos; double* xy; int8_t* dirs; const double* vel; double timestep;
+                 const double *up, *down, *left, *right; double width, height; } positions_ctx;
+static void positions_one(int e, void* q) {
+  const positions_ctx* c = (const positions_ctx*)q;
+  int32_t p = c->pos[e];
+  positions_env(c->n, c->keys + (int64_t)e * 624, &p, c->xy + (int64_t)e * c->n * 2, c->dirs + (int64_t)e * c->n, c->vel + (int64_t)e * c->n,
+                c->timestep, c->n_lanes, c->up, c->down, c->left, c->right, c->width, c->height);
+  c->pos[e] = p;
+}
+void v2xsim_positions(int E, int n, uint32_t* keys, int32_t* pos, double* xy, int8_t* dirs, const double* vel, double timestep,
+                      int n_lanes, const double* up, const double* down, const double* left, const double* right, double width,
+                      double height) {
+  positions_ctx c = { n, n_lanes, keys, pos, xy, dirs, vel, timestep, up, down, left, right, width, height };
+  par_for(E, positions_one, &c);
+}
+
+typedef struct {
+  int32_t E, n, rb, n_lanes;
+  double timestep, width, height;
+  const double *up, *down, *left, *right;           /* lane tables [n_lanes] */
+  const double* vel;                                /* [E][n]   (constant within an episode) */
+  const int64_t* dest;                              /* [E][n]   (constant within an episode) */
+  double p_v2v, p_v2i, veh_gain, veh_nf, sig2;
+  /* state in (not written) */
+  const uint32_t* keys_in; const int32_t* mtpos_in; const double* xy_in; const int8_t* dirs_in;
+  const double* v2i_shadow_in; const double* v2v_shadow_in;
+  /* state out */
+  uint32_t* keys; int32_t* mtpos; double* xy; int8_t* dirs; double* v2i_shadow; double* v2v_shadow;
+  /* channels, interference, observation of the new state */
+  double *v2v_abs, *v2i_abs, *v2v_ff, *v2i_ff, *interf_db, *state, *adj;
+  float* xe; int32_t* mask; int32_t* col; uint8_t* regular;
+  double* scratch;                                  /* [E][2 n_u]: uniforms, Gaussians */
+} v2xsim_advance_args;
+
+static void advance_one(int e, void* q) {
+  const v2xsim_advance_args* a = (const v2xsim_advance_args*)q;
+  const int n = a->n, rb = a->rb;
+  const int n_draws = n + n * n + 2 * n * rb + 2 * n * n * rb, n_u = (n_draws + 1) & ~1;
+  const int W = 3 * rb + 1, ne = n * (n - 2);
+  uint32_t* mt = a->keys + (int64_t)e * 624;
+  double* xy = a->xy + (int64_t)e * n * 2;
+  int8_t* dirs = a->dirs + (int64_t)e * n;
+  double* si = a->v2i_shadow + (int64_t)e * n;
+  double* sv = a->v2v_shadow + (int64_t)e * n * n;
+  if (a->keys != a->keys_in) memcpy(mt, a->keys_in + (int64_t)e * 624, 624 * sizeof(uint32_t));
+  if (a->xy != a->xy_in) memcpy(xy, a->xy_in + (int64_t)e * n * 2, (size_t)n * 2 * sizeof(double));
+  if (a->dirs != a->dirs_in) memcpy(dirs, a->dirs_in + (int64_t)e * n, (size_t)n);
+  if (a->v2i_shadow != a->v2i_shadow_in) memcpy(si, a->v2i_shadow_in + (int64_t)e * n, (size_t)n * sizeof(double));
+  if (a->v2v_shadow != a->v2v_shadow_in) memcpy(sv, a->v2v_shadow_in + (int64_t)e * n * n, (size_t)n * n * sizeof(double));
+  int32_t p = a->mtpos_in[e];
+  const double* ve = a->vel + (int64_t)e * n;
+  positions_env(n, mt, &p, xy, dirs, ve, a->timestep, a->n_lanes, a->up, a->down, a->left, a->right, a->width, a->height);
+  double* u = a->scratch + (int64_t)e * 2 * n_u;
+  for (int k = 0; k < n_u; ++k) u[k] = mt_double(mt, &p);
+  a->mtpos[e] = p;
+  double* fv = a->v2v_ff + (int64_t)e * n * n * rb;
+  double* fi = a->v2i_ff + (int64_t)e * n * rb;
+  channels_env(n, rb, u, n_u, ve, xy, si, sv, a->v2v_abs + (int64_t)e * n * n, a->v2i_abs + (int64_t)e * n, fv, fi, u + n_u);
+  const int64_t* d = a->dest + (int64_t)e * n;
+  interference_env(n, rb, d, fv, a->p_v2i, a->veh_gain, a->veh_nf, a->sig2, a->interf_db + (int64_t)e * n * rb);
+  observe_env(n, rb, d, fv, fi, a->p_v2v, a->state + (int64_t)e * n * W, a->adj + (int64_t)e * n * n, a->xe + (int64_t)e * n * 16,
+              a->mask + (int64_t)e * n, a->col + (int64_t)e * ne, a->regular + e);
+}
+void v2xsim_advance(const v2xsim_advance_args* a) {
+  v2xsim_advance_args c = *a;
+  par_for(c.E, advance_one, &c);
+}
+
+/* the same step on the pool alone while the caller does something else: one job in flight per process */
+static v2xsim_advance_args g_job;
+/* 0: started; -1: a job is already in flight (wait for it first); -2: no pool thread could be started */
+int v2xsim_advance_start(const v2xsim_advance_args* a) {
+  pthread_mutex_lock(&P.mu);
+  const int busy = P.async_busy;
+  pthread_mutex_unlock(&P.mu);
+  if (busy) return -1;
+  g_job = *a;
+  return par_start(g_job.E, advance_one, &g_job);
+}
+/* blocks until the started job is done; 0, or -1 when none was started */
+int v2xsim_advance_wait(void) { return par_wait(); }

@@ -278,7 +278,13 @@ class Agent(object):
         dn = self.brain.num_One_Node_Input
         n_iter = -(-num_transitions // E)
         rewards = np.zeros(n_iter * E)
+        # observations straight in the engine's packed layout (no float64 state / dense adjacency on the way to the GPU or to
+        # the replay memory) when the simulator offers them and the memory lives in HBM; V2X_RL_PACKED=0: the array path
+        packed = self._packed_rollouts()
         for it in range(n_iter):
+            if packed:
+                rewards[it * E:(it + 1) * E] = self._packed_iteration()
+                continue
             states, adj = self.env.observe(C)
             steps = self.num_Episodes * 0.8 * self.num_Train_Step * self.num_transition
             per_step = (MAX_EPSILON - MIN_EPSILON) / steps
@@ -310,6 +316,96 @@ class Agent(object):
                                         actions[e].reshape(1, -1), reward[e],
                                         np.concatenate((nxt[e].reshape(1, -1), adj[e].reshape(1, -1)), axis=-1)])
         return rewards[:num_transitions] if n_iter * E == num_transitions else rewards
+
+    def _packed_iteration(self):
+        """One iteration of _generate_batched on packed observations: same epsilon draws in the same order, same Q-values
+        (the same kernels on the same float32 rows and CSR), same stored transitions."""
+        env, rep = self.env, self.device_replay
+        E, n, C = env.E, self.num_D2D, self.num_CH
+        xe, mask, col, regular = env.observe_packed(C)
+        steps = self.num_Episodes * 0.8 * self.num_Train_Step * self.num_transition
+        per_step = (MAX_EPSILON - MIN_EPSILON) / steps
+        actions = np.zeros((E, n, 1), int)
+        greedy = []
+        draw, base = np.random.random, self.num_step
+        for e in range(E):
+            step_no = base + e
+            self.epsilon = MAX_EPSILON - per_step * step_no if step_no < steps else MIN_EPSILON
+            if draw() < self.epsilon:
+                actions[e] = _random_channels(n, 1, C)
+            else:
+                greedy.append(e)
+        if greedy:
+            if regular.all():
+                # ALL environments are scored, the exploring ones' rows are dropped: one batch shape for the whole run (one
+                # captured launch instead of one per distinct number of greedy environments), and a graph's Q-values do not
+                # depend on what else is in the batch (every kernel path gives the same bits, tests/test_gpu_shapes.py)
+                q = self._predict_packed(xe, col)                                         # [E, N, C]
+                actions[greedy] = np.argmax(q[greedy], axis=2)[:, :, None]
+            else:                                      # a link that is its own receiver (rare): the general CSR builder
+                states, adj = env.observe(C)
+                q = self._predict(states[greedy], adj[greedy])
+                actions[greedy] = np.transpose(np.argmax(q, axis=2))[:, :, None]
+        v2v, v2i, _ = env.act(actions)
+        self.num_step += E
+        reward = self.v2v_weight * v2v.sum(axis=(1, 2)) + self.v2i_weight * v2i.sum(axis=1)
+        xe_next = env.observe_packed(C)[0]
+        rep.add_many_packed(xe, xe_next, col, mask, regular, actions.reshape(E, n), reward)
+        samples = self.memory.samples                  # the host list only keeps the FIFO bookkeeping (train_observe(None) x E)
+        samples.extend([None] * E)
+        if len(samples) > self.memory.capacity:
+            del samples[:len(samples) - self.memory.capacity]
+        return reward
+
+    def _packed_rollouts(self):
+        """the batched rollout takes observations in the engine's packed layout (see _generate_batched)"""
+        C = self.num_CH
+        return (self.device_replay is not None and self.num_Neighbor == 1 and hasattr(self.env, 'observe_packed')
+                and self.env.packed_ok(C) and self._compact()
+                and self.brain.num_One_Node_Input + self.brain.num_One_Edge_Input == 3 * C + 1
+                and os.environ.get("V2X_RL_PACKED", "1") != "0")
+
+    def _warm_rollout_predict(self):
+        """One throw-away predict of the current observation before a training run: the rollout predict's buffers, workspaces
+        and captured launch exist before the first greedy step needs them (early steps explore, so a warm-up episode never
+        scores anything).  Consumes no random draw and changes no state."""
+        if self._batched() and self._packed_rollouts() and getattr(self.env, 'pos', None) is not None:
+            xe, _, col, regular = self.env.observe_packed(self.num_CH)
+            if regular.all():
+                self._predict_packed(xe, col)
+
+    def _predict_packed(self, xe, col):
+        """Q-values [E, N, C] (float32, a view of a pinned buffer: valid until the next call) of all environments from their
+        packed observations: two asynchronous copies in, one launch, one copy out, one synchronisation."""
+        from ..engine import DeviceBatch
+        rep, engine = self.device_replay, self.brain.model.engine
+        torch = rep.torch
+        E, n, C = xe.shape[0], self.num_D2D, self.num_CH
+        ne = col.shape[1]
+        io = getattr(self, '_rollout_io', None)
+        if io is None or io["E"] != E:
+            dev = rep.device
+            if rep.n_edges is None:
+                rep.n_edges = n * (n - 2)
+            io = self._rollout_io = {
+                "E": E,
+                "xe_pin": torch.empty((E * n, 16), dtype=torch.float32).pin_memory(), "col_pin": torch.empty(E * ne, dtype=torch.int32).pin_memory(),
+                "q_pin": torch.empty((E * n, C), dtype=torch.float32).pin_memory(),
+                "q_dev": torch.empty((E * n, C), dtype=torch.float32, device=dev)}
+            io["db"] = DeviceBatch.from_tensors(E, n, torch.empty((E * n, 16), dtype=torch.float32, device=dev), rep.row_ptr(E),
+                                                torch.empty(E * ne, dtype=torch.int32, device=dev), ne)
+            io["xe_np"] = io["xe_pin"].numpy().reshape(E, n, 16)
+            io["col_np"] = io["col_pin"].numpy().reshape(E, ne)
+            io["q_np"] = io["q_pin"].numpy().reshape(E, n, C)
+        db = io["db"]
+        np.copyto(io["xe_np"], xe)
+        np.copyto(io["col_np"], col)
+        db.xe.copy_(io["xe_pin"], non_blocking=True)
+        db.col_idx.copy_(io["col_pin"], non_blocking=True)
+        engine.forward(db, out=io["q_dev"])
+        io["q_pin"].copy_(io["q_dev"], non_blocking=True)
+        torch.cuda.current_stream(rep.device).synchronize()
+        return io["q_np"]
 
     # ------------------------------------------------------------------ learning
     def replay(self):
@@ -403,13 +499,15 @@ class Agent(object):
         self.num_Episodes, self.num_Train_Step = num_episodes, num_train_steps
         # Everything alive now (the imported frameworks, the engines, the simulator) goes to the collector's permanent
         # generation: a full collection inside a train step walked ~1e6 such objects -- 40-70 ms, once or twice per hundred
-        # steps of a 3 ms loop (measured, tools/prof_rl_sections.py).  The freeze is a process-wide change of the collector, so it
-        # ends with this call (gc.unfreeze in the finally below: cycles among the frozen objects become collectable again, and
-        # repeated train() calls do not pile up frozen generations -- ADVICE r04); V2X_RL_GC_FREEZE=0 leaves the collector alone.
+        # steps of a 3 ms loop (measured, tools/prof_rl_sections.py).  gc.freeze() alone is a list splice; a gc.collect() in front
+        # of it (to keep garbage out of the permanent generation) is that same 40-70 ms walk and was 0.4-0.7 ms per step of a
+        # 100-step run -- whatever garbage exists now simply waits for the unfreeze.  The freeze is a process-wide change of the
+        # collector, so it ends with this call (gc.unfreeze in the finally below: cycles among the frozen objects become
+        # collectable again, and repeated train() calls do not pile up frozen generations -- ADVICE r04); V2X_RL_GC_FREEZE=0
+        # leaves the collector alone.
         frozen = os.environ.get("V2X_RL_GC_FREEZE", "1") != "0"
         if frozen:
             import gc
-            gc.collect()
             gc.freeze()
         try:
             return self._train_loop(num_episodes, num_train_steps, save_dir, save_interval, verbose)
@@ -432,6 +530,7 @@ class Agent(object):
         # HBM-resident replay: the per-step losses and Q statistics stay on the device and are read back once per episode
         # (the reference reads them after every fit, BS_brain.py:835-845 -- two host synchronisations per train step here)
         defer = self.device_replay is not None and os.environ.get("V2X_RL_DEFER_STATS", "1") != "0"
+        self._warm_rollout_predict()
         for ep in range(num_episodes):
             self.env.new_random_game(self.num_D2D)
             pending = []

@@ -23,9 +23,22 @@ from .mtstream import MTStream, gauss_uniforms, box_muller
 _DIRS = 'udlr'        # direction codes 0..3
 
 
+def _usable_cpus():
+    """CPUs this process can keep busy: its affinity mask, cut to the cgroup's CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 class BatchedEnviron(object):
     def __init__(self, down_lane, up_lane, left_lane, right_lane, width, height, n_envs=1, seeds=None, workers=None,
-                 native=None):
+                 native=None, lookahead=False):
         """seeds: one seed per environment (each environment then reproduces `random.seed(seed); Environ(...)`);
         None with n_envs == 1: the process-wide stdlib generator is used (borrowed and returned around every call).
         workers: threads that share the channel update of a step (3,360 Gaussian draws + their transcendentals per
@@ -35,9 +48,13 @@ class BatchedEnviron(object):
         operations serialises on the GIL); 10 environments are fastest on one thread.  Environments are independent,
         so the result does not depend on the thread count.
         native: evaluate the array arithmetic of a step (channel update, rates, interference, observation) in
-        libv2xsim.so (csrc/v2xsim.c: the same formulas in C, OpenMP over the environments -- real threads, no GIL).  None:
+        libv2xsim.so (csrc/v2xsim.c: the same formulas in C, the environments spread over a pool of threads -- real threads, no GIL).  None:
         whenever the library is built and the environments own their streams (V2X_SIM_NATIVE=0 switches it off); the numpy
-        code below stays the definition, the two agree to the last bits of libm (tests: 1e-12)."""
+        code below stays the definition, the two agree to the last bits of libm (tests: 1e-12).
+        lookahead: compute the NEXT simulator step on a worker thread of the library while the caller is busy with the current
+        observation (nothing in a step depends on the actions except the rates paid for them, see act()); the result is taken
+        when act() is called next and dropped when anything else touches the simulator first, so every trajectory is the one
+        without it.  Needs the native library and own streams; at most one simulator of a process looks ahead at a time."""
         self._proto = Environ.__new__(Environ)                 # constants + path-loss models of the single simulator
         p = self._proto
         p.timestep = 0.01
@@ -65,22 +82,27 @@ class BatchedEnviron(object):
             raise RuntimeError("native=True but libv2xsim.so is not built (python -c 'import __graft_entry__ as g; g.build()')")
         self._mt_keys = self._mt_pos = None
         if self.native:
-            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            # at most 16 OpenMP threads: a call is 20-300 us of work per step, and on the 256-core host of an MI355X box 32
-            # threads brought 25-48 ms stalls a few times per hundred steps (tools/prof_rl_sections.py: spinning workers
-            # against the GPU runtime's own threads) for 0.2 ms of median; V2X_SIM_THREADS overrides
-            cap = int(os.environ.get("V2X_SIM_THREADS", "16"))
-            native_sim.set_threads(max(1, min(self.E, cores, cap)))
+            # threads of the library's pool: at most 16, and never more than the CPU time the process may use (cgroup cpu.max:
+            # 16 CPUs on the MI355X boxes, whatever the 256 hardware threads suggest) less one for this thread.  The pool
+            # sleeps between jobs; the OpenMP teams of rounds 3-4 kept spinning, ran the process into its CPU quota and got it
+            # parked for 25-50 ms a few times per hundred steps (csrc/v2xsim.c).  V2X_SIM_THREADS overrides.
+            cap = int(os.environ.get("V2X_SIM_THREADS", "0")) or min(16, max(1, _usable_cpus() - 1))
+            native_sim.set_threads(max(1, min(self.E, cap)))
             if not self._shared:                               # the streams' MT19937 states, where the library can advance them
                 self._mt_keys = np.empty((self.E, 624), np.uint32)
                 self._mt_pos = np.zeros(self.E, np.int32)
         self._pool = None
+        self.lookahead = bool(lookahead)
+        self._ahead = None                 # a started v2xsim_advance job: its output arrays (inputs stay untouched until taken)
+        self._obs = None                   # observation of the CURRENT channels: (v2v, v2i, state, adj, xe, mask, col, regular)
+        self._scratch = None
         self.streams = None if self._shared else [MTStream(int(s)) for s in seeds]
         if not self._shared and len(self.streams) != self.E:
             raise ValueError("need %d seeds" % self.E)
         if self._mt_keys is not None:
             for e, st in enumerate(self.streams):
                 st.attach(self._mt_keys[e], self._mt_pos, e)
+                st.on_touch = self._drop_lookahead             # any draw outside the library invalidates a step computed ahead
         # lane tables of the mobility rule, in the reference's checking order (Environment.py:247-324):
         # direction -> (moving axis, sign, [(lanes, new direction, side-step sign, gap sign)])
         L, R, U, D = p.left_lanes, p.right_lanes, p.up_lanes, p.down_lanes
@@ -98,6 +120,7 @@ class BatchedEnviron(object):
             self.env = env
 
         def __enter__(self):
+            self.env._drop_lookahead()                         # the streams are about to be drawn from
             if self.env._shared:
                 self.s = [MTStream.borrow_stdlib()]
                 return self.s
@@ -122,6 +145,8 @@ class BatchedEnviron(object):
     # ------------------------------------------------------------------ construction
     def new_random_game(self, n_Veh=0):
         """Environment.py:495-506 for every environment."""
+        self._drop_lookahead()
+        self._obs = None
         if n_Veh > 0:
             if n_Veh % 4:
                 raise ValueError("n_Veh must be a multiple of 4; got %d" % n_Veh)
@@ -199,6 +224,7 @@ class BatchedEnviron(object):
                         self.dest[e, i] = fast.sample(ce[i], 1)[0]
                     s._import(fast.getstate())
         self.activate_links = np.ones((E, N, 1), dtype=bool)
+        self._obs = None                                       # new receivers: the cached observation is of the old ones
 
     # ------------------------------------------------------------------ mobility
     def renew_positions(self):
@@ -206,6 +232,11 @@ class BatchedEnviron(object):
         move as arrays; the few that do are walked in the reference's order because each reached lane costs its
         environment one uniform draw (turn with probability 0.4)."""
         p = self._proto
+        self._drop_lookahead()
+        if self.native and self._mt_keys is not None:          # the same walk in C, on the streams' states (csrc/v2xsim.c)
+            native_sim.positions(self._mt_keys, self._mt_pos, self.pos, self.dirs, self.vel, p.timestep,
+                                 (p.up_lanes, p.down_lanes, p.left_lanes, p.right_lanes), p.width, p.height)
+            return
         dd = self.vel * p.timestep
         axis = np.where(self.dirs < 2, 1, 0)
         sign = np.where((self.dirs == 0) | (self.dirs == 3), 1.0, -1.0)
@@ -259,6 +290,8 @@ class BatchedEnviron(object):
         """renew_channel + fast fading (:378-406) for all environments; per environment ONE block of uniforms feeds the
         n + n^2 shadowing draws and the 2 n rb + 2 n^2 rb Rayleigh draws, in the reference's order."""
         E, n, rb = self.E, self.n_Veh, self.n_RB
+        self._drop_lookahead()
+        self._obs = None
         if (n + n * n + 2 * n * rb + 2 * n * n * rb) & 1:      # keep the odd value cached like random.gauss would
             raise NotImplementedError("odd number of draws per step")
         with self._rng() as rs:
@@ -359,12 +392,120 @@ class BatchedEnviron(object):
         self.V2V_Interference_all = 10 * np.log10(out)
 
     def act(self, actions):
-        """Agent.act (BS_brain.py:366-376) for all environments: rates under `actions`, then one simulator step."""
+        """Agent.act (BS_brain.py:366-376) for all environments: rates under `actions`, then one simulator step.
+        Only the rates depend on the actions (they are computed on the channels BEFORE the step); mobility, channels, the
+        observable interference and the next observation are one library call for all environments (v2xsim_advance), taken
+        from the look-ahead worker when it was started after the previous step."""
+        if self._ahead is not None and not self._ahead.get("done"):
+            native_sim.advance_wait()                          # (the pool is the library's only one: free it for the rates)
+            self._ahead["done"] = True
         rates = self.compute_reward_with_channel_selection(actions)
+        if self._one_call_step():
+            self._advance()
+            return rates
         self.renew_positions()
         self.renew_channels_fastfading()
         self.Compute_Interference(actions)
         return rates
+
+    # ------------------------------------------------------------------ the step as one library call (+ look-ahead)
+    def _one_call_step(self):
+        n, rb = self.n_Veh, self.n_RB
+        return (self.native and self._mt_keys is not None and 2 < n <= 31 and rb <= n and 3 * rb + 1 <= 16
+                and not (n + n * n + 2 * n * rb + 2 * n * n * rb) & 1)
+
+    def _start_job(self, ahead):
+        """One v2xsim_advance from the current state into fresh arrays; ahead: on the library's worker thread.
+        -> the job (its output arrays), or None when the worker is busy with another simulator's look-ahead."""
+        if any(s.gauss_next is not None for s in self.streams):
+            raise RuntimeError("a stream holds a cached gauss value")
+        E, n, rb, p = self.E, self.n_Veh, self.n_RB, self._proto
+        n_u = n + n * n + 2 * n * rb + 2 * n * n * rb
+        if self._scratch is None or self._scratch.shape != (E, 2 * n_u):
+            self._scratch = np.empty((E, 2 * n_u))
+        f64, c = np.float64, np.ascontiguousarray
+        out = {"keys": np.empty_like(self._mt_keys), "mtpos": np.empty_like(self._mt_pos), "xy": np.empty((E, n, 2)),
+               "dirs": np.empty((E, n), np.int8), "v2i_shadow": np.empty((E, n)), "v2v_shadow": np.empty((E, n, n)),
+               "v2v_abs": np.empty((E, n, n)), "v2i_abs": np.empty((E, n)), "v2v_ff": np.empty((E, n, n, rb)),
+               "v2i_ff": np.empty((E, n, rb)), "interf_db": np.empty((E, n, 1, rb)), "state": np.empty((E, n, 3 * rb + 1)),
+               "adj": np.empty((E, n, n)), "xe": np.empty((E, n, 16), np.float32), "mask": np.empty((E, n), np.int32),
+               "col": np.empty((E, n * (n - 2)), np.int32), "regular": np.empty(E, np.uint8), "scratch": self._scratch}
+        tabs = [c(np.asarray(t, f64)) for t in (p.up_lanes, p.down_lanes, p.left_lanes, p.right_lanes)]
+        ins = {"up": tabs[0], "down": tabs[1], "left": tabs[2], "right": tabs[3], "vel": c(self.vel, f64), "dest": c(self.dest, np.int64),
+               "keys_in": self._mt_keys, "mtpos_in": self._mt_pos, "xy_in": c(self.pos, f64), "dirs_in": c(self.dirs, np.int8),
+               "v2i_shadow_in": c(self._v2i_shadow, f64), "v2v_shadow_in": c(self._v2v_shadow, f64)}
+        a = native_sim.AdvanceArgs()
+        a.E, a.n, a.rb, a.n_lanes = E, n, rb, len(tabs[0])
+        a.timestep, a.width, a.height = p.timestep, p.width, p.height
+        a.p_v2v, a.p_v2i = self.V2V_power_dB_List[self.fixed_v2v_power_index], self.V2I_power_dB
+        a.veh_gain, a.veh_nf, a.sig2 = self.vehAntGain, self.vehNoiseFigure, self.sig2
+        for k, v in list(ins.items()) + list(out.items()):
+            setattr(a, k, v.ctypes.data)
+        job = {"out": out, "ins": ins, "args": a}            # (the arrays the library reads and writes stay alive with the job)
+        if ahead:
+            return job if native_sim.advance_start(a) else None
+        native_sim.advance(a)
+        return job
+
+    def __del__(self):
+        try:
+            self._drop_lookahead()                             # the worker writes into arrays this object keeps alive
+        except Exception:
+            pass
+
+    def _drop_lookahead(self):
+        """A started look-ahead step is abandoned (its inputs were never written): wait for the worker and forget the result."""
+        if self._ahead is not None:
+            if not self._ahead.get("done"):
+                native_sim.advance_wait()
+            self._ahead = None
+
+    def _advance(self):
+        job = self._ahead
+        if job is not None:
+            if not job.get("done"):
+                native_sim.advance_wait()
+            self._ahead = None
+        else:
+            job = self._start_job(False)
+        o = job["out"]
+        self._mt_keys[:] = o["keys"]                           # in place: the MTStream objects are attached to these rows
+        self._mt_pos[:] = o["mtpos"]
+        self.pos[:] = o["xy"]
+        self.dirs[:] = o["dirs"]
+        self._v2i_shadow, self._v2v_shadow = o["v2i_shadow"], o["v2v_shadow"]
+        self.V2V_channels_abs, self.V2I_channels_abs = o["v2v_abs"], o["v2i_abs"]
+        self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading = o["v2v_ff"], o["v2i_ff"]
+        self.V2V_Interference_all = o["interf_db"]
+        self._obs = (o["v2v_ff"], o["v2i_ff"], o["state"], o["adj"], o["xe"], o["mask"], o["col"], o["regular"].astype(bool))
+        if self.lookahead:
+            self._ahead = self._start_job(True)
+
+    def _observation(self, n_channels):
+        """the cached observation of the current channels (state, adj, xe, mask, col, regular), or None"""
+        ob = self._obs
+        if (ob is not None and n_channels == self.n_RB and ob[0] is self.V2V_channels_with_fastfading
+                and ob[1] is self.V2I_channels_with_fastfading):
+            return ob[2:]
+        return None
+
+    def observe_packed(self, n_channels=4):
+        """observe() in the engine's packed form (rl/replay.py, include/v2xgnn.h): xe [E, N, 16] float32 = the observation rows
+        cast like Keras casts the feed, source masks [E, N] int32, CSR sources by destination [E, N (N-2)] int32 (zeros
+        for a graph where some link is its own receiver) and the regular flags [E].  Same arrays every call until the
+        simulator moves: read-only for the caller.  Needs the native library (packed_ok())."""
+        ob = self._observation(n_channels)
+        if ob is None:
+            if not self.packed_ok(n_channels):
+                raise RuntimeError("observe_packed needs libv2xsim.so, 3..31 links and n_channels == n_RB")
+            v2v, v2i = self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading
+            ob = native_sim.observe_packed(self.dest, v2v, v2i, self.V2V_power_dB_List[self.fixed_v2v_power_index], n_channels)
+            if v2v.flags.c_contiguous and v2i.flags.c_contiguous:
+                self._obs = (v2v, v2i) + tuple(ob)
+        return ob[2], ob[3], ob[4], ob[5]
+
+    def packed_ok(self, n_channels=4):
+        return bool(self.native and n_channels == self.n_RB and 2 < self.n_Veh <= 31 and 3 * n_channels + 1 <= 16)
 
     # ------------------------------------------------------------------ the agent's view
     def observe(self, n_channels=4):
@@ -372,6 +513,9 @@ class BatchedEnviron(object):
         (BS_brain.py:389-407, :458-467) and the adjacency [E, N, N] (Adj[p, q] = 0 for p == q and for the receiver p of
         link q, :441-445)."""
         E, n, C = self.E, self.n_Veh, n_channels
+        ob = self._observation(C)
+        if ob is not None:                                     # computed with the step (same arrays until the simulator moves)
+            return ob[0], ob[1]
         if self.native and C == self.n_RB and n > 2:
             return native_sim.observe(self.dest, self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading,
                                       self.V2V_power_dB_List[self.fixed_v2v_power_index], C)

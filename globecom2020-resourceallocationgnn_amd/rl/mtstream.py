@@ -21,6 +21,7 @@ class MTStream(object):
         self._ext = None               # attach(): the MT19937 state lives in caller-owned arrays (bulk draws in C)
         self.session = None            # a list while the owner is inside one `with env._rng()` block
         self._live = False             # pulled in during the current session: no per-draw synchronisation until it ends
+        self.on_touch = None           # called before the external state is read (the owner drops work computed ahead from it)
         self.gauss_next = None
         if _state is None:
             _state = _random.Random(seed).getstate()       # CPython seeds through init_by_array: reuse it verbatim
@@ -40,6 +41,8 @@ class MTStream(object):
     def _pull(self):
         if self._ext is None or self._live:
             return
+        if self.on_touch is not None:
+            self.on_touch()
         keys_row, pos_arr, idx = self._ext
         self._rs.set_state(('MT19937', keys_row, int(pos_arr[idx])))
         if self.session is not None:

@@ -1,8 +1,8 @@
-"""ctypes binding of libv2xsim.so (csrc/v2xsim.c): the array arithmetic of a batched simulator step in C + OpenMP.
+"""ctypes binding of libv2xsim.so (csrc/v2xsim.c): the array arithmetic of a batched simulator step in C on a pool of threads.
 
 The numpy expressions of rl/batched_env.py stay the definition (and the fallback when the library is not built, or with
-V2X_SIM_NATIVE=0); the library evaluates the same formulas in the same order, one OpenMP thread per group of
-environments -- which numpy cannot do (its Python glue serialises on the GIL: rl/batched_env.py, `workers`).
+V2X_SIM_NATIVE=0); the library evaluates the same formulas in the same order, the environments spread over
+the pool -- which numpy cannot do (its Python glue serialises on the GIL: rl/batched_env.py, `workers`).
 Random streams stay in Python; the library is handed the uniforms of a step."""
 import ctypes as C
 import os
@@ -25,7 +25,7 @@ def _load():
     if not os.path.exists(path):
         return None
     lib = C.CDLL(path)
-    if lib.v2xsim_abi() != 1:
+    if lib.v2xsim_abi() != 2:
         return None
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
     lib.v2xsim_channels.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp]
@@ -38,11 +38,35 @@ def _load():
     lib.v2xsim_reset_vehicles.argtypes = [C.c_int, C.c_int, u32p, i32p, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, dp,
                                           C.POINTER(C.c_int8), dp]
     lib.v2xsim_sample_dest.argtypes = [C.c_int, C.c_int, C.c_int, u32p, i32p, ip, ip]
+    u8p, f32p, i8p = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int8)
+    lib.v2xsim_observe_packed.argtypes = [C.c_int, C.c_int, C.c_int, ip, dp, dp, C.c_double, dp, dp, f32p, i32p, i32p, u8p]
+    lib.v2xsim_positions.argtypes = [C.c_int, C.c_int, u32p, i32p, dp, i8p, dp, C.c_double, C.c_int, dp, dp, dp, dp, C.c_double, C.c_double]
+    lib.v2xsim_advance.argtypes = [C.POINTER(AdvanceArgs)]
+    lib.v2xsim_advance_start.argtypes = [C.POINTER(AdvanceArgs)]
+    lib.v2xsim_advance_start.restype = C.c_int
+    lib.v2xsim_advance_wait.argtypes = []
+    lib.v2xsim_advance_wait.restype = C.c_int
+    for f in (lib.v2xsim_observe_packed, lib.v2xsim_positions, lib.v2xsim_advance):
+        f.restype = None
     for f in (lib.v2xsim_channels, lib.v2xsim_reward, lib.v2xsim_interference, lib.v2xsim_observe, lib.v2xsim_set_threads,
               lib.v2xsim_mt_uniforms, lib.v2xsim_reset_vehicles, lib.v2xsim_sample_dest):
         f.restype = None
     _lib = lib
+    import atexit
+    atexit.register(lib.v2xsim_advance_wait)                   # a look-ahead job still running must not outlive its arrays
     return lib
+
+
+class AdvanceArgs(C.Structure):
+    """v2xsim_advance_args of csrc/v2xsim.c (same order)"""
+    _fields_ = ([("E", C.c_int32), ("n", C.c_int32), ("rb", C.c_int32), ("n_lanes", C.c_int32),
+                 ("timestep", C.c_double), ("width", C.c_double), ("height", C.c_double)]
+                + [(k, C.c_void_p) for k in ("up", "down", "left", "right", "vel", "dest")]
+                + [(k, C.c_double) for k in ("p_v2v", "p_v2i", "veh_gain", "veh_nf", "sig2")]
+                + [(k, C.c_void_p) for k in ("keys_in", "mtpos_in", "xy_in", "dirs_in", "v2i_shadow_in", "v2v_shadow_in",
+                                             "keys", "mtpos", "xy", "dirs", "v2i_shadow", "v2v_shadow",
+                                             "v2v_abs", "v2i_abs", "v2v_ff", "v2i_ff", "interf_db", "state", "adj",
+                                             "xe", "mask", "col", "regular", "scratch")])
 
 
 def available():
@@ -151,3 +175,44 @@ def sample_dest(keys, pos, cand):
     k, p = _mt(keys, pos)
     lib.v2xsim_sample_dest(E, n, m, k, p, _i(cand), _i(dest))
     return dest
+
+
+def observe_packed(dest, v2v_ff, v2i_ff, power, n_channels):
+    """observe() plus the same observation in the engine's packed form: xe [E, n, 16] float32, source masks [E, n] int32, CSR
+    sources [E, n (n-2)] int32 (zeros for an irregular graph) and the regular flags [E]."""
+    lib = _load()
+    E, n, _, rb = v2v_ff.shape
+    dest, v2v_ff, v2i_ff = _c(dest, np.int64), _c(v2v_ff), _c(v2i_ff)
+    state, adj = np.empty((E, n, 3 * n_channels + 1)), np.empty((E, n, n))
+    xe, mask = np.empty((E, n, 16), np.float32), np.empty((E, n), np.int32)
+    col, regular = np.empty((E, max(n * (n - 2), 1)), np.int32), np.empty(E, np.uint8)
+    lib.v2xsim_observe_packed(E, n, n_channels, _i(dest), _d(v2v_ff), _d(v2i_ff), float(power), _d(state), _d(adj),
+                              xe.ctypes.data_as(C.POINTER(C.c_float)), mask.ctypes.data_as(C.POINTER(C.c_int32)),
+                              col.ctypes.data_as(C.POINTER(C.c_int32)), regular.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return state, adj, xe, mask, col, regular.astype(bool)
+
+
+def positions(keys, pos, xy, dirs, vel, timestep, lanes, width, height):
+    """renew_positions of every environment IN PLACE (xy [E, n, 2], dirs [E, n] int8; turn draws from the streams keys / pos);
+    lanes = (up, down, left, right) tables."""
+    lib = _load()
+    E, n = dirs.shape
+    assert xy.dtype == np.float64 and xy.flags.c_contiguous and dirs.dtype == np.int8 and dirs.flags.c_contiguous
+    tabs = [_c(np.asarray(t, np.float64)) for t in lanes]
+    k, p = _mt(keys, pos)
+    vel = _c(vel)
+    lib.v2xsim_positions(E, n, k, p, _d(xy), dirs.ctypes.data_as(C.POINTER(C.c_int8)), _d(vel), float(timestep), len(tabs[0]),
+                         _d(tabs[0]), _d(tabs[1]), _d(tabs[2]), _d(tabs[3]), float(width), float(height))
+
+
+def advance(args):
+    _load().v2xsim_advance(C.byref(args))
+
+
+def advance_start(args):
+    """-> True when the worker thread took the job (False: it is busy with another simulator's)"""
+    return _load().v2xsim_advance_start(C.byref(args)) == 0
+
+
+def advance_wait():
+    return _load().v2xsim_advance_wait() == 0

@@ -45,11 +45,14 @@ class DeviceReplay(object):
 
     # ------------------------------------------------------------------ storage
     def _grow(self, need):
-        """Storage grows geometrically up to `capacity` (the reference's 1e6-transition cap would be 4.1 GB at 20 links)."""
+        """Storage grows geometrically up to `capacity` (the reference's 1e6-transition cap is 4.1 GB at 20 links).  The
+        first allocation holds 65,536 transitions (275 MB at 20 links, 0.1 % of the HBM): growing means new tensors and a
+        copy, 45-50 ms on the host -- paid at 65,536, 131,072, ... stored transitions instead of inside the first hundred
+        train steps (tools/prof_rl_sections.py)."""
         if need <= self._alloc:
             return
         torch, n, E = self.torch, self.n, self.n_edges
-        new = min(self.capacity, max(need, 2 * self._alloc, 4096))
+        new = min(self.capacity, max(need, 2 * self._alloc, 65536))
         def grow(old, shape, dtype):
             t = torch.zeros((new,) + shape, dtype=dtype, device=self.device)
             if old is not None:
@@ -111,8 +114,44 @@ class DeviceReplay(object):
         self._stage.append((xe, xe_next, col, action, reward, mask, regular))      # one block of K transitions
         self._n_staged += K
 
+    def add_many_packed(self, xe, xe_next, col, mask, regular, action, reward):
+        """add_many for observations that are ALREADY in the stored layout (BatchedEnviron.observe_packed: xe / xe_next
+        [K, n, 16] float32, col [K, n (n-2)] int32, mask [K, n] int32, regular [K] bool): staged as they are.  The caller
+        must not write to the arrays afterwards (the simulator hands out fresh ones every step)."""
+        K, n = mask.shape
+        if n != self.n or n > self.MAX_LINKS:
+            raise ValueError("add_many_packed: %d links, this memory holds %d (at most %d)" % (n, self.n, self.MAX_LINKS))
+        if self.n_edges is None:
+            self.n_edges = n * (n - 2)
+        if (xe.dtype != np.float32 or xe.shape != (K, n, 16) or xe_next.shape != xe.shape or xe_next.dtype != np.float32
+                or col.dtype != np.int32 or col.shape != (K, max(self.n_edges, 1)) or mask.dtype != np.int32):
+            raise ValueError("add_many_packed: arrays are not in the packed layout")
+        self._stage.append((xe, xe_next, col, np.asarray(action, np.int32).reshape(K, n), np.asarray(reward, np.float64).reshape(K),
+                            mask, np.asarray(regular, bool)))
+        self._n_staged += K
+
     def __len__(self):
         return min(self.capacity, self.size + self._n_staged)
+
+    def _to_device(self, dst, src, name):
+        """dst (a slice of a storage tensor) <- src (host array) through a pinned staging buffer: the copy is asynchronous, the
+        buffer is one of four per (tensor, shape) and its event guards the reuse."""
+        torch = self.torch
+        key = ("stage", name, tuple(src.shape))
+        ring = self._idx_ring.get(key)
+        if ring is None:
+            ring = self._idx_ring[key] = {"pin": [torch.empty(tuple(src.shape), dtype=dst.dtype).pin_memory() for _ in range(4)],
+                                          "ev": [None] * 4, "next": 0}
+            ring["np"] = [t.numpy() for t in ring["pin"]]
+        i = ring["next"]
+        ring["next"] = (i + 1) % 4
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()
+        np.copyto(ring["np"][i], src)
+        dst.copy_(ring["pin"][i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        ring["ev"][i] = ev
 
     def flush(self):
         """Staged transitions -> HBM (one copy per tensor; ring wrap handled by splitting at the end of the storage)."""
@@ -128,8 +167,11 @@ class DeviceReplay(object):
         pos, done = self.head, 0
         while done < k:
             m = min(k - done, self._alloc - pos)
-            for t, a in zip(dst, cols):
-                t[pos:pos + m].copy_(torch.from_numpy(np.ascontiguousarray(a[done:done + m])))
+            for t, a, name in zip(dst, cols, ("xe", "xe_next", "col", "action", "reward", "mask")):
+                if self.device.type == "cuda" and m <= 4096:
+                    self._to_device(t[pos:pos + m], a[done:done + m], name)
+                else:
+                    t[pos:pos + m].copy_(torch.from_numpy(np.ascontiguousarray(a[done:done + m])))
             self._regular[pos:pos + m] = regular[done:done + m]
             pos, done = pos + m, done + m
             if pos == self.capacity:                   # full ring: overwrite the oldest transitions

@@ -38,8 +38,13 @@ def start_env(n_links=None):
     return env
 
 
-def start_env_batched(n_links, n_envs, seed):
-    """E environments on the same lane grid, environment e seeded with seed + 104729 e (rl/batched_env.py)."""
+def start_env_batched(n_links, n_envs, seed, lookahead=None):
+    """E environments on the same lane grid, environment e seeded with seed + 104729 e (rl/batched_env.py).
+    lookahead: compute every next simulator step on the library's worker thread while the agent scores and replays (same
+    trajectories, see BatchedEnviron); default on, V2X_SIM_LOOKAHEAD=0 switches it off."""
+    import os
+    if lookahead is None:
+        lookahead = os.environ.get("V2X_SIM_LOOKAHEAD", "1") != "0"
     from .batched_env import BatchedEnviron
     up_lanes = [3.5 / 2, 3.5 / 2 + 3.5, 250 + 3.5 / 2, 250 + 3.5 + 3.5 / 2, 500 + 3.5 / 2, 500 + 3.5 + 3.5 / 2]
     down_lanes = [250 - 3.5 - 3.5 / 2, 250 - 3.5 / 2, 500 - 3.5 - 3.5 / 2, 500 - 3.5 / 2, 750 - 3.5 - 3.5 / 2, 750 - 3.5 / 2]
@@ -47,6 +52,7 @@ def start_env_batched(n_links, n_envs, seed):
     right_lanes = [433 - 3.5 - 3.5 / 2, 433 - 3.5 / 2, 866 - 3.5 - 3.5 / 2, 866 - 3.5 / 2, 1299 - 3.5 - 3.5 / 2, 1299 - 3.5 / 2]
     env = BatchedEnviron(down_lanes, up_lanes, left_lanes, right_lanes, 750, 1299, n_envs=n_envs,
                          seeds=[seed + 104729 * e for e in range(n_envs)])
+    env.lookahead = bool(lookahead) and env.native
     env.new_random_game(n_links)
     return env
 

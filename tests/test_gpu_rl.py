@@ -292,3 +292,49 @@ def test_batched_rollouts_on_the_engine(n_veh, feat, batch, n_envs):
         assert np.array_equal(env_n.pos, env_d.pos) and np.array_equal(env_n.dirs, env_d.dirs)
         assert np.allclose(rew_n, rew_d, rtol=1e-9, atol=1e-12)
         assert np.allclose(loss_n, loss_d, rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("n_veh,feat,batch,n_envs", [(4, 16, 64, 6), (20, 64, 256, 50)])
+def test_packed_rollout_with_lookahead_is_the_array_rollout_bitwise(n_veh, feat, batch, n_envs):
+    """the rollout of a batched step as observe_packed -> pinned copy -> one predict launch -> argmax ->
+    add_many_packed, with the next simulator step computed on the library's worker thread meanwhile -- against the array path
+    (float64 observations, dense adjacency, PackedBatch.from_dense, add_many; V2X_RL_PACKED=0) on a simulator without
+    look-ahead: same epsilon draws, same greedy actions, same rewards, the same bytes in the replay memory and bit-identical
+    losses and weights after two episodes (a reset drops a started look-ahead step)."""
+    from v2xgnn.rl import Agent, RL_Config, native_sim
+    from v2xgnn.rl.train import start_env_batched
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+
+    def run(packed, lookahead):
+        random.seed(33)
+        np.random.seed(33)
+        old = os.environ.get("V2X_RL_PACKED")
+        os.environ["V2X_RL_PACKED"] = "1" if packed else "0"
+        try:
+            env = start_env_batched(n_veh, n_envs, 33, lookahead=lookahead)
+            cfg = RL_Config()
+            cfg.set_train_value(feat, 0.5, batch, 1, 0.1)
+            agent = Agent(n_veh, env.n_RB, env.n_Neighbor, feat, env, cfg, seed=33, device_replay=True)
+            loss, reward_step, _, q_mean, q_max, _, _ = agent.train(2, 6)
+        finally:
+            if old is None:
+                del os.environ["V2X_RL_PACKED"]
+            else:
+                os.environ["V2X_RL_PACKED"] = old
+        rep = agent.device_replay
+        rep.flush()
+        k = rep.size
+        mem = [t[:k].cpu().numpy() for t in (rep.xe, rep.xe_next, rep.col, rep.mask, rep.action, rep.reward)]
+        return env, agent, loss, reward_step, q_mean, np.concatenate([a.ravel() for a in agent.brain.model.get_weights()]), mem
+
+    env_p, ag_p, loss_p, rew_p, qm_p, w_p, mem_p = run(True, True)
+    env_a, ag_a, loss_a, rew_a, qm_a, w_a, mem_a = run(False, False)
+    assert env_p.lookahead and not env_a.lookahead and getattr(ag_p, "_rollout_io", None) is not None
+    assert getattr(ag_a, "_rollout_io", None) is None
+    assert ag_p.num_step == ag_a.num_step and len(ag_p.memory.samples) == len(ag_a.memory.samples)
+    assert np.array_equal(rew_p, rew_a)
+    for a, b in zip(mem_p, mem_a):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.array_equal(loss_p, loss_a) and np.array_equal(qm_p, qm_a) and np.array_equal(w_p, w_a)
+    assert np.array_equal(env_p.pos, env_a.pos) and np.array_equal(env_p._mt_keys, env_a._mt_keys)

@@ -237,6 +237,99 @@ def test_native_step_equals_the_numpy_step(n_links):
         assert s0._export() == s1._export()                    # same MT19937 position after 150 x 3,360 (or 160) draws
 
 
+def test_native_walk_with_turns_and_reentries_equals_the_numpy_walk():
+    """renew_positions in C (v2xsim_positions / v2xsim_advance) against the numpy + Python walk: vehicles made fast enough to
+    reach a crossing lane almost every step and to leave the map within the test -- positions, directions and the streams
+    (one uniform per reached lane, in the reference's checking order) stay identical, bit for bit."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    E, n = 6, 8
+    envs = []
+    for native in (False, True):
+        env = BatchedEnviron(*_lanes(), 750, 1299, n_envs=E, seeds=[5 + 7919 * e for e in range(E)], workers=1, native=native)
+        env.new_random_game(n)
+        env.vel[:] = env.vel * 150.0                           # 15-22 m per step: a lane every few steps, the map edge in < 100
+        envs.append(env)
+    a, b = envs
+    turns = exits = 0
+    for it in range(400):
+        d0, p0 = a.dirs.copy(), a.pos.copy()
+        a.renew_positions()
+        b.renew_positions()
+        assert np.array_equal(a.pos, b.pos) and np.array_equal(a.dirs, b.dirs), it
+        turns += int((a.dirs != d0).sum())
+        exits += int((np.abs(a.pos - p0).max(axis=2) > 30).sum())
+    assert turns > 200 and exits > 20, (turns, exits)
+    for s0, s1 in zip(a.streams, b.streams):
+        assert s0._export() == s1._export()
+    # ... and as part of the one-call step (act): same walk, then the channel draws
+    act = np.zeros((E, n, 1), int)
+    for it in range(50):
+        ra, rb = a.act(act), b.act(act)
+        assert np.array_equal(a.pos, b.pos) and np.array_equal(a.dirs, b.dirs), it
+        assert np.allclose(ra[0], rb[0], rtol=1e-9, atol=0)
+    for s0, s1 in zip(a.streams, b.streams):
+        assert s0._export() == s1._export()
+
+
+def test_lookahead_is_invisible():
+    """lookahead=True computes the next step on the library's worker thread while the caller is busy: every array the
+    simulator exposes, every rate and every stream is bit for bit what the simulator without it produces -- through plain
+    steps, episode resets, steps made by hand (renew_positions / renew_channels_fastfading) and direct draws from a stream, all
+    of which find a started look-ahead and must drop it."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    E, n = 7, 20
+    envs = []
+    for ahead in (False, True):
+        env = BatchedEnviron(*_lanes(), 750, 1299, n_envs=E, seeds=[3 + 15485863 * e for e in range(E)], lookahead=ahead)
+        env.new_random_game(n)
+        envs.append(env)
+    a, b = envs
+    assert b.lookahead and not a.lookahead and a._one_call_step()
+    rng = np.random.default_rng(9)
+    names = ("pos", "dirs", "vel", "dest", "_v2i_shadow", "_v2v_shadow", "V2V_channels_abs", "V2I_channels_abs",
+             "V2V_channels_with_fastfading", "V2I_channels_with_fastfading", "V2V_Interference_all", "_mt_keys", "_mt_pos")
+
+    def same(tag):
+        for k in names:
+            assert np.array_equal(getattr(a, k), getattr(b, k)), (tag, k)
+        for x, y in zip(a.observe(4) + a.observe_packed(4), b.observe(4) + b.observe_packed(4)):
+            assert x.dtype == y.dtype and np.array_equal(x, y), tag
+    for it in range(60):
+        act = rng.integers(0, 4, size=(E, n, 1))
+        for x, y in zip(a.act(act), b.act(act)):
+            assert np.array_equal(x, y)
+        assert a._ahead is None and b._ahead is not None      # the next step is already on its way
+        same(it)
+        if it % 13 == 5:
+            a.new_random_game(n); b.new_random_game(n)
+            assert b._ahead is None
+            same("reset")
+        if it % 17 == 3:
+            a.renew_positions(); b.renew_positions()
+            a.renew_channels_fastfading(); b.renew_channels_fastfading()
+            same("by hand")
+        if it % 19 == 7:
+            assert a.streams[2].random() == b.streams[2].random() and b._ahead is None        # a bare draw drops it too
+            for x, y in zip(a.act(act), b.act(act)):
+                assert np.array_equal(x, y)
+            with a._rng() as ra, b._rng() as rb:
+                assert ra[1].random() == rb[1].random()
+            assert b._ahead is None
+    # the packed observation is the dense one: float32 rows, source masks, CSR sources by destination
+    st, adj = b.observe(4)
+    xe, mask, col, regular = b.observe_packed(4)
+    assert np.array_equal(xe[:, :, :13], st.astype(np.float32)) and not xe[:, :, 13:].any()
+    assert np.array_equal(mask, ((adj != 0).astype(np.int64) << np.arange(n)[None, :, None]).sum(axis=1))
+    for e in range(E):
+        assert regular[e] == bool(np.all((adj[e] != 0).sum(axis=0) == n - 2))
+        if regular[e]:
+            assert np.array_equal(col[e], np.nonzero(adj[e].T)[1])
+
+
 def test_native_mt19937_is_the_stdlib_stream():
     from v2xgnn.rl import native_sim
     if not native_sim.available():

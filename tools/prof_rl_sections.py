@@ -12,6 +12,8 @@ random.seed(1001); np.random.seed(1001)
 cfg = RL_Config(); cfg.set_train_value(64, 0.5, 4096, 1, 0.1)
 env = start_env_batched(20, 50, 1001)
 agent = Agent(env.n_Veh, env.n_RB, env.n_Neighbor, 64, env, cfg, seed=1001, device=0, use_graph=True)
+_ctx = torch.cuda.stream(torch.cuda.Stream()) if os.environ.get("STREAM", "1") != "0" else None     # hipGraphs need a non-default stream (as bench.py)
+if _ctx is not None: _ctx.__enter__()
 agent.train(1, 2)
 if os.environ.get('THREADS'): native_sim.set_threads(int(os.environ['THREADS']))
 rec = {}
@@ -21,10 +23,17 @@ def wrap(obj, name, label=None):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); rec.setdefault(label, []).append(time.perf_counter() - t0); return r
     setattr(obj, name, g)
-for nm in ("mt_uniforms", "channels", "observe", "reward", "interference_db"):
+for nm in ("mt_uniforms", "channels", "observe", "reward", "interference_db", "advance", "advance_start", "advance_wait", "observe_packed"):
     wrap(native_sim, nm, "native." + nm)
 for nm in ("observe", "act", "new_random_game", "renew_positions", "renew_channels_fastfading", "renew_channel", "renew_neighbor", "_advance_channels", "act_for_training"):
     if hasattr(env, nm): wrap(env, nm, "env." + nm)
+wrap(env, "_advance", "env._advance"); wrap(env, "_start_job", "env._start_job")
+wrap(agent, "_packed_iteration"); wrap(agent, "_predict_packed"); wrap(agent.device_replay, "add_many_packed"); wrap(agent.device_replay, "flush")
+wrap(agent.brain, "update_target_model"); wrap(agent.brain.model, "consume_fit_shuffle")
+_cpu = torch.Tensor.cpu
+def _cpu_timed(self, *a, **k):
+    t0 = time.perf_counter(); r = _cpu(self, *a, **k); rec.setdefault("tensor.cpu()", []).append(time.perf_counter() - t0); return r
+torch.Tensor.cpu = _cpu_timed
 wrap(agent, "_predict"); wrap(agent, "_generate_batched"); wrap(agent, "_replay_on_device"); wrap(agent, "train_observe")
 wrap(agent.device_replay, "add_many"); wrap(agent.device_replay, "sample"); wrap(agent.memory, "sample_indices")
 wrap(agent.brain.model.engine, "dqn_step"); wrap(agent.brain.model.engine, "forward", "engine.forward")

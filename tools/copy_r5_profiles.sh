@@ -7,6 +7,6 @@ cp $O/kernel_stats_share4.txt $P/r05_kernel_stats_share4.txt; cp $O/kernel_stats
 cp $O/mfma_share4.txt $P/r05_pmc_share4.txt; cp $O/mfma_share8.txt $P/r05_pmc_share8.txt
 cp $O/stalls.txt $P/r05_stalls.txt
 cp $O/roofline.md $P/r05_roofline.md; cp $O/roofline_cfg4.md $P/r05_roofline_configs3.md; cp $O/roofline_cfg5.md $P/r05_roofline_configs4.md
-for f in dropin_profile dp_host_overhead dp_host_overhead_b512 predict_latency gputests lib_sha rl_sections split_phases_b512 split_phases_b1024 mlpwg_phases_b512 degree_sweep wide_tail_ab ragged_small_ab soak_split; do cp $O/$f.txt $P/r05_$f.txt; done
+for f in dropin_profile dp_host_overhead dp_host_overhead_b512 predict_latency gputests lib_sha rl_sections split_phases_b512 split_phases_b1024 mlpwg_phases_b512 degree_sweep wide_tail_ab ragged_small_ab soak_split rl_sections_arrays_no_lookahead rl_loop_kernels cpu_quota; do cp $O/$f.txt $P/r05_$f.txt; done
 cp $O/fetch_cfg4.txt $P/r05_pmc_fetch_cfg4.txt; cp $O/write_cfg4.txt $P/r05_pmc_write_cfg4.txt; cp $O/fetch_cfg5.txt $P/r05_pmc_fetch_cfg5.txt; cp $O/write_cfg5.txt $P/r05_pmc_write_cfg5.txt
 cp $O/hbm_traffic.json $P/hbm_traffic.json

@@ -55,6 +55,9 @@ bash tools/wide_tail_ab.sh 2>&1 | cut -c1-330 > $O/wide_tail_ab.txt
 bash tools/ragged_small_ab.sh > $O/ragged_small_ab.txt 2>&1
 SOAK_STEPS=90000 python tools/soak_split.py 2>&1 | grep -v amdgpu.ids | tail -1 > $O/soak_split.txt
 python tools/prof_rl_sections.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 > $O/rl_sections.txt
+V2X_SIM_LOOKAHEAD=0 V2X_RL_PACKED=0 python tools/prof_rl_sections.py 2>&1 | grep -v amdgpu.ids | cut -c1-400 > $O/rl_sections_arrays_no_lookahead.txt
+bash tools/rl_loop_kernels.sh 2>&1 | grep -v -e amdgpu.ids -e rocprofv3 | cut -c1-200 > $O/rl_loop_kernels.txt
+cat /sys/fs/cgroup/cpu.max > $O/cpu_quota.txt 2>/dev/null; nproc >> $O/cpu_quota.txt
 python bench.py --workload cfg0 --envs 10 > $O/bench_cfg0_episode_envs10.json 2>/dev/null
 for i in 1 2 3; do python bench.py --workload cfg2loop --envs 50 --episodes 5 > $O/bench_cfg2loop_envs50_run$i.json 2>/dev/null; done
 python tools/predict_latency.py 2>&1 | grep -v amdgpu.ids > $O/predict_latency.txt

@@ -15,3 +15,4 @@ print("total kernel time %.3f ms over %d launches" % (tot / 1e6, sum(int(r["Call
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:22]:
     print("%-70s calls %6s total %9.3f ms avg %8.2f us" % (r["Name"][:70], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3))
 PY
+rm -f $OUT/*kernel_trace.csv $OUT/*agent_info.csv

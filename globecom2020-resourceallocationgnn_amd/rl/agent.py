@@ -42,13 +42,14 @@ class Memory(object):
         if len(self.samples) > self.capacity:
             self.samples.pop(0)
 
-    def sample_indices(self, n):
+    def sample_indices(self, n, length=None):
         """n distinct positions when enough are stored, otherwise n draws with replacement -- the same global
-        numpy RNG calls as the reference (:261, :268)."""
-        if len(self.samples) >= n:
-            return np.random.choice(len(self.samples), n, replace=False)
+        numpy RNG calls as the reference (:261, :268).  length: draw for a memory of that many samples (default: now)."""
+        length = len(self.samples) if length is None else int(length)
+        if length >= n:
+            return np.random.choice(length, n, replace=False)
         # (one vectorised call consumes the legacy generator exactly like n scalar randint calls; checked in the tests)
-        return np.random.randint(0, len(self.samples), size=n)
+        return np.random.randint(0, length, size=n)
 
     def sample(self, n):
         return [self.samples[i] for i in self.sample_indices(n)]
@@ -283,7 +284,7 @@ class Agent(object):
         packed = self._packed_rollouts()
         for it in range(n_iter):
             if packed:
-                rewards[it * E:(it + 1) * E] = self._packed_iteration()
+                rewards[it * E:(it + 1) * E] = self._packed_iteration(last=it == n_iter - 1)
                 continue
             states, adj = self.env.observe(C)
             steps = self.num_Episodes * 0.8 * self.num_Train_Step * self.num_transition
@@ -317,9 +318,13 @@ class Agent(object):
                                         np.concatenate((nxt[e].reshape(1, -1), adj[e].reshape(1, -1)), axis=-1)])
         return rewards[:num_transitions] if n_iter * E == num_transitions else rewards
 
-    def _packed_iteration(self):
+    def _packed_iteration(self, last=False):
         """One iteration of _generate_batched on packed observations: same epsilon draws in the same order, same Q-values
-        (the same kernels on the same float32 rows and CSR), same stored transitions."""
+        (the same kernels on the same float32 rows and CSR), same stored transitions.
+        While the GPU is still busy with the previous fit (the predict below has to wait for it anyway) the host does what
+        does not depend on the actions: the observation half of the transitions goes to its replay slots, and -- inside
+        Agent.train, where the replay is known to follow this rollout -- the replay's minibatch is drawn and its slots
+        uploaded: the numpy stream sees epsilon draws, minibatch draw, shuffle draw in the reference's order either way."""
         env, rep = self.env, self.device_replay
         E, n, C = env.E, self.num_D2D, self.num_CH
         xe, mask, col, regular = env.observe_packed(C)
@@ -335,6 +340,11 @@ class Agent(object):
                 actions[e] = _random_channels(n, 1, C)
             else:
                 greedy.append(e)
+        rep.stage_early(xe, col, mask)
+        if last and getattr(self, '_predraw_ok', False):
+            mem_len = min(self.memory.capacity, len(self.memory.samples) + E)
+            idx = self._draw_replay_indices(mem_len)
+            self._predrawn = (idx, rep.prefetch_indices(idx, E))
         if greedy:
             if regular.all():
                 # ALL environments are scored, the exploring ones' rows are dropped: one batch shape for the whole run (one
@@ -447,6 +457,23 @@ class Agent(object):
         # the reference reads "original" Q statistics from p AFTER it was overwritten in place (:684-690, :743-746)
         return result, q_mean, q_max_mean, q_mean.copy(), q_max_mean.copy()
 
+    def _draw_replay_indices(self, mem_len=None):
+        """The replay's draws from the process-wide numpy stream, in the reference's order: the minibatch positions
+        (Memory.sample, BS_brain.py:261/:268), then Model.fit's shuffle of the sample order.
+        mem_len: the memory's length at the time of the replay when that is not now (the rollout draws ahead)."""
+        B, model = self.batch_size, self.brain.model
+        trainer = model.trainer
+        if self._shard_world() > 1:                                # own memory, own draws: B / G graphs of the minibatch
+            idx = self.memory.sample_indices(B // trainer.world, mem_len)
+            model.consume_fit_shuffle(len(idx))
+        else:
+            idx = self.memory.sample_indices(B, mem_len)
+            model.consume_fit_shuffle(B)       # same RNG stream as fit()
+            if trainer is not None and trainer.world > 1:
+                per = B // trainer.world
+                idx = idx[trainer.rank * per:(trainer.rank + 1) * per]
+        return idx
+
     def _replay_on_device(self, defer=False):
         """replay() with the minibatch gathered, scored, labelled and fitted in HBM.  Under data parallelism every
         rank draws the same indices and processes only its own contiguous share of them.
@@ -458,17 +485,13 @@ class Agent(object):
         trainer = model.trainer
         if trainer is not None and trainer.world > 1 and B % trainer.world:
             raise ValueError("batch %d not divisible by %d ranks" % (B, trainer.world))
-        if self._shard_world() > 1:                                # own memory, own draws: B / G graphs of the minibatch
-            idx = self.memory.sample_indices(B // trainer.world)
-            model.consume_fit_shuffle(len(idx))
-        else:
-            idx = self.memory.sample_indices(B)
-            model.consume_fit_shuffle(B)       # Model.fit's np.random.shuffle draw: same RNG stream as fit()
-            if trainer is not None and trainer.world > 1:
-                per = B // trainer.world
-                idx = idx[trainer.rank * per:(trainer.rank + 1) * per]
         rep = self.device_replay
-        sb, sb_next, action, reward = rep.sample(idx)
+        pre, self._predrawn = getattr(self, '_predrawn', None), None
+        if pre is not None:                                        # drawn by the rollout right after its epsilon draws
+            idx, pre = pre
+        else:
+            idx = self._draw_replay_indices()
+        sb, sb_next, action, reward = rep.sample(idx, pre=pre)
         if trainer is None and hasattr(model.engine, 'dqn_step'):
             # single GPU: the whole step in one call, the online graph layers run once (v2x_dqn_step)
             y = rep.target_buffer(len(idx), self.num_CH)
@@ -512,6 +535,7 @@ class Agent(object):
         try:
             return self._train_loop(num_episodes, num_train_steps, save_dir, save_interval, verbose)
         finally:
+            self._predraw_ok, self._predrawn = False, None
             if frozen:
                 gc.unfreeze()
 
@@ -531,6 +555,7 @@ class Agent(object):
         # (the reference reads them after every fit, BS_brain.py:835-845 -- two host synchronisations per train step here)
         defer = self.device_replay is not None and os.environ.get("V2X_RL_DEFER_STATS", "1") != "0"
         self._warm_rollout_predict()
+        self._predraw_ok = defer                   # every rollout of this loop is followed by its replay (see _packed_iteration)
         for ep in range(num_episodes):
             self.env.new_random_game(self.num_D2D)
             pending = []

@@ -42,6 +42,8 @@ class DeviceReplay(object):
         self._idx_ring = {}
         self._n_staged = 0
         self._regular = np.ones(0, bool)       # host-side: slot holds a graph with in-degree n-2 everywhere
+        self._early = None                     # stage_early(): (slot, xe, col, mask) already copied for the next packed block
+        self._db_cache = {}
 
     # ------------------------------------------------------------------ storage
     def _grow(self, need):
@@ -126,9 +128,37 @@ class DeviceReplay(object):
         if (xe.dtype != np.float32 or xe.shape != (K, n, 16) or xe_next.shape != xe.shape or xe_next.dtype != np.float32
                 or col.dtype != np.int32 or col.shape != (K, max(self.n_edges, 1)) or mask.dtype != np.int32):
             raise ValueError("add_many_packed: arrays are not in the packed layout")
+        early = self._early
+        if early is not None and not (not self._stage and early[1] is xe and early[2] is col and early[3] is mask):
+            self._early = None                 # something else was staged in between: the plain path (the rows are rewritten)
         self._stage.append((xe, xe_next, col, np.asarray(action, np.int32).reshape(K, n), np.asarray(reward, np.float64).reshape(K),
                             mask, np.asarray(regular, bool)))
         self._n_staged += K
+
+    def stage_early(self, xe, col, mask):
+        """The observation half of the block the NEXT add_many_packed will stage (same array objects), copied to its slots
+        now -- the caller has time to spare before it knows the actions (the GPU is still fitting); flush() then copies
+        only xe_next / action / reward.  Not taken (False) when anything is staged already or the ring is about to wrap."""
+        K = xe.shape[0]
+        if self.n_edges is None:
+            self.n_edges = self.n * (self.n - 2)
+        if (self._stage or self._early is not None or self.device.type != "cuda" or K > 4096
+                or self.size + K > self.capacity or self.head + K > self.capacity or self.head != self.size):
+            return False
+        self._grow(self.size + K)
+        pos = self.head
+        for t, a, name in ((self.xe, xe, "xe"), (self.col, col, "col"), (self.mask, mask, "mask")):
+            self._to_device(t[pos:pos + K], a, name)
+        self._early = (pos, xe, col, mask)
+        return True
+
+    def prefetch_indices(self, idx, K):
+        """Upload the slots of a minibatch drawn AHEAD: idx are positions in the FIFO order as it will be once K more
+        transitions are stored.  -> what sample(idx, pre=...) takes, or None when the ring wraps by then."""
+        if self.size + self._n_staged + K > self.capacity:
+            return None
+        slots = np.asarray(idx, np.int64).astype(np.int32)               # not wrapped: FIFO position = slot
+        return slots, self._upload_indices(slots)
 
     def __len__(self):
         return min(self.capacity, self.size + self._n_staged)
@@ -165,9 +195,13 @@ class DeviceReplay(object):
         regular = self._stage[0][6] if one else np.concatenate([s[6] for s in self._stage])
         dst = (self.xe, self.xe_next, self.col, self.action, self.reward, self.mask)
         pos, done = self.head, 0
+        skip = self._early is not None and one and self._early[0] == pos and self._early[1] is cols[0]
+        self._early = None
         while done < k:
             m = min(k - done, self._alloc - pos)
             for t, a, name in zip(dst, cols, ("xe", "xe_next", "col", "action", "reward", "mask")):
+                if skip and name in ("xe", "col", "mask"):
+                    continue                           # stage_early() copied them
                 if self.device.type == "cuda" and m <= 4096:
                     self._to_device(t[pos:pos + m], a[done:done + m], name)
                 else:
@@ -227,13 +261,17 @@ class DeviceReplay(object):
         start = self.head if self.size == self.capacity else 0
         return ((start + idx) % self.capacity).astype(np.int32)
 
-    def sample(self, idx):
-        """-> (batch of s, batch of s', action [k, n] int32, reward [k] float64), all in HBM."""
+    def sample(self, idx, pre=None):
+        """-> (batch of s, batch of s', action [k, n] int32, reward [k] float64), all in HBM.
+        pre: prefetch_indices(idx, ...) of the same idx (their slots are on the device already)."""
         self.flush()
         torch = self.torch
         k = len(idx)
-        slots = self.logical_to_slot(idx)
-        idx_dev = self._upload_indices(slots)
+        if pre is not None:
+            slots, idx_dev = pre
+        else:
+            slots = self.logical_to_slot(idx)
+            idx_dev = self._upload_indices(slots)
         xe = self._gather(self.xe, idx_dev, k, 'xe').view(k * self.n, 16)
         xe_next = self._gather(self.xe_next, idx_dev, k, 'xe_next').view(k * self.n, 16)
         action = self._gather(self.action, idx_dev, k, 'action')
@@ -241,6 +279,10 @@ class DeviceReplay(object):
         if self._regular[slots].all():                             # every sampled graph has in-degree n-2: CSR as stored
             col = self._gather(self.col, idx_dev, k, 'col').view(-1)
             rp, max_edges = self.row_ptr(k), self.n_edges
+            dbs = self._db_cache.get(k)                # the gather buffers are reused: so are the batch descriptors
+            if dbs is None or dbs[0].xe.data_ptr() != xe.data_ptr() or dbs[0].col_idx.data_ptr() != col.data_ptr():
+                dbs = self._db_cache[k] = tuple(DeviceBatch.from_tensors(k, self.n, t, rp, col, max_edges) for t in (xe, xe_next))
+            return dbs[0], dbs[1], action, reward
         else:                                                      # expand the source masks (ascending sources per row)
             masks = self._gather(self.mask, idx_dev, k, 'mask')                                  # [k, n(q)]
             bits = ((masks[:, :, None] >> torch.arange(self.n, device=self.device, dtype=torch.int32)) & 1).bool()

@@ -418,3 +418,40 @@ def test_device_replay_add_many_stages_what_add_stages():
         u, v = np.concatenate([s[i] for s in one._stage]), many._stage[0][i]
         assert u.dtype == np.asarray(v).dtype and np.array_equal(u, np.asarray(v)), i
     assert list(many._stage[0][6]) == [True, True, True, False, True, True, True]
+
+
+def test_pool_survives_a_fork():
+    """The library's pool threads do not exist in a forked child (pthread_atfork handler in csrc/v2xsim.c): a child that
+    inherits a simulator steps it on a pool of its own and gets the parent's trajectory."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available() or not hasattr(os, "fork"):
+        pytest.skip("libv2xsim.so not built / no fork")
+    E, n = 6, 8
+    env = BatchedEnviron(*_lanes(), 750, 1299, n_envs=E, seeds=[17 + 31 * e for e in range(E)], lookahead=True)
+    env.new_random_game(n)
+    act = np.zeros((E, n, 1), int)
+    env.act(act)                                               # pool threads exist, a look-ahead step is in flight
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                                               # child: drop the inherited job, three steps, report a digest
+        try:
+            env._ahead = None
+            env.lookahead = False
+            for _ in range(3):
+                env.act(act)
+            os.write(w, env.pos.tobytes() + env._mt_pos.tobytes())
+        finally:
+            os._exit(0)
+    os.close(w)
+    for _ in range(3):
+        env.act(act)
+    want = env.pos.tobytes() + env._mt_pos.tobytes()
+    got = b""
+    while len(got) < len(want):
+        chunk = os.read(r, len(want) - len(got))
+        if not chunk:
+            break
+        got += chunk
+    os.close(r)
+    _, status = os.waitpid(pid, 0)
+    assert status == 0 and got == want

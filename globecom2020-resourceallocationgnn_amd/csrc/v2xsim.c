@@ -12,6 +12,7 @@
 #include <stdatomic.h>
 #include <stdint.h>
 #include <string.h>
+#include "../../include/v2xsim.h"
 
 #define TWOPI 6.283185307179586476925286766559
 
@@ -527,23 +528,6 @@ void v2xsim_positions(int E, int n, uint32_t* keys, int32_t* pos, double* xy, in
   par_for(E, positions_one, &c);
 }
 
-typedef struct {
-  int32_t E, n, rb, n_lanes;
-  double timestep, width, height;
-  const double *up, *down, *left, *right;           /* lane tables [n_lanes] */
-  const double* vel;                                /* [E][n]   (constant within an episode) */
-  const int64_t* dest;                              /* [E][n]   (constant within an episode) */
-  double p_v2v, p_v2i, veh_gain, veh_nf, sig2;
-  /* state in (not written) */
-  const uint32_t* keys_in; const int32_t* mtpos_in; const double* xy_in; const int8_t* dirs_in;
-  const double* v2i_shadow_in; const double* v2v_shadow_in;
-  /* state out */
-  uint32_t* keys; int32_t* mtpos; double* xy; int8_t* dirs; double* v2i_shadow; double* v2v_shadow;
-  /* channels, interference, observation of the new state */
-  double *v2v_abs, *v2i_abs, *v2v_ff, *v2i_ff, *interf_db, *state, *adj;
-  float* xe; int32_t* mask; int32_t* col; uint8_t* regular;
-  double* scratch;                                  /* [E][2 n_u]: uniforms, Gaussians */
-} v2xsim_advance_args;
 
 static void advance_one(int e, void* q) {
   const v2xsim_advance_args* a = (const v2xsim_advance_args*)q;

@@ -1,0 +1,74 @@
+/* libv2xsim.so -- host-side helper of the CALLERS of the hot path (the batched simulator behind the DQN loop),
+ * not part of the drop-in boundary (that is include/v2xgnn.h).  Plain C, no GPU: the array arithmetic of E independent V2X
+ * simulators, one environment per task of the library's own thread pool (threads sleep between jobs).  Bound with ctypes in
+ * globecom2020-resourceallocationgnn_amd/rl/native_sim.py; the numpy expressions of rl/batched_env.py are the definition and
+ * the fallback, tests/test_rl_batched_env.py compares the two (integer state and random streams identical, reals to libm
+ * rounding).  All arrays are C-contiguous; E environments, n vehicles = links, rb resource blocks.
+ * MT19937 states are numpy RandomState layout: keys[E][624] uint32 + pos[E] int32, advanced in place.
+ * One caller thread at a time.                                                                                           */
+#ifndef V2XSIM_H
+#define V2XSIM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int v2xsim_abi(void);                       /* 2 */
+void v2xsim_set_threads(int n);             /* threads a loop may use, the caller included */
+int v2xsim_max_threads(void);
+
+/* renew_channel + renew_channels_fastfading (Environment.py:378-406, path loss :94-146) from the step's uniforms u[E][n_u]
+ * (random.gauss order: cos value, then the sin value of a pair); shadowing states are updated in place */
+void v2xsim_channels(int E, int n, int rb, const double* u, int n_u, const double* vel, const double* pos, double* v2i_shadow,
+                     double* v2v_shadow, double* v2v_abs, double* v2i_abs, double* v2v_ff, double* v2i_ff, double* scratch);
+/* compute_reward_with_channel_selection (Environment.py:408-458), every link active, one receiver per link */
+void v2xsim_reward(int E, int n, int rb, const int64_t* ch, const int64_t* dest, const double* v2v_ff, const double* v2i_ff,
+                   const double* v2i_abs, double p_v2v, double p_v2i, double veh_gain, double bs_gain, double bs_nf, double veh_nf,
+                   double sig2, double* v2v_rate, double* v2i_rate, double* interference, double* v2i_interf, double* v2v_interf);
+/* Compute_Interference (Environment.py:460-493), the observable part, in dB: out[E][n][rb] */
+void v2xsim_interference(int E, int n, int rb, const int64_t* dest, const double* v2v_ff, double p_v2i, double veh_gain,
+                         double veh_nf, double sig2, double* out);
+/* Agent.observe for all environments (BS_brain.py:389-407, :441-445, :458-467): state[E][n][3C+1], adj[E][n][n] */
+void v2xsim_observe(int E, int n, int C, const int64_t* dest, const double* v2v_ff, const double* v2i_ff, double power,
+                    double* state, double* adj);
+/* ... and the same observation in the engine's packed layout (include/v2xgnn.h): xe[E][n][16] float32, source masks
+ * mask[E][n], CSR sources col[E][n (n-2)] (zeros for a graph with a link that is its own receiver), regular[E] */
+void v2xsim_observe_packed(int E, int n, int C, const int64_t* dest, const double* v2v_ff, const double* v2i_ff, double power,
+                           double* state, double* adj, float* xe, int32_t* mask, int32_t* col, uint8_t* regular);
+/* the next n_u random.random() doubles of every stream */
+void v2xsim_mt_uniforms(int E, uint32_t* keys, int32_t* pos, double* out, int n_u);
+/* add_new_vehicles_by_number (Environment.py:217-234): the integer draws of an episode reset in the stdlib generator's order */
+void v2xsim_reset_vehicles(int E, int n, uint32_t* keys, int32_t* pos, int n_lanes, const double* down, const double* up,
+                           const double* left, const double* right, int width, int height, double* xy, int8_t* dirs, double* vel);
+/* renew_neighbor's draw (Environment.py:375): random.sample(candidates, 1)[0] per link, populations of 1..21 */
+void v2xsim_sample_dest(int E, int n, int m, uint32_t* keys, int32_t* pos, const int64_t* cand, int64_t* dest);
+/* renew_positions (Environment.py:236-345) in place; dirs: 0 up, 1 down, 2 left, 3 right */
+void v2xsim_positions(int E, int n, uint32_t* keys, int32_t* pos, double* xy, int8_t* dirs, const double* vel, double timestep,
+                      int n_lanes, const double* up, const double* down, const double* left, const double* right, double width,
+                      double height);
+
+/* One whole simulator step (what Agent.act runs after the rates, BS_brain.py:366-376: positions, channels, interference) plus the
+ * next observation, as a map state-in -> state-out that never writes its inputs.  v2xsim_advance runs it now;
+ * v2xsim_advance_start on the pool alone while the caller does something else (0 started, -1 a job is in flight, -2 no thread),
+ * v2xsim_advance_wait blocks until that job is done (0, or -1 when none was started).  rl/batched_env.py (`lookahead`). */
+typedef struct {
+  int32_t E, n, rb, n_lanes;
+  double timestep, width, height;
+  const double *up, *down, *left, *right;
+  const double* vel; const int64_t* dest;
+  double p_v2v, p_v2i, veh_gain, veh_nf, sig2;
+  const uint32_t* keys_in; const int32_t* mtpos_in; const double* xy_in; const int8_t* dirs_in;
+  const double* v2i_shadow_in; const double* v2v_shadow_in;
+  uint32_t* keys; int32_t* mtpos; double* xy; int8_t* dirs; double* v2i_shadow; double* v2v_shadow;
+  double *v2v_abs, *v2i_abs, *v2v_ff, *v2i_ff, *interf_db, *state, *adj;
+  float* xe; int32_t* mask; int32_t* col; uint8_t* regular;
+  double* scratch;                           /* [E][2 n_u], n_u = n + n^2 + 2 n rb + 2 n^2 rb (even) */
+} v2xsim_advance_args;
+void v2xsim_advance(const v2xsim_advance_args* a);
+int v2xsim_advance_start(const v2xsim_advance_args* a);
+int v2xsim_advance_wait(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -32,6 +32,23 @@ def test_library_exports_every_declared_symbol():
     assert b'gfx950' in vlib.load_library().v2x_version()
 
 
+def test_simulator_library_exports_every_declared_symbol():
+    """include/v2xsim.h (the batched simulator's helper library, callers' side) against libv2xsim.so and its ctypes binding"""
+    from v2xgnn.rl import native_sim
+    hdr = open(os.path.join(ROOT, 'include', 'v2xsim.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(v2xsim_[a-z_0-9]+)\s*\(', hdr))
+    assert len(declared) >= 15
+    path = os.path.join(os.path.dirname(vlib.library_path()), 'libv2xsim.so')
+    assert os.path.exists(path), "build first (__graft_entry__.build())"
+    lib = C.CDLL(path)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libv2xsim.so does not export %s" % name
+    assert lib.v2xsim_abi() == 2 and native_sim.available()
+    a = native_sim.AdvanceArgs()
+    assert [f[0] for f in a._fields_][:4] == ["E", "n", "rb", "n_lanes"] and C.sizeof(a) == 4 * 4 + 3 * 8 + 6 * 8 + 5 * 8 + 24 * 8
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():

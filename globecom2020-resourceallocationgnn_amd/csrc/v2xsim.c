@@ -41,7 +41,8 @@ static struct {
   uint32_t gen;
   _Atomic uint64_t ticket;                          /* (gen << 32) | next index */
   _Atomic int remaining;
-  int async_busy;                                   /* a par_start job is in flight */
+  int async_busy;                                   /* a par_start job is in flight (or done and not yet waited for) */
+  int async_id;                                     /* its ticket */
 } P = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
 static int g_threads = 1;            /* threads a loop may use, the caller included (v2xsim_set_threads) */
 
@@ -101,7 +102,7 @@ static void post(env_fn fn, void* ctx, int n, int workers) {
 static void par_for(int n, env_fn fn, void* ctx) {
   if (n <= 0) return;
   pthread_mutex_lock(&P.mu);
-  if (P.async_busy || g_threads <= 1 || n == 1) {   /* the pool is working ahead (or not wanted): the caller alone */
+  if ((P.async_busy && atomic_load(&P.remaining) > 0) || g_threads <= 1 || n == 1) {   /* the pool is working ahead (or not wanted): the caller alone */
     pthread_mutex_unlock(&P.mu);
     for (int e = 0; e < n; ++e) fn(e, ctx);
     return;
@@ -117,19 +118,24 @@ static void par_for(int n, env_fn fn, void* ctx) {
     pthread_mutex_unlock(&P.mu);
   }
 }
-/* 0: started; -1: another job is in flight */
+/* > 0: started, the job's ticket; -1: another job is still RUNNING (one that is done but was never waited for -- its owner
+ * forgot it or died -- is simply replaced: its results are complete); -2: no pool thread */
 static int par_start(int n, env_fn fn, void* ctx) {
   pthread_mutex_lock(&P.mu);
-  if (P.async_busy) { pthread_mutex_unlock(&P.mu); return -1; }
+  if (P.async_busy && atomic_load(&P.remaining) > 0) { pthread_mutex_unlock(&P.mu); return -1; }
   post(fn, ctx, n, g_threads < n ? g_threads : n);
-  if (P.n_workers == 0) { pthread_mutex_unlock(&P.mu); return -2; }
+  if (P.n_workers == 0) { P.async_busy = 0; pthread_mutex_unlock(&P.mu); return -2; }
   P.async_busy = 1;
+  P.async_id = (int)(P.gen & 0x3fffffffu) + 1;
+  const int id = P.async_id;
   pthread_mutex_unlock(&P.mu);
-  return 0;
+  return id;
 }
-static int par_wait(void) {
+/* returns when job `id` is done (at once when it is not the job in flight: a later job can only have started after it);
+ * id 0: whatever is in flight */
+static int par_wait(int id) {
   pthread_mutex_lock(&P.mu);
-  if (!P.async_busy) { pthread_mutex_unlock(&P.mu); return -1; }
+  if (!P.async_busy || (id != 0 && P.async_id != id)) { pthread_mutex_unlock(&P.mu); return 0; }
   while (atomic_load(&P.remaining) > 0) pthread_cond_wait(&P.cv_done, &P.mu);
   P.async_busy = 0;
   pthread_mutex_unlock(&P.mu);
@@ -565,14 +571,12 @@ void v2xsim_advance(const v2xsim_advance_args* a) {
 
 /* the same step on the pool alone while the caller does something else: one job in flight per process */
 static v2xsim_advance_args g_job;
-/* 0: started; -1: a job is already in flight (wait for it first); -2: no pool thread could be started */
 int v2xsim_advance_start(const v2xsim_advance_args* a) {
   pthread_mutex_lock(&P.mu);
-  const int busy = P.async_busy;
+  const int running = P.async_busy && atomic_load(&P.remaining) > 0;
   pthread_mutex_unlock(&P.mu);
-  if (busy) return -1;
+  if (running) return -1;
   g_job = *a;
   return par_start(g_job.E, advance_one, &g_job);
 }
-/* blocks until the started job is done; 0, or -1 when none was started */
-int v2xsim_advance_wait(void) { return par_wait(); }
+int v2xsim_advance_wait(int id) { return par_wait(id); }

@@ -356,10 +356,13 @@ class Agent(object):
                 states, adj = env.observe(C)
                 q = self._predict(states[greedy], adj[greedy])
                 actions[greedy] = np.transpose(np.argmax(q, axis=2))[:, :, None]
-        v2v, v2i, _ = env.act(actions)
+        # inside Agent.train the simulator step itself waits until the replay is enqueued (the next observe applies it): only the
+        # rates and the next observation -- both ready -- are needed to store the transitions
+        defer_step = getattr(self, '_predraw_ok', False) and hasattr(env, 'act_deferred')
+        v2v, v2i, _ = env.act_deferred(actions) if defer_step else env.act(actions)
         self.num_step += E
         reward = self.v2v_weight * v2v.sum(axis=(1, 2)) + self.v2i_weight * v2i.sum(axis=1)
-        xe_next = env.observe_packed(C)[0]
+        xe_next = env.next_packed_observation(C) if defer_step else env.observe_packed(C)[0]
         rep.add_many_packed(xe, xe_next, col, mask, regular, actions.reshape(E, n), reward)
         samples = self.memory.samples                  # the host list only keeps the FIFO bookkeeping (train_observe(None) x E)
         samples.extend([None] * E)
@@ -414,7 +417,7 @@ class Agent(object):
         db.col_idx.copy_(io["col_pin"], non_blocking=True)
         engine.forward(db, out=io["q_dev"])
         io["q_pin"].copy_(io["q_dev"], non_blocking=True)
-        torch.cuda.current_stream(rep.device).synchronize()
+        torch.cuda.current_stream(rep.device).synchronize()      # (polling an event instead: no difference, measured)
         return io["q_np"]
 
     # ------------------------------------------------------------------ learning
@@ -536,6 +539,8 @@ class Agent(object):
             return self._train_loop(num_episodes, num_train_steps, save_dir, save_interval, verbose)
         finally:
             self._predraw_ok, self._predrawn = False, None
+            if hasattr(self.env, 'finish_step'):
+                self.env.finish_step()
             if frozen:
                 gc.unfreeze()
 

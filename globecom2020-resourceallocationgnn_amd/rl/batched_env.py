@@ -96,6 +96,7 @@ class BatchedEnviron(object):
         self._ahead = None                 # a started v2xsim_advance job: its output arrays (inputs stay untouched until taken)
         self._obs = None                   # observation of the CURRENT channels: (v2v, v2i, state, adj, xe, mask, col, regular)
         self._scratch = None
+        self._step_pending = False         # act_deferred(): the rates are out, the simulator step is applied at the next call
         self.streams = None if self._shared else [MTStream(int(s)) for s in seeds]
         if not self._shared and len(self.streams) != self.E:
             raise ValueError("need %d seeds" % self.E)
@@ -344,6 +345,7 @@ class BatchedEnviron(object):
     def compute_reward_with_channel_selection(self, actions):
         """actions [E, N] or [E, N, 1] -> V2V rates [E, N, 1], V2I rates [E, min(rb, N)], interference at the base
         station [E, rb] (Environment.py:408-458, every link active, one receiver per link)."""
+        self.finish_step()
         E, n, rb = self.E, self.n_Veh, self.n_RB
         ch = np.asarray(actions).reshape(E, n).astype(np.int64)
         if self.native:
@@ -379,6 +381,7 @@ class BatchedEnviron(object):
 
     def Compute_Interference(self, actions):
         """Environment.py:460-493 (observable part: noise + the co-channel V2I transmitter), [E, N, 1, rb] in dB."""
+        self.finish_step()
         E, n, rb = self.E, self.n_Veh, self.n_RB
         if self.native and rb <= n:
             self.V2V_Interference_all = native_sim.interference_db(self.dest, self.V2V_channels_with_fastfading, self.V2I_power_dB,
@@ -396,10 +399,8 @@ class BatchedEnviron(object):
         Only the rates depend on the actions (they are computed on the channels BEFORE the step); mobility, channels, the
         observable interference and the next observation are one library call for all environments (v2xsim_advance), taken
         from the look-ahead worker when it was started after the previous step."""
-        if self._ahead is not None and not self._ahead.get("done"):
-            native_sim.advance_wait()                          # (the pool is the library's only one: free it for the rates)
-            self._ahead["done"] = True
-        rates = self.compute_reward_with_channel_selection(actions)
+        self.finish_step()
+        rates = self._rates(actions)
         if self._one_call_step():
             self._advance()
             return rates
@@ -407,6 +408,38 @@ class BatchedEnviron(object):
         self.renew_channels_fastfading()
         self.Compute_Interference(actions)
         return rates
+
+    def act_deferred(self, actions):
+        """act() that returns as soon as the rates are known; the simulator step itself (taking over the look-ahead result,
+        starting the next one) is applied at the next call of any method of this object, or by finish_step() -- between the two
+        the public arrays still show the state BEFORE the step.  For callers with better things to do first (the agent
+        enqueues its replay); trajectories are those of act()."""
+        self.finish_step()
+        if not self._one_call_step():
+            return self.act(actions)
+        rates = self._rates(actions)
+        self._step_pending = True
+        return rates
+
+    def finish_step(self, start_next=True):
+        """apply the step act_deferred() left pending (start_next: look ahead again right away)"""
+        if self._step_pending:
+            self._step_pending = False
+            self._advance(start_next)
+
+    def next_packed_observation(self, n_channels=4):
+        """observe_packed()[0] of the state AFTER the pending step, without applying it when the look-ahead has it ready"""
+        job = self._ahead
+        if self._step_pending and job is not None and job.get("done") and n_channels == self.n_RB:
+            return job["out"]["xe"]
+        self.finish_step()
+        return self.observe_packed(n_channels)[0]
+
+    def _rates(self, actions):
+        if self._ahead is not None and not self._ahead.get("done"):
+            native_sim.advance_wait(self._ahead["ticket"])     # (the pool is the library's only one: free it for the rates)
+            self._ahead["done"] = True
+        return self.compute_reward_with_channel_selection(actions)
 
     # ------------------------------------------------------------------ the step as one library call (+ look-ahead)
     def _one_call_step(self):
@@ -443,7 +476,8 @@ class BatchedEnviron(object):
             setattr(a, k, v.ctypes.data)
         job = {"out": out, "ins": ins, "args": a}            # (the arrays the library reads and writes stay alive with the job)
         if ahead:
-            return job if native_sim.advance_start(a) else None
+            job["ticket"] = native_sim.advance_start(a)
+            return job if job["ticket"] else None
         native_sim.advance(a)
         return job
 
@@ -455,16 +489,18 @@ class BatchedEnviron(object):
 
     def _drop_lookahead(self):
         """A started look-ahead step is abandoned (its inputs were never written): wait for the worker and forget the result."""
+        if self._step_pending:                                 # ... but a pending step is applied first: its draws come before
+            self.finish_step(start_next=False)                 # whatever the caller is about to do with the streams
         if self._ahead is not None:
             if not self._ahead.get("done"):
-                native_sim.advance_wait()
+                native_sim.advance_wait(self._ahead["ticket"])
             self._ahead = None
 
-    def _advance(self):
+    def _advance(self, start_next=True):
         job = self._ahead
         if job is not None:
             if not job.get("done"):
-                native_sim.advance_wait()
+                native_sim.advance_wait(job["ticket"])
             self._ahead = None
         else:
             job = self._start_job(False)
@@ -478,7 +514,7 @@ class BatchedEnviron(object):
         self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading = o["v2v_ff"], o["v2i_ff"]
         self.V2V_Interference_all = o["interf_db"]
         self._obs = (o["v2v_ff"], o["v2i_ff"], o["state"], o["adj"], o["xe"], o["mask"], o["col"], o["regular"].astype(bool))
-        if self.lookahead:
+        if self.lookahead and start_next:
             self._ahead = self._start_job(True)
 
     def _observation(self, n_channels):
@@ -494,6 +530,7 @@ class BatchedEnviron(object):
         cast like Keras casts the feed, source masks [E, N] int32, CSR sources by destination [E, N (N-2)] int32 (zeros
         for a graph where some link is its own receiver) and the regular flags [E].  Same arrays every call until the
         simulator moves: read-only for the caller.  Needs the native library (packed_ok())."""
+        self.finish_step()
         ob = self._observation(n_channels)
         if ob is None:
             if not self.packed_ok(n_channels):
@@ -512,6 +549,7 @@ class BatchedEnviron(object):
         """Agent.observe for all environments -> D2D_State [E, N, 2C+1+C] = [V2V gain | V2I gain | power | edge gain]
         (BS_brain.py:389-407, :458-467) and the adjacency [E, N, N] (Adj[p, q] = 0 for p == q and for the receiver p of
         link q, :441-445)."""
+        self.finish_step()
         E, n, C = self.E, self.n_Veh, n_channels
         ob = self._observation(C)
         if ob is not None:                                     # computed with the step (same arrays until the simulator moves)

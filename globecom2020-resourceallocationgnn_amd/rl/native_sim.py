@@ -44,7 +44,7 @@ def _load():
     lib.v2xsim_advance.argtypes = [C.POINTER(AdvanceArgs)]
     lib.v2xsim_advance_start.argtypes = [C.POINTER(AdvanceArgs)]
     lib.v2xsim_advance_start.restype = C.c_int
-    lib.v2xsim_advance_wait.argtypes = []
+    lib.v2xsim_advance_wait.argtypes = [C.c_int]
     lib.v2xsim_advance_wait.restype = C.c_int
     for f in (lib.v2xsim_observe_packed, lib.v2xsim_positions, lib.v2xsim_advance):
         f.restype = None
@@ -53,7 +53,7 @@ def _load():
         f.restype = None
     _lib = lib
     import atexit
-    atexit.register(lib.v2xsim_advance_wait)                   # a look-ahead job still running must not outlive its arrays
+    atexit.register(lib.v2xsim_advance_wait, 0)                   # a look-ahead job still running must not outlive its arrays
     return lib
 
 
@@ -210,9 +210,10 @@ def advance(args):
 
 
 def advance_start(args):
-    """-> True when the worker thread took the job (False: it is busy with another simulator's)"""
-    return _load().v2xsim_advance_start(C.byref(args)) == 0
+    """-> the job's ticket (> 0) when the pool took the job, 0 when it is still busy with another simulator's"""
+    return max(0, _load().v2xsim_advance_start(C.byref(args)))
 
 
-def advance_wait():
-    return _load().v2xsim_advance_wait() == 0
+def advance_wait(ticket=0):
+    """returns when job `ticket` is done (0: whatever is in flight)"""
+    return _load().v2xsim_advance_wait(int(ticket)) == 0

@@ -49,8 +49,9 @@ void v2xsim_positions(int E, int n, uint32_t* keys, int32_t* pos, double* xy, in
 
 /* One whole simulator step (what Agent.act runs after the rates, BS_brain.py:366-376: positions, channels, interference) plus the
  * next observation, as a map state-in -> state-out that never writes its inputs.  v2xsim_advance runs it now;
- * v2xsim_advance_start on the pool alone while the caller does something else (0 started, -1 a job is in flight, -2 no thread),
- * v2xsim_advance_wait blocks until that job is done (0, or -1 when none was started).  rl/batched_env.py (`lookahead`). */
+ * v2xsim_advance_start on the pool alone while the caller does something else (> 0: the job's ticket; -1: another job is still
+ * running -- one that is done and was never waited for is replaced; -2: no thread), v2xsim_advance_wait(ticket) returns when
+ * that job is done (ticket 0: whatever is in flight).  One job in flight per process.  rl/batched_env.py (`lookahead`). */
 typedef struct {
   int32_t E, n, rb, n_lanes;
   double timestep, width, height;
@@ -66,7 +67,7 @@ typedef struct {
 } v2xsim_advance_args;
 void v2xsim_advance(const v2xsim_advance_args* a);
 int v2xsim_advance_start(const v2xsim_advance_args* a);
-int v2xsim_advance_wait(void);
+int v2xsim_advance_wait(int ticket);
 
 #ifdef __cplusplus
 }

@@ -420,6 +420,42 @@ def test_device_replay_add_many_stages_what_add_stages():
     assert list(many._stage[0][6]) == [True, True, True, False, True, True, True]
 
 
+def test_deferred_step_is_the_step():
+    """act_deferred() hands out the rates and leaves the simulator step pending: the next packed observation is readable from
+    the look-ahead result, the public arrays still show the old state, and whatever touches the simulator next (an observe, a
+    reset, a draw from a stream) finds the step applied first -- trajectories are those of act()."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    E, n = 5, 20
+    envs = []
+    for ahead in (False, True):
+        env = BatchedEnviron(*_lanes(), 750, 1299, n_envs=E, seeds=[29 + 7 * e for e in range(E)], lookahead=ahead)
+        env.new_random_game(n)
+        envs.append(env)
+    a, b = envs
+    rng = np.random.default_rng(4)
+    for it in range(40):
+        act = rng.integers(0, 4, size=(E, n, 1))
+        pos_before, had_job = b.pos.copy(), b._ahead is not None
+        ra, rb = a.act(act), b.act_deferred(act)
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y)
+        assert b._step_pending and np.array_equal(b.pos, pos_before)
+        assert np.array_equal(b.next_packed_observation(4), a.observe_packed(4)[0])
+        assert b._step_pending == had_job and (had_job or it == 0 or it % 7 in (4, 6))   # (no look-ahead result to read from after a reset / a draw)
+        if it % 7 == 3:
+            a.new_random_game(n); b.new_random_game(n)         # applies the pending step, then resets; no look-ahead wasted
+            assert not b._step_pending and b._ahead is None
+        elif it % 7 == 5:
+            assert a.streams[1].random() == b.streams[1].random() and not b._step_pending
+        for x, y in zip(a.observe(4) + a.observe_packed(4), b.observe(4) + b.observe_packed(4)):
+            assert np.array_equal(x, y)
+        assert not b._step_pending
+        for k in ("pos", "dirs", "_v2v_shadow", "V2V_channels_with_fastfading", "V2V_Interference_all", "_mt_keys", "_mt_pos"):
+            assert np.array_equal(getattr(a, k), getattr(b, k)), (it, k)
+
+
 def test_pool_survives_a_fork():
     """The library's pool threads do not exist in a forked child (pthread_atfork handler in csrc/v2xsim.c): a child that
     inherits a simulator steps it on a pool of its own and gets the parent's trajectory."""

@@ -27,6 +27,14 @@ for nm in ("mt_uniforms", "channels", "observe", "reward", "interference_db", "a
     wrap(native_sim, nm, "native." + nm)
 for nm in ("observe", "act", "new_random_game", "renew_positions", "renew_channels_fastfading", "renew_channel", "renew_neighbor", "_advance_channels", "act_for_training"):
     if hasattr(env, nm): wrap(env, nm, "env." + nm)
+for nm in ("act_deferred", "next_packed_observation", "finish_step", "observe_packed"):
+    wrap(env, nm, "env." + nm)
+wrap(agent, "_draw_replay_indices"); wrap(agent.device_replay, "stage_early"); wrap(agent.device_replay, "prefetch_indices")
+wrap(agent.device_replay, "_upload_indices"); wrap(agent.device_replay, "_gather")
+_sync = torch.cuda.Stream.synchronize
+def _sync_timed(self):
+    t0 = time.perf_counter(); r = _sync(self); rec.setdefault("stream.synchronize", []).append(time.perf_counter() - t0); return r
+torch.cuda.Stream.synchronize = _sync_timed
 wrap(env, "_advance", "env._advance"); wrap(env, "_start_job", "env._start_job")
 wrap(agent, "_packed_iteration"); wrap(agent, "_predict_packed"); wrap(agent.device_replay, "add_many_packed"); wrap(agent.device_replay, "flush")
 wrap(agent.brain, "update_target_model"); wrap(agent.brain.model, "consume_fit_shuffle")

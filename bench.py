@@ -192,6 +192,20 @@ def step_bytes_per_graph(N, F, L, E, C=4, Dn=9, De=4):
     return 3 * fwd
 
 
+def usable_cpus():
+    """CPUs this process can keep busy: its affinity mask cut to the cgroup's CPU quota (the MI355X boxes show 256 hardware threads and
+    grant 16 CPUs' worth of time per 100 ms, `cpu.max` = "1600000 100000": 64 worker processes there are 16 CPUs shared by 64)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -279,8 +293,10 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
                                              "what": what if b == (B if name == "C2" else b) else what + " (timed on a %d-graph sample)" % b}
     # C2 on all cores for real: the BLAS thread pool cannot use them (the per-slot products are too small: the
     # "all_cores" figure above is SLOWER than one thread on a 128-thread host), worker processes over graph shards can
-    host_cores = len(os.sched_getaffinity(0))
-    workers = max(1, min(host_cores, B // 64))
+    host_cores, usable = len(os.sched_getaffinity(0)), usable_cpus()
+    # (sized by the hardware threads, not by the quota: measured on a box with 256 threads and a 16-CPU quota, 16 workers 105 k
+    #  graphs/s, 32 workers 170 k, 64 workers 159-194 k -- the JSON carries both figures)
+    workers = int(os.environ.get("V2X_BENCH_CPU_WORKERS", "0")) or max(1, min(host_cores, B // 64))
     try:
         so = sharded_leg(B, workers)
         try:
@@ -298,7 +314,7 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
     # the headline CPU number is the best C2 figure; `cores` = the threads / processes of that run
     main_leg = max(legs["C2_sharded_processes"], legs["C2_all_cores"], legs["C2_one_thread"], key=lambda l: l["graphs_per_s"])
     return {"value": main_leg["graphs_per_s"], "unit": "graph-instances/s", "cores": int(main_leg["threads"]), "kind": "port",
-            "cpu_model": cpu_model(), "host_cores": host_cores,
+            "cpu_model": cpu_model(), "host_cores": host_cores, "usable_cpus": usable,
             "sample": "median of %d fit steps of B=%d (N=%d,F=%d,L=%d,%s weights) after 1 warm-up, numpy fp32 CSR oracle "
                       "(leg C2, %d core(s)); a CPU restatement of the reference math, not Keras/TF1"
                       % (main_leg["steps"], main_leg["batch"], N, F, L, "shared" if share else "per-node", main_leg["threads"]),
@@ -855,7 +871,7 @@ def cpu_leg_share(wl, budget_s=8.0):
         finally:
             so.close()
         return {"value": round(bs / sec, 1), "unit": "graph-instances/s", "cores": int(workers), "kind": "port", "cpu_model": cpu_model(),
-                "ms_per_step": round(1e3 * sec, 2), "steps": steps,
+                "usable_cpus": usable_cpus(), "ms_per_step": round(1e3 * sec, 2), "steps": steps,
                 "sample": "median of %d fit steps of a %d-graph sample of the 1024-graph share (N=100, F=256, L=3, per-node weights): "
                           "%d worker processes x 1 BLAS thread over graph shards, gradients summed, one Adam update; numpy fp32 CSR "
                           "oracle, not Keras/TF1" % (steps, bs, workers)}

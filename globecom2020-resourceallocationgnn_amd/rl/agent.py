@@ -504,9 +504,18 @@ class Agent(object):
             q_next = target.engine.forward(sb_next)                   # target  (adjacency reused, :583)
             y = rep.dqn_targets(q, q_next, action, reward, self.gamma)
             loss = trainer.train_step(sb, y, n_graphs_global=B) if trainer is not None else model.engine.train_step(sb, y)
-        yv = y.view(len(idx), n, -1).double()
-        stats = rep.torch.stack([yv.sum(dim=(0, 2)) / self.num_Actions, yv.max(dim=2).values.sum(dim=0)])
-        if trainer is not None and trainer.world > 1:
+        # Q statistics of the fitted targets (BS_brain.py:743-746), summed in float64 on the device: sum of all entries and sum of
+        # the per-sample maxima, per link.  Deferred on one GPU: the two divisions (by the number of actions, by the batch) are
+        # the same IEEE operations on the host at the end of the episode -- three launches per step instead of seven.
+        torch = rep.torch
+        y3 = y.view(len(idx), n, -1)
+        s_all = y3.sum(dim=(0, 2), dtype=torch.float64)
+        s_max = y3.amax(dim=2).sum(dim=0, dtype=torch.float64)
+        multi = trainer is not None and trainer.world > 1
+        if defer and hasattr(loss, 'cpu') and not multi:
+            return loss, (s_all, s_max)
+        stats = torch.stack([s_all / self.num_Actions, s_max])
+        if multi:
             trainer.dist.all_reduce(stats, group=trainer.group)
         if defer and hasattr(loss, 'cpu'):
             return loss, stats / B
@@ -586,9 +595,15 @@ class Agent(object):
             if pending:
                 torch = self.device_replay.torch
                 lo = torch.stack([p[0].double() for p in pending]).cpu().numpy()            # [steps, n]
-                st = torch.stack([p[1] for p in pending]).cpu().numpy()                     # [steps, 2, n]
                 loss[:, ep, :len(pending)] = lo.T
-                q_mean[:, ep, :len(pending)], q_max[:, ep, :len(pending)] = st[:, 0].T, st[:, 1].T
+                if isinstance(pending[0][1], tuple):                                        # raw sums: divide here (see _replay_on_device)
+                    s_all = torch.stack([p[1][0] for p in pending]).cpu().numpy()           # [steps, n]
+                    s_max = torch.stack([p[1][1] for p in pending]).cpu().numpy()
+                    q_mean[:, ep, :len(pending)] = (s_all / self.num_Actions / self.batch_size).T
+                    q_max[:, ep, :len(pending)] = (s_max / self.batch_size).T
+                else:
+                    st = torch.stack([p[1] for p in pending]).cpu().numpy()                 # [steps, 2, n]
+                    q_mean[:, ep, :len(pending)], q_max[:, ep, :len(pending)] = st[:, 0].T, st[:, 1].T
             reward_episode[ep] = np.sum(reward_step[ep])
             if verbose:
                 print(datetime.datetime.now().strftime('%H:%M:%S'), 'episode', ep + 1, 'reward %.3f' % reward_episode[ep],

@@ -96,6 +96,7 @@ class BatchedEnviron(object):
         self._ahead = None                 # a started v2xsim_advance job: its output arrays (inputs stay untouched until taken)
         self._obs = None                   # observation of the CURRENT channels: (v2v, v2i, state, adj, xe, mask, col, regular)
         self._scratch = None
+        self._job_static = None
         self._step_pending = False         # act_deferred(): the rates are out, the simulator step is applied at the next call
         self.streams = None if self._shared else [MTStream(int(s)) for s in seeds]
         if not self._shared and len(self.streams) != self.E:
@@ -463,16 +464,24 @@ class BatchedEnviron(object):
                "v2i_ff": np.empty((E, n, rb)), "interf_db": np.empty((E, n, 1, rb)), "state": np.empty((E, n, 3 * rb + 1)),
                "adj": np.empty((E, n, n)), "xe": np.empty((E, n, 16), np.float32), "mask": np.empty((E, n), np.int32),
                "col": np.empty((E, n * (n - 2)), np.int32), "regular": np.empty(E, np.uint8), "scratch": self._scratch}
-        tabs = [c(np.asarray(t, f64)) for t in (p.up_lanes, p.down_lanes, p.left_lanes, p.right_lanes)]
-        ins = {"up": tabs[0], "down": tabs[1], "left": tabs[2], "right": tabs[3], "vel": c(self.vel, f64), "dest": c(self.dest, np.int64),
+        st = self._job_static
+        if st is None or st[0] != (E, n, rb):                  # the constant half of the argument block, once per episode shape
+            tabs = [c(np.asarray(t, f64)) for t in (p.up_lanes, p.down_lanes, p.left_lanes, p.right_lanes)]
+            t = native_sim.AdvanceArgs()
+            t.E, t.n, t.rb, t.n_lanes = E, n, rb, len(tabs[0])
+            t.timestep, t.width, t.height = p.timestep, p.width, p.height
+            t.p_v2v, t.p_v2i = self.V2V_power_dB_List[self.fixed_v2v_power_index], self.V2I_power_dB
+            t.veh_gain, t.veh_nf, t.sig2 = self.vehAntGain, self.vehNoiseFigure, self.sig2
+            t.up, t.down, t.left, t.right = (x.ctypes.data for x in tabs)
+            st = self._job_static = ((E, n, rb), t, tabs)
+        ins = {"tabs": st[2], "vel": c(self.vel, f64), "dest": c(self.dest, np.int64),
                "keys_in": self._mt_keys, "mtpos_in": self._mt_pos, "xy_in": c(self.pos, f64), "dirs_in": c(self.dirs, np.int8),
                "v2i_shadow_in": c(self._v2i_shadow, f64), "v2v_shadow_in": c(self._v2v_shadow, f64)}
-        a = native_sim.AdvanceArgs()
-        a.E, a.n, a.rb, a.n_lanes = E, n, rb, len(tabs[0])
-        a.timestep, a.width, a.height = p.timestep, p.width, p.height
-        a.p_v2v, a.p_v2i = self.V2V_power_dB_List[self.fixed_v2v_power_index], self.V2I_power_dB
-        a.veh_gain, a.veh_nf, a.sig2 = self.vehAntGain, self.vehNoiseFigure, self.sig2
-        for k, v in list(ins.items()) + list(out.items()):
+        a = native_sim.AdvanceArgs.from_buffer_copy(st[1])
+        for k, v in ins.items():
+            if k != "tabs":
+                setattr(a, k, v.ctypes.data)
+        for k, v in out.items():
             setattr(a, k, v.ctypes.data)
         job = {"out": out, "ins": ins, "args": a}            # (the arrays the library reads and writes stay alive with the job)
         if ahead:

@@ -35,6 +35,14 @@ _sync = torch.cuda.Stream.synchronize
 def _sync_timed(self):
     t0 = time.perf_counter(); r = _sync(self); rec.setdefault("stream.synchronize", []).append(time.perf_counter() - t0); return r
 torch.cuda.Stream.synchronize = _sync_timed
+_copy = torch.Tensor.copy_
+def _copy_timed(self, *a, **k):
+    t0 = time.perf_counter(); r = _copy(self, *a, **k); rec.setdefault("tensor.copy_", []).append(time.perf_counter() - t0); return r
+torch.Tensor.copy_ = _copy_timed
+_copyto = np.copyto
+def _copyto_timed(*a, **k):
+    t0 = time.perf_counter(); r = _copyto(*a, **k); rec.setdefault("np.copyto", []).append(time.perf_counter() - t0); return r
+np.copyto = _copyto_timed
 wrap(env, "_advance", "env._advance"); wrap(env, "_start_job", "env._start_job")
 wrap(agent, "_packed_iteration"); wrap(agent, "_predict_packed"); wrap(agent.device_replay, "add_many_packed"); wrap(agent.device_replay, "flush")
 wrap(agent.brain, "update_target_model"); wrap(agent.brain.model, "consume_fit_shuffle")

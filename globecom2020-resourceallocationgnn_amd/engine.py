@@ -177,6 +177,19 @@ class GnnEngine(object):
         self._check(self._lib.v2x_forward(self._h, C.byref(s), q.ctypes.data, 0, self._stream()))
         return q
 
+    def forward_to_host(self, batch, q):
+        """forward() of a device-addressable batch with the Q-values copied into the host array q [R, C] float32 and the stream
+        synchronised inside the call (the library's own device-to-host copy: one call instead of forward + copy + synchronise).
+        The batch's arrays may live in pinned host memory (device-mapped under unified addressing): the kernels then read the
+        few kilobytes of a rollout batch straight over the bus and no copy launch is involved at all."""
+        if not isinstance(batch, DeviceBatch):
+            raise ValueError("forward_to_host takes a DeviceBatch")
+        if q.dtype != np.float32 or not q.flags.c_contiguous or q.size != batch.n_rows * self.spec.n_channels:
+            raise ValueError("q must be a C-contiguous float32 array of %d x %d" % (batch.n_rows, self.spec.n_channels))
+        s = _batch_struct(batch)
+        self._check(self._lib.v2x_forward(self._h, C.byref(s), q.ctypes.data, 0, self._stream()))
+        return q
+
     def _step(self, fn, batch, y, n_global, want_loss):
         s = _batch_struct(batch)
         n_global = int(n_global or 0)

@@ -165,7 +165,8 @@ class DeviceReplay(object):
 
     def _to_device(self, dst, src, name):
         """dst (a slice of a storage tensor) <- src (host array) through a pinned staging buffer: the copy is asynchronous, the
-        buffer is one of four per (tensor, shape) and its event guards the reuse."""
+        buffer is one of four per (tensor, shape) and its event guards the reuse.  (Measured and dropped: v2x_gather_rows reading the
+        pinned buffer directly as the copy engine -- no faster on the host, slower on the device.)"""
         torch = self.torch
         key = ("stage", name, tuple(src.shape))
         ring = self._idx_ring.get(key)
@@ -231,23 +232,28 @@ class DeviceReplay(object):
         return out
 
     def _upload_indices(self, slots):
-        """The storage slots of a minibatch -> HBM without a blocking copy: through one of four pinned staging buffers
-        (a pinned source makes the copy asynchronous; its event guards the buffer's reuse) into a device buffer whose address
-        does not change."""
+        """The storage slots of a minibatch where the gather kernels can read them: one of four PINNED host buffers, which the
+        device addresses directly (unified addressing) -- 16 KB read over the bus by the kernels themselves instead of a copy
+        launch of ours.  The buffer's event (recorded by sample() behind its last gather) guards the reuse."""
         torch, k = self.torch, len(slots)
         ring = self._idx_ring.setdefault(k, {"pin": [torch.empty(k, dtype=torch.int32).pin_memory() for _ in range(4)],
-                                             "ev": [None] * 4, "dev": torch.empty(k, dtype=torch.int32, device=self.device),
-                                             "next": 0})
+                                             "ev": [None] * 4, "next": 0})
         i = ring["next"]
         ring["next"] = (i + 1) % 4
         if ring["ev"][i] is not None:
             ring["ev"][i].synchronize()
+            ring["ev"][i] = None
         ring["pin"][i].numpy()[:] = slots
-        ring["dev"].copy_(ring["pin"][i], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        ring["ev"][i] = ev
-        return ring["dev"]
+        self._idx_in_use = (ring, i)
+        return ring["pin"][i]
+
+    def _indices_consumed(self):
+        """call behind the last kernel that reads the buffer _upload_indices handed out"""
+        use, self._idx_in_use = getattr(self, "_idx_in_use", None), None
+        if use is not None:
+            ev = self.torch.cuda.Event()
+            ev.record()
+            use[0]["ev"][use[1]] = ev
 
     def row_ptr(self, k):
         if k not in self._row_ptr:
@@ -278,6 +284,7 @@ class DeviceReplay(object):
         reward = self._gather(self.reward, idx_dev, k, 'reward')
         if self._regular[slots].all():                             # every sampled graph has in-degree n-2: CSR as stored
             col = self._gather(self.col, idx_dev, k, 'col').view(-1)
+            self._indices_consumed()
             rp, max_edges = self.row_ptr(k), self.n_edges
             dbs = self._db_cache.get(k)                # the gather buffers are reused: so are the batch descriptors
             if dbs is None or dbs[0].xe.data_ptr() != xe.data_ptr() or dbs[0].col_idx.data_ptr() != col.data_ptr():
@@ -285,6 +292,7 @@ class DeviceReplay(object):
             return dbs[0], dbs[1], action, reward
         else:                                                      # expand the source masks (ascending sources per row)
             masks = self._gather(self.mask, idx_dev, k, 'mask')                                  # [k, n(q)]
+            self._indices_consumed()
             bits = ((masks[:, :, None] >> torch.arange(self.n, device=self.device, dtype=torch.int32)) & 1).bool()
             col = bits.nonzero()[:, 2].to(torch.int32).contiguous()                               # (graph, q, p) order
             rp = torch.zeros(k * self.n + 1, dtype=torch.int32, device=self.device)

@@ -344,3 +344,34 @@ def test_packed_rollout_with_lookahead_is_the_array_rollout_bitwise(n_veh, feat,
         assert a.shape == b.shape and np.array_equal(a, b)
     assert np.array_equal(loss_p, loss_a) and np.array_equal(qm_p, qm_a) and np.array_equal(w_p, w_a)
     assert np.array_equal(env_p.pos, env_a.pos) and np.array_equal(env_p._mt_keys, env_a._mt_keys)
+
+
+@pytest.mark.parametrize("B", [3, 50, 200])
+def test_forward_to_host_from_pinned_memory_equals_forward(B):
+    """GnnEngine.forward_to_host on a batch whose arrays live in PINNED HOST memory (the rollout predict: the kernels read the
+    observations over the bus, the library copies Q back and synchronises) against the ordinary device-batch forward:
+    the same bits, on the one-launch predict (3 graphs), the split-tile kernels (50) and the whole-tile kernels (200)."""
+    import torch
+    from v2xgnn import GnnSpec, GnnEngine, PackedBatch
+    from v2xgnn.engine import DeviceBatch
+    from util import f32_params, random_inputs
+    from oracle import compact as oc
+    N, F = 20, 64
+    spec = GnnSpec(n_nodes=N, feat_dim=F)
+    rng = np.random.default_rng(77 + B)
+    eng = GnnEngine(spec)
+    eng.set_weights(oc.params_to_list(f32_params(spec, rng)))
+    x, e, adj = random_inputs(rng, B, N, ref_topology=True)
+    pb = PackedBatch.from_dense(x, e, adj)
+    db = eng.to_device(pb)
+    q_dev = eng.forward(db).cpu().numpy()
+    pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+    hb = DeviceBatch.from_tensors(B, N, pin(pb.xe), db.row_ptr, pin(pb.col_idx), pb.max_edges)
+    q = np.full((B * N, spec.n_channels), np.nan, np.float32)
+    for _ in range(3):
+        assert eng.forward_to_host(hb, q) is q and np.array_equal(q, q_dev)
+    with pytest.raises(ValueError):
+        eng.forward_to_host(hb, q.astype(np.float64))
+    with pytest.raises(ValueError):
+        eng.forward_to_host(pb, q)
+    eng.close()

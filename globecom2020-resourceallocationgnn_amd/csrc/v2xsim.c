@@ -580,3 +580,58 @@ int v2xsim_advance_start(const v2xsim_advance_args* a) {
   return par_start(g_job.E, advance_one, &g_job);
 }
 int v2xsim_advance_wait(int id) { return par_wait(id); }
+
+/* ---- Memory.sample's draw (BS_brain.py:261): numpy's legacy np.random.choice(n, k, replace=False) --------------------------------
+ * = RandomState.permutation(n)[:k] = shuffle(arange(n))[:k]: for i = n-1 .. 1: j = random_interval(i); swap(x[i], x[j]), with
+ * random_interval's masked rejection on 32-bit outputs (numpy/random/src/distributions/distributions.c; n < 2^32).  The whole
+ * memory is permuted for every minibatch -- 1e6 transitions at the reference's capacity -- and numpy spends 15-28 ms on it
+ * (memcpy swaps of int64 items behind a Python-level call).  Same generator, same draws, same result here on a caller-provided
+ * int32 scratch: key[624] / pos are the process-wide RandomState's (get_state / set_state around the call).  The indices
+ * are drawn first (sequential), then the swaps run with the target lines prefetched.                                    */
+static inline uint32_t np_interval(uint32_t* mt, int32_t* pos, uint32_t max) {
+  uint32_t mask = max, v;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+  do { v = mt_next(mt, pos) & mask; } while (v > max);
+  return v;
+}
+/* out[0..k) = np.random.choice(n, k, replace=False) for the generator state (key, pos), which is advanced; scratch: n int32,
+ * draws: n uint32.  Returns 0, or -1 for sizes outside 1 <= k <= n < 2^31. */
+int v2xsim_np_choice_noreplace(uint32_t* key, int32_t* pos, int64_t n, int64_t k, int32_t* scratch, uint32_t* draws, int64_t* out) {
+  if (n < 1 || k < 1 || k > n || n >= ((int64_t)1 << 31)) return -1;
+  int32_t p = *pos;
+  {
+    /* random_interval(i) for i = n-1 .. 1 without a data-dependent branch: every 32-bit output is masked and stored for the
+     * current i, which only moves on when the value was accepted (a rejected value is overwritten by the next one);
+     * the mask changes where i crosses a power of two */
+    int64_t i = n - 1;
+    while (i >= 1) {
+      uint32_t mask = (uint32_t)i;
+      mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+      const int64_t lo = (int64_t)(mask >> 1) + 1;               /* smallest i with this mask */
+      while (i >= lo) {
+        const uint32_t v = mt_next(key, &p) & mask;
+        draws[i] = v;
+        i -= v <= (uint32_t)i;
+      }
+    }
+  }
+  *pos = p;
+  for (int64_t i = 0; i < n; ++i) scratch[i] = (int32_t)i;
+  for (int64_t i = n - 1; i >= 1; --i) {
+    if (i > 16) __builtin_prefetch(scratch + draws[i - 16], 1, 1);
+    const uint32_t j = draws[i];
+    const int32_t t = scratch[i];
+    scratch[i] = scratch[j];
+    scratch[j] = t;
+  }
+  for (int64_t i = 0; i < k; ++i) out[i] = scratch[i];
+  return 0;
+}
+/* np.random.shuffle(np.arange(n)) consumed without building the array (Model.fit's shuffle of one batch) */
+int v2xsim_np_shuffle_skip(uint32_t* key, int32_t* pos, int64_t n) {
+  if (n < 0 || n >= ((int64_t)1 << 31)) return -1;
+  int32_t p = *pos;
+  for (int64_t i = n - 1; i >= 1; --i) (void)np_interval(key, &p, (uint32_t)i);
+  *pos = p;
+  return 0;
+}

@@ -46,6 +46,10 @@ def _load():
     lib.v2xsim_advance_start.restype = C.c_int
     lib.v2xsim_advance_wait.argtypes = [C.c_int]
     lib.v2xsim_advance_wait.restype = C.c_int
+    lib.v2xsim_np_choice_noreplace.argtypes = [u32p, i32p, C.c_int64, C.c_int64, i32p, u32p, ip]
+    lib.v2xsim_np_choice_noreplace.restype = C.c_int
+    lib.v2xsim_np_shuffle_skip.argtypes = [u32p, i32p, C.c_int64]
+    lib.v2xsim_np_shuffle_skip.restype = C.c_int
     for f in (lib.v2xsim_observe_packed, lib.v2xsim_positions, lib.v2xsim_advance):
         f.restype = None
     for f in (lib.v2xsim_channels, lib.v2xsim_reward, lib.v2xsim_interference, lib.v2xsim_observe, lib.v2xsim_set_threads,
@@ -217,3 +221,29 @@ def advance_start(args):
 def advance_wait(ticket=0):
     """returns when job `ticket` is done (0: whatever is in flight)"""
     return _load().v2xsim_advance_wait(int(ticket)) == 0
+
+
+_choice_scratch = {}
+
+
+def np_choice_noreplace(n, k):
+    """np.random.choice(n, k, replace=False) on the process-wide legacy generator -- the same draws, the same indices, the same
+    state afterwards -- with the permutation of the n positions done in the library (numpy: 15-28 ms at n = 1e6, here 3-5)."""
+    lib = _load()
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    if name != 'MT19937':
+        raise RuntimeError("np.random is not on MT19937")
+    key = np.ascontiguousarray(key, np.uint32).copy()
+    p = np.array([pos], np.int32)
+    buf = _choice_scratch.get("buf")
+    if buf is None or buf[0].size < n:
+        m = max(int(n), 2 * (buf[0].size if buf is not None else 0), 65536)
+        buf = _choice_scratch["buf"] = (np.empty(m, np.int32), np.empty(m, np.uint32))
+    out = np.empty(int(k), np.int64)
+    rc = lib.v2xsim_np_choice_noreplace(key.ctypes.data_as(C.POINTER(C.c_uint32)), p.ctypes.data_as(C.POINTER(C.c_int32)), int(n), int(k),
+                                        buf[0].ctypes.data_as(C.POINTER(C.c_int32)), buf[1].ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        out.ctypes.data_as(C.POINTER(C.c_int64)))
+    if rc != 0:
+        raise ValueError("np_choice_noreplace: need 1 <= k <= n < 2**31")
+    np.random.set_state((name, key, int(p[0]), has_gauss, cached))
+    return out

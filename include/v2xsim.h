@@ -69,6 +69,12 @@ void v2xsim_advance(const v2xsim_advance_args* a);
 int v2xsim_advance_start(const v2xsim_advance_args* a);
 int v2xsim_advance_wait(int ticket);
 
+/* Memory.sample's draw (BS_brain.py:261): numpy's legacy np.random.choice(n, k, replace=False) = permutation(n)[:k] on the
+ * process-wide RandomState's MT19937 state (key[624], pos: get_state / set_state around the call), draw for draw; scratch [n]
+ * int32, draws [n] uint32; 0 or -1 (sizes).  v2xsim_np_shuffle_skip: the draws of np.random.shuffle(np.arange(n)) only. */
+int v2xsim_np_choice_noreplace(uint32_t* key, int32_t* pos, int64_t n, int64_t k, int32_t* scratch, uint32_t* draws, int64_t* out);
+int v2xsim_np_shuffle_skip(uint32_t* key, int32_t* pos, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

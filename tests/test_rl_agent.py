@@ -246,3 +246,28 @@ def test_more_than_31_links_keep_the_host_replay_memory_under_auto():
     assert len(agent.memory.samples) == 3
     with pytest.raises(ValueError, match="at most 31 links"):
         Agent(32, env.n_RB, env.n_Neighbor, 16, env, cfg, brain=brain, device_replay=True)
+
+
+def test_native_sampler_is_numpys_choice_without_replacement():
+    """Memory.sample_indices past 16,384 stored transitions: the library's restatement of np.random.choice(n, k, replace=False)
+    (= permutation(n)[:k]: Fisher-Yates from the top with random_interval's masked rejection) on the process-wide generator --
+    the same indices, the same dtype, and the generator in the same state afterwards, for sizes around powers of two and at
+    the reference's capacity."""
+    from v2xgnn.rl import native_sim
+    from v2xgnn.rl.agent import Memory
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    for n, k in ((1, 1), (2, 1), (3, 2), (100, 7), (1025, 1025), (16384, 4096), (65536, 3), (65537, 4096), (200000, 4096), (1000000, 512)):
+        np.random.seed(n + k)
+        np.random.random(3); np.random.normal()                 # (a cached Gaussian in the state must survive the round trip)
+        a, ra, ga = np.random.choice(n, k, replace=False), np.random.random(2), np.random.normal(size=3)
+        np.random.seed(n + k)
+        np.random.random(3); np.random.normal()
+        b, rb, gb = native_sim.np_choice_noreplace(n, k), np.random.random(2), np.random.normal(size=3)
+        assert a.dtype == b.dtype and np.array_equal(a, b) and np.array_equal(ra, rb) and np.array_equal(ga, gb), (n, k)
+    mem = Memory(10 ** 6)
+    mem.samples = [None] * 50000
+    np.random.seed(5)
+    want, want2 = np.random.choice(50000, 4096, replace=False), np.random.choice(70000, 4096, replace=False)
+    np.random.seed(5)
+    assert np.array_equal(mem.sample_indices(4096), want) and np.array_equal(mem.sample_indices(4096, 70000), want2)

@@ -14,10 +14,13 @@ import os
 
 import numpy as np
 
+from . import native_sim
+
 MEMORY_CAPACITY = 1000000          # BS_brain.py:274
 UPDATE_TARGET_FREQUENCY = 500      # :275
 MAX_EPSILON = 1                    # :276
 MIN_EPSILON = 0.01                 # :277
+NATIVE_SAMPLER_MIN = 16384         # stored transitions from which Memory.sample's draw runs in libv2xsim.so (below: numpy is as fast)
 
 
 
@@ -50,7 +53,7 @@ class Memory(object):
             # numpy permutes the WHOLE memory for this (permutation(length)[:n]): 15-75 ms at the reference's capacity of 1e6
             # transitions.  The library runs the same shuffle on the same generator state -- same draws, same positions, same
             # state afterwards (tests/test_rl_agent.py) -- in 3-7 ms; below ~16k stored transitions numpy's call is as fast.
-            if length >= 16384 and os.environ.get("V2X_RL_NATIVE_SAMPLER", "1") != "0":
+            if length >= NATIVE_SAMPLER_MIN and os.environ.get("V2X_RL_NATIVE_SAMPLER", "1") != "0":
                 from . import native_sim
                 if native_sim.available():
                     return native_sim.np_choice_noreplace(length, n)
@@ -350,8 +353,15 @@ class Agent(object):
         rep.stage_early(xe, col, mask)
         if last and getattr(self, '_predraw_ok', False):
             mem_len = min(self.memory.capacity, len(self.memory.samples) + E)
-            idx = self._draw_replay_indices(mem_len)
-            self._predrawn = (idx, rep.prefetch_indices(idx, E))
+            n_draw = self.batch_size // (self.brain.model.trainer.world if self._shard_world() > 1 else 1)
+            if (mem_len >= NATIVE_SAMPLER_MIN and mem_len >= n_draw and native_sim.available()
+                    and os.environ.get("V2X_RL_NATIVE_SAMPLER", "1") != "0"):
+                # a large memory: the permutation behind the draw takes 0.2-7 ms -- on a helper thread while this one scores,
+                # acts and stores (nothing below draws from np.random; _replay_on_device collects the result first)
+                self._predrawn = ("ahead", native_sim.ChoiceAhead(mem_len, n_draw), mem_len)
+            else:
+                idx = self._draw_replay_indices(mem_len)
+                self._predrawn = (idx, rep.prefetch_indices(idx, E))
         if greedy:
             if regular.all():
                 # ALL environments are scored, the exploring ones' rows are dropped: one batch shape for the whole run (one
@@ -475,17 +485,18 @@ class Agent(object):
         # the reference reads "original" Q statistics from p AFTER it was overwritten in place (:684-690, :743-746)
         return result, q_mean, q_max_mean, q_mean.copy(), q_max_mean.copy()
 
-    def _draw_replay_indices(self, mem_len=None):
+    def _draw_replay_indices(self, mem_len=None, ahead=None):
         """The replay's draws from the process-wide numpy stream, in the reference's order: the minibatch positions
         (Memory.sample, BS_brain.py:261/:268), then Model.fit's shuffle of the sample order.
-        mem_len: the memory's length at the time of the replay when that is not now (the rollout draws ahead)."""
+        mem_len: the memory's length at the time of the replay when that is not now (the rollout draws ahead).
+        ahead: a native_sim.ChoiceAhead started for exactly this draw (its result replaces Memory.sample_indices)."""
         B, model = self.batch_size, self.brain.model
         trainer = model.trainer
         if self._shard_world() > 1:                                # own memory, own draws: B / G graphs of the minibatch
-            idx = self.memory.sample_indices(B // trainer.world, mem_len)
+            idx = ahead.result() if ahead is not None else self.memory.sample_indices(B // trainer.world, mem_len)
             model.consume_fit_shuffle(len(idx))
         else:
-            idx = self.memory.sample_indices(B, mem_len)
+            idx = ahead.result() if ahead is not None else self.memory.sample_indices(B, mem_len)
             model.consume_fit_shuffle(B)       # same RNG stream as fit()
             if trainer is not None and trainer.world > 1:
                 per = B // trainer.world
@@ -505,7 +516,9 @@ class Agent(object):
             raise ValueError("batch %d not divisible by %d ranks" % (B, trainer.world))
         rep = self.device_replay
         pre, self._predrawn = getattr(self, '_predrawn', None), None
-        if pre is not None:                                        # drawn by the rollout right after its epsilon draws
+        if pre is not None and isinstance(pre[0], str):            # started by the rollout on a helper thread: collect it
+            idx, pre = self._draw_replay_indices(pre[2], ahead=pre[1]), None
+        elif pre is not None:                                      # drawn by the rollout right after its epsilon draws
             idx, pre = pre
         else:
             idx = self._draw_replay_indices()
@@ -562,6 +575,9 @@ class Agent(object):
         try:
             return self._train_loop(num_episodes, num_train_steps, save_dir, save_interval, verbose)
         finally:
+            pre = getattr(self, '_predrawn', None)
+            if pre is not None and isinstance(pre[0], str):        # a draw still running on the helper thread: np.random gets its state back
+                pre[1].result()
             self._predraw_ok, self._predrawn = False, None
             if hasattr(self.env, 'finish_step'):
                 self.env.finish_step()

@@ -247,3 +247,36 @@ def np_choice_noreplace(n, k):
         raise ValueError("np_choice_noreplace: need 1 <= k <= n < 2**31")
     np.random.set_state((name, key, int(p[0]), has_gauss, cached))
     return out
+
+
+class ChoiceAhead(object):
+    """np_choice_noreplace(n, k) running on a helper thread (the library call releases the GIL): started right after the caller's
+    last draw from np.random, finished -- result(): the indices, and np.random moved on past the draws -- before its next one.
+    Between the two the process-wide generator must not be used; the caller (Agent._packed_iteration inside Agent.train) knows
+    that nothing draws there."""
+    _pool = None
+
+    def __init__(self, n, k):
+        lib = _load()
+        name, key, pos, has_gauss, cached = np.random.get_state()
+        if name != 'MT19937':
+            raise RuntimeError("np.random is not on MT19937")
+        self._rest = (name, has_gauss, cached)
+        self._key = np.ascontiguousarray(key, np.uint32).copy()
+        self._pos = np.array([pos], np.int32)
+        self._buf = (np.empty(int(n), np.int32), np.empty(int(n), np.uint32))      # (not the shared scratch: another thread)
+        self._out = np.empty(int(k), np.int64)
+        if ChoiceAhead._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            ChoiceAhead._pool = ThreadPoolExecutor(max_workers=1)
+        u32p, i32p = C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+        self._fut = ChoiceAhead._pool.submit(lib.v2xsim_np_choice_noreplace, self._key.ctypes.data_as(u32p), self._pos.ctypes.data_as(i32p),
+                                             int(n), int(k), self._buf[0].ctypes.data_as(i32p), self._buf[1].ctypes.data_as(u32p),
+                                             self._out.ctypes.data_as(C.POINTER(C.c_int64)))
+
+    def result(self):
+        if self._fut.result() != 0:
+            raise ValueError("np_choice_noreplace: need 1 <= k <= n < 2**31")
+        name, has_gauss, cached = self._rest
+        np.random.set_state((name, self._key, int(self._pos[0]), has_gauss, cached))
+        return self._out

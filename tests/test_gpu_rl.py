@@ -294,8 +294,9 @@ def test_batched_rollouts_on_the_engine(n_veh, feat, batch, n_envs):
         assert np.allclose(loss_n, loss_d, rtol=2e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("n_veh,feat,batch,n_envs,capacity", [(4, 16, 64, 6, None), (20, 64, 256, 50, None), (4, 16, 64, 6, 130)])
-def test_packed_rollout_with_lookahead_is_the_array_rollout_bitwise(n_veh, feat, batch, n_envs, capacity, monkeypatch):
+@pytest.mark.parametrize("n_veh,feat,batch,n_envs,capacity,sampler_min", [(4, 16, 64, 6, None, None), (20, 64, 256, 50, None, None),
+                                                                            (4, 16, 64, 6, 130, None), (20, 64, 256, 50, None, 300)])
+def test_packed_rollout_with_lookahead_is_the_array_rollout_bitwise(n_veh, feat, batch, n_envs, capacity, sampler_min, monkeypatch):
     """the rollout of a batched step as observe_packed -> pinned copy -> one predict launch -> argmax ->
     add_many_packed, with the next simulator step computed on the library's worker thread meanwhile -- against the array path
     (float64 observations, dense adjacency, PackedBatch.from_dense, add_many; V2X_RL_PACKED=0) on a simulator without
@@ -303,7 +304,8 @@ def test_packed_rollout_with_lookahead_is_the_array_rollout_bitwise(n_veh, feat,
     losses and weights after two episodes (a reset drops a started look-ahead step).  Inside Agent.train the packed rollout
     also copies the observation half of its transitions to their replay slots and draws / uploads the replay's minibatch before
     it scores (the GPU is still fitting); capacity 130: a replay memory that wraps every third step, where those shortcuts
-    must step aside."""
+    must step aside; sampler_min: the minibatch draw restated in libv2xsim.so, on a helper thread in the packed run and in line
+    in the array run (the last case: 300 stored transitions instead of 16,384 switch it on)."""
     from v2xgnn.rl import Agent, RL_Config, native_sim
     from v2xgnn.rl import agent as agent_mod
     from v2xgnn.rl.train import start_env_batched
@@ -311,6 +313,8 @@ def test_packed_rollout_with_lookahead_is_the_array_rollout_bitwise(n_veh, feat,
         pytest.skip("libv2xsim.so not built")
     if capacity is not None:
         monkeypatch.setattr(agent_mod, "MEMORY_CAPACITY", capacity)
+    if sampler_min is not None:        # the library's sampler from 300 stored transitions on: in the packed run it works on a helper thread
+        monkeypatch.setattr(agent_mod, "NATIVE_SAMPLER_MIN", sampler_min)
 
     def run(packed, lookahead):
         random.seed(33)

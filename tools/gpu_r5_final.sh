@@ -60,6 +60,8 @@ bash tools/rl_loop_kernels.sh 2>&1 | grep -v -e amdgpu.ids -e rocprofv3 | cut -c
 cat /sys/fs/cgroup/cpu.max > $O/cpu_quota.txt 2>/dev/null; nproc >> $O/cpu_quota.txt
 python bench.py --workload cfg0 --envs 10 > $O/bench_cfg0_episode_envs10.json 2>/dev/null
 for i in 1 2 3; do python bench.py --workload cfg2loop --envs 50 --episodes 5 > $O/bench_cfg2loop_envs50_run$i.json 2>/dev/null; done
+python bench.py --workload cfg2loop --envs 50 --episodes 200 > $O/bench_cfg2loop_envs50_4000steps.json 2>/dev/null
+V2X_RL_NATIVE_SAMPLER=0 python bench.py --workload cfg2loop --envs 50 --episodes 200 > $O/bench_cfg2loop_envs50_4000steps_numpy_sampler.json 2>/dev/null
 python tools/predict_latency.py 2>&1 | grep -v amdgpu.ids > $O/predict_latency.txt
 python tools/dropin_profile.py 2>&1 | grep -v amdgpu.ids > $O/dropin_profile.txt
 python tools/dp_host_overhead.py 2>&1 | grep -v -e amdgpu.ids -e "version" -e Hostname -e Librccl > $O/dp_host_overhead.txt

@@ -229,7 +229,7 @@ def _timed_steps(step, budget_s, min_steps, max_steps, warmup):
     return float(np.median(ts)), len(ts)
 
 
-def cpu_baseline(N, F, L, share, B, budget_s=30.0):
+def cpu_baseline(N, F, L, share, B, budget_s=30.0, full=False):
     """The CPU restatements of the path timed on this host, fp32, at 1 BLAS thread and at all
     cores: C0 = the reference's own formulation (per-node weights, dict inputs, dense kron(Adj, I_F) adjacency,
     batched dot: oracle/literal.py) at the reference's configuration N=4, F=16, B=512; C1 = the same formulation at
@@ -313,10 +313,17 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0):
                                         "steps": 0, "batch": B}
     # the headline CPU number is the best C2 figure; `cores` = the threads / processes of that run
     main_leg = max(legs["C2_sharded_processes"], legs["C2_all_cores"], legs["C2_one_thread"], key=lambda l: l["graphs_per_s"])
-    return {"value": main_leg["graphs_per_s"], "unit": "graph-instances/s", "cores": int(main_leg["threads"]), "kind": "port",
-            "cpu_model": cpu_model(), "host_cores": host_cores, "usable_cpus": usable,
+    # `workers` = the threads / processes of that run; `cores` = the CPUs they could keep busy at once (the box's cgroup grants
+    # `usable_cpus` CPUs' worth of time however many hardware threads it shows: 64 worker processes there are 16 CPUs shared by 64)
+    if not full:
+        legs = {k_: {"graphs_per_s": v_["graphs_per_s"], "ms_per_step": v_.get("ms_per_step"), "batch": v_["batch"], "threads": v_["threads"]}
+                for k_, v_ in legs.items()}
+    return {"value": main_leg["graphs_per_s"], "unit": "graph-instances/s", "usable_cpus": usable, "workers": int(main_leg["threads"]),
+            "cores": int(min(main_leg["threads"], usable)), "kind": "port",
+            "cpu_model": cpu_model(), "host_cores": host_cores,
             "sample": "median of %d fit steps of B=%d (N=%d,F=%d,L=%d,%s weights) after 1 warm-up, numpy fp32 CSR oracle "
-                      "(leg C2, %d core(s)); a CPU restatement of the reference math, not Keras/TF1"
+                      "(leg C2, %d worker(s)); a CPU restatement of the reference math, not Keras/TF1; legs: C0 = the reference's "
+                      "formulation (dense kron adjacency) N=4 F=16 B=512, C1 = the same at N=20 F=64 B=256, C2 = compact CSR at the benchmark's size"
                       % (main_leg["steps"], main_leg["batch"], N, F, L, "shared" if share else "per-node", main_leg["threads"]),
             "legs": legs}
 
@@ -401,7 +408,8 @@ def main_rl(args):
         from oracle.engine import OracleEngine
         r = rl_episode(links, feat, batch, gamma, steps, 1001, engine_factory=lambda spec: OracleEngine(spec, dtype=np.float32),
                        envs=args.envs, episodes=1)
-        cpu = {"value": r["train_steps_per_s"], "unit": "train-steps/s", "cores": len(os.sched_getaffinity(0)), "kind": "port",
+        cpu = {"value": r["train_steps_per_s"], "unit": "train-steps/s", "usable_cpus": usable_cpus(), "workers": 1,
+               "cores": 1, "kind": "port",
                "cpu_model": cpu_model(), "sample": "one episode (seed 1001, after the same warm-up) with the numpy fp32 oracle as the Q-network", "detail": r}
     _print_last(json.dumps({"metric": "DQN train steps/s (50 simulator transitions + 1 replay of batch %d each), %d V2V links, feat_dim %d"
                                 % (batch, links, feat),
@@ -542,6 +550,9 @@ def build_parser():
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in boundary leg (dict API at the reference's configuration)")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the short passes of configs[3] / configs[4] at their per-GPU shares (config.other_workloads)")
+    ap.add_argument("--other-kernels", action="store_true",
+                    help="config.other_workloads in its long form (workload prose, kernel path, per-kernel HIP-event times); the default "
+                         "line is kept under 8 KB so that a record that keeps only a tail of stdout keeps all of it")
     ap.add_argument("--no-weak-pass", action="store_true", help="N > 1: skip the second timed pass at --batch graphs PER GPU (config.weak)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0)
     ap.add_argument("--workload", choices=["cfg2", "cfg4", "cfg5", "cfg0", "cfg2loop"], default="cfg2",
@@ -833,7 +844,7 @@ def run_workload(args, ctx, light=False):
                                          "+RCCL grad all-reduce" if world > 1 else ""),
                           "weights": "shared" if args.share_weights else "per-node (reference semantics)",
                           "global_batch": n_global, "graphs_per_gpu": B_local, "scaling": args.scaling, "n_params": eng.n_params,
-                          "aggregation": path.get("aggregation"), "kernel_path": path, "fast_path": fast, "weak": weak,
+                          "aggregation": path.get("aggregation"), "kernel_path": path, "weak": weak,
                           "ranks_seen": (dist.get_world_size() if dist is not None else 1), "rccl_version": rccl,
                           "collective_backend": (dist.get_backend() if dist is not None else None),
                           "dp_form": (None if trainer is None else
@@ -870,8 +881,8 @@ def cpu_leg_share(wl, budget_s=8.0):
             sec, steps = _timed_steps(so.step, budget_s, 2, 20, 1)
         finally:
             so.close()
-        return {"value": round(bs / sec, 1), "unit": "graph-instances/s", "cores": int(workers), "kind": "port", "cpu_model": cpu_model(),
-                "usable_cpus": usable_cpus(), "ms_per_step": round(1e3 * sec, 2), "steps": steps,
+        return {"value": round(bs / sec, 1), "unit": "graph-instances/s", "usable_cpus": usable_cpus(), "workers": int(workers),
+                "cores": int(min(workers, usable_cpus())), "kind": "port", "ms_per_step": round(1e3 * sec, 2), "steps": steps,
                 "sample": "median of %d fit steps of a %d-graph sample of the 1024-graph share (N=100, F=256, L=3, per-node weights): "
                           "%d worker processes x 1 BLAS thread over graph shards, gradients summed, one Adam update; numpy fp32 CSR "
                           "oracle, not Keras/TF1" % (steps, bs, workers)}
@@ -893,8 +904,8 @@ def cpu_leg_share(wl, budget_s=8.0):
         if best is None or sec < best[0]:
             best = (sec, steps, nthr)
     sec, steps, nthr = best
-    return {"value": round(bs / sec, 1), "unit": "graph-instances/s", "cores": int(nthr), "kind": "port", "cpu_model": cpu_model(),
-            "ms_per_step": round(1e3 * sec, 2), "steps": steps,
+    return {"value": round(bs / sec, 1), "unit": "graph-instances/s", "usable_cpus": usable_cpus(), "workers": int(nthr),
+            "cores": int(min(nthr, usable_cpus())), "kind": "port", "ms_per_step": round(1e3 * sec, 2), "steps": steps,
             "sample": "median of %d fit steps of a %d-graph ragged sample (8-128 links, %d node rows) of the 2048-graph share (F=64, L=2, "
                       "shared weights), numpy fp32 CSR oracle at %d BLAS thread(s) (the better of 1 and the pool's size), not Keras/TF1"
                       % (steps, bs, int(offs[-1]), nthr)}
@@ -922,11 +933,14 @@ def other_workloads(args, ctx):
         a = resolve_workload(a)
         r = run_workload(a, ctx, light=True)
         rf = r.get("roofline") or {}
-        return {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
-                "steps": r["steps"], "timed_seconds": r["timed_seconds"], "graphs_per_gpu": r["config"]["graphs_per_gpu"],
-                "aggregation": r["aggregation"], "kernel_path": r["config"]["kernel_path"], "dominant_kernel": rf.get("kernel"),
-                "bound": rf.get("bound"), "frac": rf.get("frac"), "step_hbm_frac": rf.get("step_hbm_frac"),
-                "step_mfma_frac": rf.get("step_mfma_frac"), "kernels": r.get("kernels")}
+        d = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+             "graphs_per_gpu": r["config"]["graphs_per_gpu"], "graph_layers": r["config"]["kernel_path"].get("graph_layers"),
+             "aggregation": r["aggregation"], "dominant_kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"),
+             "step_hbm_frac": rf.get("step_hbm_frac"), "step_mfma_frac": rf.get("step_mfma_frac")}
+        if args.other_kernels:            # the long form: workload prose, the whole path, HIP-event times of every kernel
+            d.update({"workload": r["config"]["workload"], "kernel_path": r["config"]["kernel_path"],
+                      "timed_seconds": r["timed_seconds"], "kernels": r.get("kernels")})
+        return d
 
     def guarded(key, fn):
         try:
@@ -956,16 +970,52 @@ def other_workloads(args, ctx):
                 os.environ["V2X_FUSED"] = had
     guarded("per_edge_gather", per_edge)
 
-    def dqn_loop():
+    def dqn_loop(envs, episodes):
         import torch
         with torch.cuda.stream(torch.cuda.Stream()):
-            r = rl_episode(20, 64, 4096, 0.5, 20, 1001, use_graph=True, envs=50, episodes=5)
-        r["workload"] = ("BASELINE.json configs[2] on one GPU: 5 episodes x 20 train steps x (50 rollout transitions on 50 simulators "
-                         "stepped as arrays + 1 replay of batch 4096), 20 links, feat_dim 64; one agent, two-step warm-up episode "
-                         "outside the timed region")
+            r = rl_episode(20, 64, 4096, 0.5, 20, 1001, use_graph=True, envs=envs, episodes=episodes)
+        r["simulators"], r["episodes"] = max(envs, 1), episodes
+        if args.other_kernels:
+            r["workload"] = ("BASELINE.json configs[2] on one GPU: %d episodes x 20 train steps x (50 rollout transitions on %s + 1 replay "
+                             "of batch 4096), 20 links, feat_dim 64; one agent, two-step warm-up episode outside the timed region"
+                             % (episodes, "50 simulators stepped as arrays" if envs > 1 else
+                                "ONE simulator, sequentially, a B=1 predict each: the reference's own loop shape (BS_brain.py:818-832)"))
         return r
-    guarded("cfg2loop", dqn_loop)
+    # the key says which loop: 50 simulators stepped as arrays, or the reference's shape (one simulator, 50 sequential transitions)
+    guarded("cfg2loop_envs50", lambda: dqn_loop(50, 5))
+    guarded("cfg2loop_env1", lambda: dqn_loop(1, 2))
     return out
+
+
+def summary(out, others, dropin, cpu):
+    """Every figure of the default run that is quoted beside the headline, as one flat object of numbers: ms per step of the shares of
+    the metric's batch (2 / 4 / 8 GPUs), configs[3] / [4] at their shares with the dominant kernel's roofline fraction and the CPU
+    leg (graphs/s), the per-edge CSR gather step, both DQN loops (50 simulators as arrays; the reference's one-simulator shape) and the
+    dict-API replay at the reference's configuration."""
+    o = others or {}
+
+    def get(key, field, nd=4):
+        v = (o.get(key) or {}).get(field)
+        return None if v is None else round(float(v), nd)
+
+    def cpu_of(key):
+        v = ((o.get(key) or {}).get("cpu_baseline") or {}).get("value")
+        return None if v is None else round(float(v), 1)
+    sm = {"ms": out["ms_per_step"], "frac": (out.get("roofline") or {}).get("frac"),
+          "step_mfma_frac": (out.get("roofline") or {}).get("step_mfma_frac"),
+          "fast_path_ms": (out.get("fast_path") or {}).get("ms_per_step"),
+          "cpu": None if cpu is None else cpu["value"], "cpu_workers": None if cpu is None else cpu["workers"],
+          "usable_cpus": None if cpu is None else cpu["usable_cpus"],
+          "share2_ms": get("cfg2_share2", "ms_per_step"), "share4_ms": get("cfg2_share4", "ms_per_step"),
+          "share8_ms": get("cfg2_share8", "ms_per_step"),
+          "cfg4_ms": get("cfg4", "ms_per_step"), "cfg4_frac": get("cfg4", "frac"), "cfg4_step_mfma_frac": get("cfg4", "step_mfma_frac"),
+          "cfg4_cpu": cpu_of("cfg4"),
+          "cfg5_ms": get("cfg5", "ms_per_step"), "cfg5_frac": get("cfg5", "frac"), "cfg5_step_mfma_frac": get("cfg5", "step_mfma_frac"),
+          "cfg5_cpu": cpu_of("cfg5"),
+          "per_edge_ms": get("per_edge_gather", "ms_per_step"),
+          "cfg2loop_envs50_ms": get("cfg2loop_envs50", "ms_per_train_step", 3), "cfg2loop_env1_ms": get("cfg2loop_env1", "ms_per_train_step", 3),
+          "dropin_ms": (dropin or {}).get("replay_triple_ms"), "predict_one_us": (dropin or {}).get("predict_one_step_us")}
+    return sm
 
 
 def main():
@@ -1007,7 +1057,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not ragged:
         b_local = args.batch // (args.shard_of if args.scaling == "strong" else 1)
-        cpu = cpu_baseline(args.nodes, args.feat, args.layers, args.share_weights, b_local, args.cpu_seconds)
+        cpu = cpu_baseline(args.nodes, args.feat, args.layers, args.share_weights, b_local, args.cpu_seconds, full=args.other_kernels)
     dropin = None
     if solo and args.workload == "cfg2" and not args.no_dropin:
         try:
@@ -1020,14 +1070,21 @@ def main():
     out = run_workload(args, ctx)
     if rank == 0:
         out["cpu_baseline"] = cpu
+        if "kernels" in out:
+            out["kernels_note"] = ("HIP events around eager launches of an instrumented pass (roofline.avg_launch_us comes from it); their sum "
+                                   "exceeds ms_per_step, which is the hipGraph replay of the same launches; rocprofv3 averages: profiles/")
         if dropin is not None:
             out["dropin_ref_config"] = dropin
+            if not args.other_kernels:
+                dropin.pop("what", None)           # (prose: BS.predict + BS.predict(target) + BS.train_dnn on the reference's dict payload, N=4 F=16 B=512)
             if cpu is not None and "C0_one_thread" in cpu.get("legs", {}):
                 dropin["cpu_fit_step_C0_ms"] = cpu["legs"]["C0_one_thread"]["ms_per_step"]
         if others is not None:
             out["config"]["other_workloads"] = others
             pe = others.get("per_edge_gather") or {}
-            out["config"]["per_edge_gather"] = {k_: pe.get(k_) for k_ in ("value", "unit", "ms_per_step", "aggregation", "kernel_path", "error") if k_ in pe}
+            out["config"]["per_edge_gather"] = {k_: pe.get(k_) for k_ in ("value", "unit", "ms_per_step", "aggregation", "graph_layers", "error") if k_ in pe}
+        # numbers only, LAST key of the line: survives a record that keeps a tail of stdout or filters keys
+        out["summary"] = summary(out, others, dropin, cpu)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

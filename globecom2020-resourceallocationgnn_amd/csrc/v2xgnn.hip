@@ -2552,6 +2552,17 @@ int v2x_adam_step(float* param, const float* grad, float* mom, float* vel, int64
 }
 
 // ---------------------------------------------------------------------------- DQN replay glue
+int v2x_device_addressable(const void* p) {
+  v2x_model* nullm = nullptr;
+  if (!p) FAIL(nullm, V2X_EINVAL, "device_addressable: null pointer");
+  hipPointerAttribute_t at;
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }     // unknown to the runtime: pageable host memory
+  if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) return 1;
+  if (at.type == hipMemoryTypeHost) return at.devicePointer == p ? 1 : 0;
+  return 0;
+}
+
 int v2x_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_idx, int64_t row_bytes, void* stream) {
   v2x_model* nullm = nullptr;
   if (!src || !idx || !dst || n_idx <= 0 || row_bytes <= 0 || (row_bytes & 3))

@@ -43,6 +43,8 @@ static struct {
   _Atomic int remaining;
   int async_busy;                                   /* a par_start job is in flight (or done and not yet waited for) */
   int async_id;                                     /* its ticket */
+  int sync_busy;                                    /* a par_for job of ANOTHER caller is in flight (ctypes releases the GIL: two
+                                                       host threads may step two simulators at once): later callers run alone */
 } P = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER };
 static int g_threads = 1;            /* threads a loop may use, the caller included (v2xsim_set_threads) */
 
@@ -81,6 +83,7 @@ static void pool_after_fork(void) {                 /* the threads do not exist 
   pthread_cond_init(&P.cv_done, 0);
   P.n_started = 0;
   P.async_busy = 0;
+  P.sync_busy = 0;
   atomic_store(&P.remaining, 0);
 }
 /* post a job for `workers` pool threads (mu held) */
@@ -102,27 +105,29 @@ static void post(env_fn fn, void* ctx, int n, int workers) {
 static void par_for(int n, env_fn fn, void* ctx) {
   if (n <= 0) return;
   pthread_mutex_lock(&P.mu);
-  if ((P.async_busy && atomic_load(&P.remaining) > 0) || g_threads <= 1 || n == 1) {   /* the pool is working ahead (or not wanted): the caller alone */
+  if ((P.async_busy && atomic_load(&P.remaining) > 0) || P.sync_busy || g_threads <= 1 || n == 1) {
+    /* the pool is working ahead, or on another caller's loop (the job slot is ONE: posting over it would strand that caller's
+       environments), or is not wanted: the caller alone */
     pthread_mutex_unlock(&P.mu);
     for (int e = 0; e < n; ++e) fn(e, ctx);
     return;
   }
+  P.sync_busy = 1;
   post(fn, ctx, n, (g_threads < n ? g_threads : n) - 1);
   const uint32_t gen = P.gen;
   pthread_mutex_unlock(&P.mu);
   for (int e; (e = take(gen, n)) >= 0;) { fn(e, ctx); atomic_fetch_sub(&P.remaining, 1); }
   for (int spin = 0; spin < 4000 && atomic_load(&P.remaining) > 0; ++spin) __builtin_ia32_pause();
-  if (atomic_load(&P.remaining) > 0) {
-    pthread_mutex_lock(&P.mu);
-    while (atomic_load(&P.remaining) > 0) pthread_cond_wait(&P.cv_done, &P.mu);
-    pthread_mutex_unlock(&P.mu);
-  }
+  pthread_mutex_lock(&P.mu);
+  while (atomic_load(&P.remaining) > 0) pthread_cond_wait(&P.cv_done, &P.mu);
+  P.sync_busy = 0;
+  pthread_mutex_unlock(&P.mu);
 }
 /* > 0: started, the job's ticket; -1: another job is still RUNNING (one that is done but was never waited for -- its owner
  * forgot it or died -- is simply replaced: its results are complete); -2: no pool thread */
 static int par_start(int n, env_fn fn, void* ctx) {
   pthread_mutex_lock(&P.mu);
-  if (P.async_busy && atomic_load(&P.remaining) > 0) { pthread_mutex_unlock(&P.mu); return -1; }
+  if ((P.async_busy && atomic_load(&P.remaining) > 0) || P.sync_busy) { pthread_mutex_unlock(&P.mu); return -1; }
   post(fn, ctx, n, g_threads < n ? g_threads : n);
   if (P.n_workers == 0) { P.async_busy = 0; pthread_mutex_unlock(&P.mu); return -2; }
   P.async_busy = 1;

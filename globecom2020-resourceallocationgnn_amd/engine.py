@@ -184,6 +184,13 @@ class GnnEngine(object):
         few kilobytes of a rollout batch straight over the bus and no copy launch is involved at all."""
         if not isinstance(batch, DeviceBatch):
             raise ValueError("forward_to_host takes a DeviceBatch")
+        if not getattr(batch, "_addressable", False):        # once per batch object: its tensors do not change under it
+            for name in ("xe", "nbr", "row_ptr", "col_idx", "graph_off"):
+                t = getattr(batch, name)
+                if t is not None and not t.is_cuda and self._lib.v2x_device_addressable(t.data_ptr()) != 1:
+                    raise ValueError("forward_to_host: batch.%s is host memory the device cannot address (pageable, or mapped at "
+                                     "another address): pin it (tensor.pin_memory()) or move it to the device" % name)
+            batch._addressable = True
         if q.dtype != np.float32 or not q.flags.c_contiguous or q.size != batch.n_rows * self.spec.n_channels:
             raise ValueError("q must be a C-contiguous float32 array of %d x %d" % (batch.n_rows, self.spec.n_channels))
         s = _batch_struct(batch)

@@ -66,6 +66,7 @@ SYMBOLS = [
     ("v2x_mlp_fwd", C.c_int, [_P, _I, _P, _P, _P, _P, _P]),
     ("v2x_mlp_huber_bwd", C.c_int, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     ("v2x_adam_step", C.c_int, [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _P]),
+    ("v2x_device_addressable", C.c_int, [_P]),
     ("v2x_gather_rows", C.c_int, [_P, _P, _P, _L, _L, _P]),
     ("v2x_dqn_targets", C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("v2x_dqn_step", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_int32, _P, _P, C.c_int, _P]),

@@ -422,6 +422,8 @@ class Agent(object):
                 "xe_pin": torch.empty((E * n, 16), dtype=torch.float32).pin_memory(), "col_pin": torch.empty(E * ne, dtype=torch.int32).pin_memory(),
                 "q_pin": torch.empty((E * n, C), dtype=torch.float32).pin_memory(),
                 "q_dev": torch.empty((E * n, C), dtype=torch.float32, device=dev)}
+            if io["zero_copy"] and any(engine._lib.v2x_device_addressable(io[k_].data_ptr()) != 1 for k_ in ("xe_pin", "col_pin")):
+                io["zero_copy"] = False                        # no unified addressing here: the copy path
             if io["zero_copy"]:
                 # the batch descriptor points INTO the pinned buffers: the predict's kernels read the 136 KB of observations over
                 # the bus themselves, the library copies Q back and synchronises -- no copy launches of ours, one call

@@ -430,6 +430,7 @@ class BatchedEnviron(object):
 
     def next_packed_observation(self, n_channels=4):
         """observe_packed()[0] of the state AFTER the pending step, without applying it when the look-ahead has it ready"""
+        self._foreign_job()
         job = self._ahead
         if self._step_pending and job is not None and job.get("done") and n_channels == self.n_RB:
             return job["out"]["xe"]
@@ -437,6 +438,7 @@ class BatchedEnviron(object):
         return self.observe_packed(n_channels)[0]
 
     def _rates(self, actions):
+        self._foreign_job()
         if self._ahead is not None and not self._ahead.get("done"):
             native_sim.advance_wait(self._ahead["ticket"])     # (the pool is the library's only one: free it for the rates)
             self._ahead["done"] = True
@@ -485,6 +487,7 @@ class BatchedEnviron(object):
             setattr(a, k, v.ctypes.data)
         job = {"out": out, "ins": ins, "args": a}            # (the arrays the library reads and writes stay alive with the job)
         if ahead:
+            job["pid"] = os.getpid()                           # (a forked child has the job dict but not the threads working on it)
             job["ticket"] = native_sim.advance_start(a)
             return job if job["ticket"] else None
         native_sim.advance(a)
@@ -501,11 +504,22 @@ class BatchedEnviron(object):
         if self._step_pending:                                 # ... but a pending step is applied first: its draws come before
             self.finish_step(start_next=False)                 # whatever the caller is about to do with the streams
         if self._ahead is not None:
-            if not self._ahead.get("done"):
+            if not self._ahead.get("done") and not self._foreign_job():
                 native_sim.advance_wait(self._ahead["ticket"])
             self._ahead = None
 
+    def _foreign_job(self):
+        """The look-ahead job was started by ANOTHER process (this one is a fork taken while it was in flight): the pool threads
+        that were writing its arrays do not exist here and the library's bookkeeping was reset (pool_after_fork), so waiting
+        returns at once on half-written outputs.  Its inputs were never touched: drop it, the step is recomputed synchronously."""
+        job = self._ahead
+        if job is not None and job.get("pid", os.getpid()) != os.getpid():
+            self._ahead = None
+            return True
+        return False
+
     def _advance(self, start_next=True):
+        self._foreign_job()
         job = self._ahead
         if job is not None:
             if not job.get("done"):

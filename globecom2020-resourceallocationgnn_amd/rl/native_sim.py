@@ -253,14 +253,27 @@ class ChoiceAhead(object):
     """np_choice_noreplace(n, k) running on a helper thread (the library call releases the GIL): started right after the caller's
     last draw from np.random, finished -- result(): the indices, and np.random moved on past the draws -- before its next one.
     Between the two the process-wide generator must not be used; the caller (Agent._packed_iteration inside Agent.train) knows
-    that nothing draws there."""
+    that nothing draws there -- and result() CHECKS it: the generator's state (position, a CRC of the key, the cached gauss
+    value) is compared with the snapshot the helper started from.  If anything drew from np.random in between (a callback, a
+    logging hook, a later edit of the rollout), the helper's work is thrown away and the draw is redone synchronously from the
+    CURRENT state -- exactly what the reference's `np.random.choice` at this point would have drawn (BS_brain.py:258-270);
+    with V2X_RL_STRICT_RNG=1 (the tests) it raises instead.  `fallbacks` counts the redone draws of the process."""
     _pool = None
+    fallbacks = 0
+
+    @staticmethod
+    def _fingerprint(state):
+        import zlib
+        name, key, pos, has_gauss, cached = state
+        return (name, int(pos), zlib.crc32(np.ascontiguousarray(key, np.uint32).tobytes()), int(has_gauss), float(cached))
 
     def __init__(self, n, k):
         lib = _load()
-        name, key, pos, has_gauss, cached = np.random.get_state()
+        name, key, pos, has_gauss, cached = state = np.random.get_state()
         if name != 'MT19937':
             raise RuntimeError("np.random is not on MT19937")
+        self._snapshot = self._fingerprint(state)
+        self._n, self._k = int(n), int(k)
         self._rest = (name, has_gauss, cached)
         self._key = np.ascontiguousarray(key, np.uint32).copy()
         self._pos = np.array([pos], np.int32)
@@ -277,6 +290,12 @@ class ChoiceAhead(object):
     def result(self):
         if self._fut.result() != 0:
             raise ValueError("np_choice_noreplace: need 1 <= k <= n < 2**31")
+        if self._fingerprint(np.random.get_state()) != self._snapshot:
+            if os.environ.get("V2X_RL_STRICT_RNG") == "1":
+                raise RuntimeError("np.random was used between ChoiceAhead's start and result(): the helper's draws would be "
+                                   "replayed over them")
+            ChoiceAhead.fallbacks += 1
+            return np_choice_noreplace(self._n, self._k)
         name, has_gauss, cached = self._rest
         np.random.set_state((name, self._key, int(self._pos[0]), has_gauss, cached))
         return self._out

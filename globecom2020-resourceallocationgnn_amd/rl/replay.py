@@ -16,6 +16,7 @@ contains one is expanded from the masks instead (torch ops, variable edge count)
 the next sample (the reference stores 50 transitions between replays, BS_brain.py:758).
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -236,8 +237,16 @@ class DeviceReplay(object):
         device addresses directly (unified addressing) -- 16 KB read over the bus by the kernels themselves instead of a copy
         launch of ours.  The buffer's event (recorded by sample() behind its last gather) guards the reuse."""
         torch, k = self.torch, len(slots)
-        ring = self._idx_ring.setdefault(k, {"pin": [torch.empty(k, dtype=torch.int32).pin_memory() for _ in range(4)],
-                                             "ev": [None] * 4, "next": 0})
+        ring = self._idx_ring.get(k)
+        if ring is None:
+            ring = self._idx_ring[k] = {"pin": [torch.empty(k, dtype=torch.int32).pin_memory() for _ in range(4)],
+                                        "ev": [None] * 4, "next": 0, "dev": None}
+            # zero copy needs the pinned buffers mapped at their own address (checked, not assumed); V2X_RL_ZERO_COPY=0, or a
+            # platform without unified addressing: a copy launch into a device buffer of the same ring instead
+            zero_copy = os.environ.get("V2X_RL_ZERO_COPY", "1") != "0" and all(
+                self._lib.v2x_device_addressable(t.data_ptr()) == 1 for t in ring["pin"])
+            if not zero_copy:
+                ring["dev"] = [torch.empty(k, dtype=torch.int32, device=self.device) for _ in range(4)]
         i = ring["next"]
         ring["next"] = (i + 1) % 4
         if ring["ev"][i] is not None:
@@ -245,6 +254,9 @@ class DeviceReplay(object):
             ring["ev"][i] = None
         ring["pin"][i].numpy()[:] = slots
         self._idx_in_use = (ring, i)
+        if ring["dev"] is not None:
+            ring["dev"][i].copy_(ring["pin"][i], non_blocking=True)
+            return ring["dev"][i]
         return ring["pin"][i]
 
     def _indices_consumed(self):

@@ -183,6 +183,11 @@ int  v2x_adam_step(float* param, const float* grad, float* mom, float* vel, int6
  * Counterparts of the minibatch assembly (BS_brain.py:573-640: per-sample Python loops filling the
  * 13 input arrays) and of the target rule (BS_brain.py:670-692) of Agent.replay, for transitions
  * that stay resident in HBM.  All pointers [dev].                                              */
+/* 1 when the device can dereference p as it stands: device or managed memory, or page-locked host memory that is mapped
+ * at the SAME address (hipHostMalloc defaults under unified addressing: what the zero-copy predict and the replay's index
+ * ring hand to kernels, rl/agent.py, rl/replay.py); 0 for pageable host memory or a mapping at another address; a negative
+ * V2X_E* code when the runtime cannot say.  Callers check once per buffer, before they set on_device = 1 on host arrays.    */
+int  v2x_device_addressable(const void* p);
 /* dst[i][0..row_bytes) = src[idx[i]][0..row_bytes)   (row_bytes a multiple of 4)               */
 int  v2x_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_idx, int64_t row_bytes,
                      void* stream);

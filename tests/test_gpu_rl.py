@@ -379,3 +379,46 @@ def test_forward_to_host_from_pinned_memory_equals_forward(B):
     with pytest.raises(ValueError):
         eng.forward_to_host(pb, q)
     eng.close()
+
+
+def test_native_sampler_is_this_box_numpys_choice():
+    """libv2xsim's restatement of np.random.choice(n, k, replace=False) follows a numpy-version-specific
+    legacy algorithm; the draw-for-draw comparison is a CPU test that would otherwise only ever see the build container's numpy.
+    The same comparison against the numpy of the GPU box, plus the look-ahead form and its guard."""
+    import test_rl_agent as t
+    t.test_native_sampler_is_numpys_choice_without_replacement()
+    from v2xgnn.rl import native_sim
+    np.random.seed(123)
+    want, after = np.random.choice(70000, 4096, replace=False), np.random.random(2)
+    np.random.seed(123)
+    ca = native_sim.ChoiceAhead(70000, 4096)
+    assert np.array_equal(ca.result(), want) and np.array_equal(np.random.random(2), after)
+
+
+def test_forward_to_host_refuses_pageable_host_memory():
+    """forward_to_host hands host pointers to kernels (on_device = 1); a batch of pageable CPU tensors must be a
+    ValueError, not a GPU page fault.  Pinned tensors pass (v2x_device_addressable checks the mapping address)."""
+    import torch
+    import v2xgnn
+    from v2xgnn import GnnSpec, GnnEngine
+    from v2xgnn.engine import DeviceBatch
+    spec = GnnSpec(n_nodes=4, feat_dim=16, n_mp_layers=2)
+    eng = GnnEngine(spec)
+    rng = np.random.default_rng(3)
+    eng.set_weights([rng.normal(0, 0.2, size=s).astype(np.float32) for s in v2xgnn.keras_list_shapes(spec)])
+    B, n = 3, 4
+    xe = torch.from_numpy(rng.normal(0.8, 0.3, size=(B * n, 16)).astype(np.float32))
+    xe[:, 13:] = 0
+    rp = torch.arange(B * n + 1, dtype=torch.int32) * 2
+    col = torch.tensor([[(q + 1) % n, (q + 2) % n] for q in range(n)] * B, dtype=torch.int32).sort(dim=1).values.reshape(-1).contiguous()
+    q = np.empty((B * n, 4), np.float32)
+    lib = eng._lib
+    assert lib.v2x_device_addressable(xe.data_ptr()) == 0
+    with pytest.raises(ValueError, match="cannot address"):
+        eng.forward_to_host(DeviceBatch.from_tensors(B, n, xe, rp.cuda(), col.cuda(), 2 * n), q)
+    pinned = [t.pin_memory() for t in (xe, rp, col)]
+    assert all(lib.v2x_device_addressable(t.data_ptr()) == 1 for t in pinned)
+    got = eng.forward_to_host(DeviceBatch.from_tensors(B, n, pinned[0], pinned[1], pinned[2], 2 * n), q).copy()
+    want = eng.forward(DeviceBatch.from_tensors(B, n, xe.cuda(), rp.cuda(), col.cuda(), 2 * n)).cpu().numpy()
+    assert np.array_equal(got, want)
+    eng.close()

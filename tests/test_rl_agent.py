@@ -6,6 +6,7 @@ import random
 import types
 
 import numpy as np
+import pytest
 
 from v2xgnn.rl import Agent, Memory, RL_Config
 from test_rl_env import make_env
@@ -271,3 +272,37 @@ def test_native_sampler_is_numpys_choice_without_replacement():
     want, want2 = np.random.choice(50000, 4096, replace=False), np.random.choice(70000, 4096, replace=False)
     np.random.seed(5)
     assert np.array_equal(mem.sample_indices(4096), want) and np.array_equal(mem.sample_indices(4096, 70000), want2)
+
+
+def test_choice_ahead_notices_a_draw_in_its_window(monkeypatch):
+    """ChoiceAhead borrows np.random's state between its start and result().  A draw from the process-wide
+    generator in between must not be rolled back: result() redoes the draw from the CURRENT state (what the reference's
+    np.random.choice at that point would draw), or raises under V2X_RL_STRICT_RNG=1.  Untouched state: the helper's result."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    n, k = 30000, 512
+    np.random.seed(77)
+    want = np.random.choice(n, k, replace=False)
+    after = np.random.random(3)
+    np.random.seed(77)
+    ca = native_sim.ChoiceAhead(n, k)
+    assert np.array_equal(ca.result(), want) and np.array_equal(np.random.random(3), after)
+    # a draw inside the window
+    np.random.seed(77)
+    stray_want = np.random.random(2)
+    want2 = np.random.choice(n, k, replace=False)
+    after2 = np.random.random(3)
+    np.random.seed(77)
+    n_fb = native_sim.ChoiceAhead.fallbacks
+    ca = native_sim.ChoiceAhead(n, k)
+    stray = np.random.random(2)
+    got = ca.result()
+    assert np.array_equal(stray, stray_want) and np.array_equal(got, want2) and np.array_equal(np.random.random(3), after2)
+    assert native_sim.ChoiceAhead.fallbacks == n_fb + 1
+    monkeypatch.setenv("V2X_RL_STRICT_RNG", "1")
+    np.random.seed(77)
+    ca = native_sim.ChoiceAhead(n, k)
+    np.random.normal()                                            # (leaves a cached gauss value: position may be unchanged on a refill boundary)
+    with pytest.raises(RuntimeError, match="np.random was used"):
+        ca.result()

@@ -491,3 +491,74 @@ def test_pool_survives_a_fork():
     os.close(r)
     _, status = os.waitpid(pid, 0)
     assert status == 0 and got == want
+
+
+def test_fork_with_a_lookahead_in_flight_is_recomputed_in_the_child():
+    """a child forked while a look-ahead job is in flight inherits the job dict but not the threads that were
+    writing its arrays; it must not commit them.  The child here does NOTHING to protect itself (keeps _ahead, keeps
+    look-ahead on): the pid recorded in the job makes _advance drop it and recompute -- the parent's trajectory."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available() or not hasattr(os, "fork"):
+        pytest.skip("libv2xsim.so not built / no fork")
+    E, n = 6, 8
+    env = BatchedEnviron(*_lanes(), 750, 1299, n_envs=E, seeds=[5 + 13 * e for e in range(E)], lookahead=True)
+    env.new_random_game(n)
+    act = np.zeros((E, n, 1), int)
+    env.act(act)
+    assert env._ahead is not None and env._ahead["pid"] == os.getpid()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            for _ in range(3):
+                env.act(act)
+            os.write(w, env.pos.tobytes() + env._mt_pos.tobytes() + env.V2V_channels_with_fastfading.tobytes())
+        finally:
+            os._exit(0)
+    os.close(w)
+    for _ in range(3):
+        env.act(act)
+    want = env.pos.tobytes() + env._mt_pos.tobytes() + env.V2V_channels_with_fastfading.tobytes()
+    got = b""
+    while len(got) < len(want):
+        chunk = os.read(r, len(want) - len(got))
+        if not chunk:
+            break
+        got += chunk
+    os.close(r)
+    _, status = os.waitpid(pid, 0)
+    assert status == 0 and got == want
+
+
+def test_two_host_threads_stepping_two_simulators():
+    """ctypes releases the GIL, so two Python threads can be inside the library's loops at once; its pool has ONE job
+    slot.  The second caller must run its loop alone instead of posting over the first one's job (which stranded
+    environments of the first job: silently wrong arrays).  Two simulators stepped concurrently == stepped one after the other."""
+    import threading
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    E, n, steps = 24, 12, 12
+    native_sim.set_threads(4)
+
+    def run(seed0, out, concurrent_with=None):
+        env = BatchedEnviron(*_lanes(), 750, 1299, n_envs=E, seeds=[seed0 + 7 * e for e in range(E)], lookahead=False)
+        env.new_random_game(n)
+        act = np.zeros((E, n, 1), int)
+        if concurrent_with is not None:
+            concurrent_with.wait()
+        for _ in range(steps):
+            env.act(act)
+        out.append((env.pos.copy(), env._mt_pos.copy(), env.V2V_channels_with_fastfading.copy(), env.V2V_Interference_all.copy()))
+    seq = {s: [] for s in (3, 1000)}
+    for s in seq:
+        run(s, seq[s])
+    for rep in range(3):
+        par = {s: [] for s in seq}
+        bar = threading.Barrier(2)
+        ths = [threading.Thread(target=run, args=(s, par[s], bar)) for s in seq]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        for s in seq:
+            for a, b in zip(seq[s][0], par[s][0]):
+                assert np.array_equal(a, b), (rep, s)

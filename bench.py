@@ -82,6 +82,9 @@ def algorithmic_flops(name, R, F, L, C=4, Dn=9, De=4):
     table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"]
     table["k_mlp_train_wg"] = table["k_mlp_train"] + table["k_wgrad_dense"]   # + the four Dense weight gradients, same launch
     table["k_wgrad_all"] = table["k_wgrad_gnn"] + table["k_wgrad_dense"]
+    # small batches: Dense-0's weight gradient is a role of the graph layers' launch instead of the MLP launch's (csrc/v2xgnn.hip, dense0_rides)
+    table["k_mlp_train_wg123"] = table["k_mlp_train_wg"] - dense0
+    table["k_wgrad_gnn_d0"] = table["k_wgrad_gnn"] + dense0
     table["k_gnn_fwd_fused"] = embed + L * gnn                        # embed + L stages (graph-major fused launch)
     table["k_gnn_bwd_fused"] = L * table["k_node_dgrad"]              # L data gradients
     table["k_gnn_fwd_ragged"] = table["k_gnn_fwd_fused"]              # the same layers for variable-size graphs (kernels_ragged.hpp)
@@ -124,6 +127,8 @@ def algorithmic_bytes(name, B, N, F, E, L=2, C=4, Dn=9, De=4):
     table["k_gnn_bwd_ragged"] = 4 * R * 2 * F + L * 4 * R * F + 16 * R + (L + 1) * 4 * R * F
     table["k_mlp_train"] = table["k_mlp_fwd"] + table["k_mlp_bwd"] - 4 * R * C  # fwd + Huber + bwd fused: q is not re-read
     table["k_mlp_train_wg"] = table["k_mlp_train"]    # weight gradients from the values on chip: no further node-row bytes
+    table["k_mlp_train_wg123"] = table["k_mlp_train"] + 4 * R * 80                       # + the dz1 rows for the Dense-0 role
+    table["k_wgrad_gnn_d0"] = table["k_wgrad_gnn"] + 4 * R * (Dn + 2 * F + 80)
     table["k_adj_masks"] = csr + 2 * 4 * R * ((min(max(N, 1), 128) + 31) // 32)   # CSR in, bit masks by source and by destination out
     #                       (ragged batches are modelled as ONE graph of R rows: their masks are 4 words, graphs of <= 128 links)
     if F >= 128:        # wide-feature path (csrc/kernels_wide.hpp): Dense-0 and its gradients are launches of their own,

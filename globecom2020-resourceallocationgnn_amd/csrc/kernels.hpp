@@ -1068,6 +1068,12 @@ struct WgradArgs {
   // xe^T . dpre_0[:, those columns], written to the embed layer's block of the same slab (its neighbour-init rows: zeros)
   const float* e_dpre; int e_stride, e_col0, e_n_real;
   int64_t e_layer_off, e_slot_stride; RowPad e_pad;
+  // wgrad_body FRAGK: the K0 and K2 segments are FRAGMENT-major (MlpArgs::frag_groups: h_L and a_L as the fused graph-layer
+  // kernels leave them for k_mlp_train_wg), this many 16-row groups per slot
+  int frag_groups;
+  // a role that covers only PART of the layer's K rows (Dense-0 cut in two, WG_KIND_DENSE0A / B): padded K row of its first
+  // segment; the bias gradient is written by the role with bias_too set
+  int k_off, no_bias;
 };
 
 constexpr int WG_TR = 16;        // rows per MFMA block (chunk sizes are multiples of it)
@@ -1120,6 +1126,20 @@ __device__ __forceinline__ void wg_load(WgOperand<W>& o, const WgSrc& src, unsig
   }
 }
 
+// The same operand from a FRAGMENT-major source (MlpArgs::frag_groups): per (slot, 16-row group) W/16 blocks of 256 floats,
+// block b = features 16b .. 16b+15, element (row r, feature f) at ((f & 15) >> 2) * 64 + r * 4 + (f & 3).  With the labelling
+// feature = 64 g + 4 j + t the four tiles t of lane index j are one float4 again: block 4 g + (j >> 2), row group j & 3.
+// tile: element offset of the (slot, group) tile; r: the lane's row inside the tile at this k-step (4 kg + s).
+template <int W>
+__device__ __forceinline__ void wg_load_frag(WgOperand<W>& o, gfloat_p p, unsigned tile, int r, int s, int j) {
+  static_assert(W % 64 == 0, "fragment-major operands are whole 64-feature groups");
+#pragma unroll
+  for (int g = 0; g < WgOperand<W>::G; ++g) {
+    typedef const __attribute__((address_space(1))) f32x4* gvec_p;
+    o.g[g][s] = *(gvec_p)(p + tile + (4 * g + (j >> 2)) * 256 + ((j & 3) * 16 + r) * 4);
+  }
+}
+
 // K operands K0|K1|K2 (compile-time padded widths, 0 = absent), N operand NW.  Every wave owns ALL output tiles for
 // ITS OWN 16-row blocks (blocks wv, wv+4, ... of the chunk): each element is loaded from HBM exactly once, 4*KT*NT
 // MFMAs per block (4.6k cycles for a GNN stage) run while the next block's loads are in flight (register double
@@ -1132,7 +1152,9 @@ __device__ __forceinline__ void wg_load(WgOperand<W>& o, const WgSrc& src, unsig
 // multiplied for its tiles, their gradient rows are written as exact zeros.
 // EN > 0: this role also produces EN output tiles of the EMBED layer's gradient (K1 must be the [x|e] tile): the light
 // embed role (16 MFMAs per block, load-bound) otherwise needs workgroups of its own, which queue behind the heavy ones.
-template <int K0, int K1, int K2, int NW, int DEPTH = 2, bool ZERO1 = false, int EN = 0>
+// FRAGK: K0 and K2 come from fragment-major buffers (Dense-0's h_L / a_L behind the fused graph-layer kernels: the role the
+// decision-MLP launch hands to this one at small batches, kernels_mlpwg.hpp WG0 = false); whole 16-row groups only.
+template <int K0, int K1, int K2, int NW, int DEPTH = 2, bool ZERO1 = false, int EN = 0, bool FRAGK = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, const int bx, const int slot) {
   constexpr int T0 = K0 / 16, T1 = K1 / 16, T2 = K2 / 16, KT = T0 + T1 + T2, NT = NW / 16;
   constexpr int EW = 16 * EN, ENA = EN > 0 ? EN : 1;
@@ -1142,7 +1164,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
   const int j = lane & 15, kg = lane >> 4;
   const int i_begin = bx * a.chunk, i_end = min(i_begin + a.chunk, a.n_idx);
-  long long* tsp = (a.ts && bx == 1 && slot == 0 && blockIdx.z == 0 && lane == 0) ? a.ts + wv * 64 : nullptr;
+  long long* tsp = (a.ts && bx == 1 && slot == 0 && lane == 0) ? a.ts + wv * 64 : nullptr;      // (ts: one role of the launch only)
   int tsn = 0;
   auto mark = [&]() {
     if (tsp && tsn < 64) tsp[tsn] = tsn == 0 ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter();
@@ -1213,13 +1235,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   const int n_rows_here = max(i_end - i_begin, 0);
   const int n_full = n_rows_here / WG_TR;
   const unsigned idx_lane0 = (unsigned)(a.idx_base + i_begin + 4 * kg);
+  const unsigned ftile0 = (unsigned)slot * (unsigned)a.frag_groups + (unsigned)((a.idx_base + i_begin) >> 4);   // FRAGK
   auto load_full = [&](int blk, Block& b) {                      // full block: no clamps on rows, no masks
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const unsigned idx = idx_lane0 + (unsigned)(blk * WG_TR + s);
-      wg_load<K0>(b.k0, src[0], idx * src[0].rs + src[0].off, s, j, 1.f);
+      if constexpr (FRAGK) wg_load_frag<K0>(b.k0, src[0].p, (ftile0 + (unsigned)blk) * (unsigned)(K0 * 16), 4 * kg + s, s, j);
+      else wg_load<K0>(b.k0, src[0], idx * src[0].rs + src[0].off, s, j, 1.f);
       wg_load<K1L>(b.k1, src[1], idx * src[1].rs + src[1].off, s, j, 1.f);
-      wg_load<K2>(b.k2, src[2], idx * src[2].rs + src[2].off, s, j, 1.f);
+      if constexpr (FRAGK) wg_load_frag<K2>(b.k2, src[2].p, (ftile0 + (unsigned)blk) * (unsigned)(K2 * 16), 4 * kg + s, s, j);
+      else wg_load<K2>(b.k2, src[2], idx * src[2].rs + src[2].off, s, j, 1.f);
       wg_load<NW>(b.n, srcn, idx * srcn.rs + srcn.off, s, j, 1.f);
       wg_load<EW>(b.e, srce, idx * srce.rs + srce.off, s, j, 1.f);
     }
@@ -1379,9 +1404,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
   //      => float4 stores.
   float* dst = a.slab + (int64_t)(a.chunk_base + bx) * a.slab_stride + a.layer_off + slot * a.slot_stride;
   auto krow = [&](int kt, int i) -> int {
-    if (kt < T0) return WgOperand<K0>::feature(kt, i);
-    if (kt < T0 + T1) return K0 + WgOperand<K1>::feature(kt - T0, i);
-    return K0 + K1 + WgOperand<K2>::feature(kt - T0 - T1, i);
+    if (kt < T0) return a.k_off + WgOperand<K0>::feature(kt, i);
+    if (kt < T0 + T1) return a.k_off + K0 + WgOperand<K1>::feature(kt - T0, i);
+    return a.k_off + K0 + K1 + WgOperand<K2>::feature(kt - T0 - T1, i);
   };
   constexpr int NG = WgOperand<NW>::G, NR = WgOperand<NW>::R;
   constexpr int UNITS = KT * (NG + NR);                          // (k tile, n group | n dword tile)
@@ -1405,7 +1430,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, float* smem, cons
       }
     }
   }
-  if (tid < NT * 16) {
+  if (tid < NT * 16 && !a.no_bias) {
     const int nt = tid >> 4, jj = tid & 15, col = WgOperand<NW>::feature(nt, jj);
     if (col < a.n_real)
       dst[(int64_t)a.pad.k_real * a.n_real + col] =
@@ -1450,39 +1475,72 @@ constexpr int WG_MAX_ROLES = 8;
 #ifndef V2X_WG_DEPTH_MERGED
 #define V2X_WG_DEPTH_MERGED 2
 #endif
-struct WgradMulti { WgradArgs w[WG_MAX_ROLES]; };
+#ifndef V2X_WG_DEPTH_D0
+#define V2X_WG_DEPTH_D0 4
+#endif
+// packed: roles with DIFFERENT chunk counts in one grid.  A (chunks, slots, roles) grid sized for the largest count would launch
+// workgroups that exit at once for the others, and workgroups go to the XCDs round-robin by linear id: with 4 chunks for the
+// graph layers and 2 for the Dense-0 halves every real workgroup of the halves landed on XCDs 0, 1, 4, 5 -- 40 workgroups on 32
+// CUs there, a second round, 30 us instead of 20 (round 6, profiles/r06_wgrad_roles_b512.txt).  Packed: a 1-D grid of exactly the
+// real workgroups, role r owning ids [wg_begin[r], wg_begin[r + 1]), chunk fastest inside it.
+struct WgradMulti { WgradArgs w[WG_MAX_ROLES]; int wg_begin[WG_MAX_ROLES + 1]; int packed; };
 enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 3, WG_KIND_DENSE2 = 4, WG_KIND_DENSE3 = 5,
-       WG_KIND_EMBED_NONBR = 6, WG_KIND_GNN_E1 = 7, WG_KIND_GNN_E2 = 8, WG_KIND_GNN_E4 = 9 };   // _En: + n tiles of the embed gradient
+       WG_KIND_EMBED_NONBR = 6, WG_KIND_GNN_E1 = 7, WG_KIND_GNN_E2 = 8, WG_KIND_GNN_E4 = 9,      // _En: + n tiles of the embed gradient
+       // Dense-0 cut along K into [h | x] and [agg] (25 + 20 accumulator tiles instead of 45: the whole layer in one role spills),
+       // _F: h_L / a_L fragment-major
+       WG_KIND_DENSE0A = 10, WG_KIND_DENSE0A_F = 11, WG_KIND_DENSE0B = 12, WG_KIND_DENSE0B_F = 13 };
 
-// MODE 0: the GNN stages, 1: the Dense layers, 2: both families in one launch (roles ordered heaviest first)
+// MODE 0: the GNN stages, 1: the Dense layers, 2: both families in one launch (roles ordered heaviest first),
+// 3: the GNN stages + Dense-0 in two halves (small batches: kernels_mlpwg.hpp WG0 = false leaves dz1 for it)
 template <int F, int MODE>
 __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   typedef const __attribute__((address_space(4))) unsigned* CWords;
   static_assert(sizeof(WgradArgs) % 4 == 0, "WgradArgs must be dword sized");
   constexpr int NW = sizeof(WgradArgs) / 4;
-  CWords srcw = (CWords)__builtin_amdgcn_kernarg_segment_ptr() + blockIdx.z * NW;
+  CWords kw = (CWords)__builtin_amdgcn_kernarg_segment_ptr();
+  int role = blockIdx.z, bx_ = blockIdx.x, slot_ = blockIdx.y;
+  static_assert(offsetof(WgradMulti, wg_begin) == WG_MAX_ROLES * sizeof(WgradArgs), "wg_begin follows the roles");
+  if (kw[WG_MAX_ROLES * NW + WG_MAX_ROLES + 1]) {                // packed (workgroup-uniform)
+    const int id = blockIdx.x;
+    role = 0;
+#pragma unroll
+    for (int r = 1; r < WG_MAX_ROLES; ++r) role += id >= (int)kw[WG_MAX_ROLES * NW + r] ? 1 : 0;   // (unused roles: begin = grid size)
+    bx_ = id - (int)kw[WG_MAX_ROLES * NW + role];
+  }
+  CWords srcw = kw + role * NW;
   WgradArgs a;
   unsigned* dstw = reinterpret_cast<unsigned*>(&a);
 #pragma unroll
   for (int i = 0; i < NW; ++i) dstw[i] = srcw[i];
+  if (kw[WG_MAX_ROLES * NW + WG_MAX_ROLES + 1]) { slot_ = bx_ / a.n_chunks; bx_ -= slot_ * a.n_chunks; }
   if constexpr (MODE != 1) {
-    if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN>(a, smem, blockIdx.x, blockIdx.y); return; }
-    if (a.kind == WG_KIND_GNN_E1) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 1>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_GNN) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_GNN>(a, smem, bx_, slot_); return; }
+    if (a.kind == WG_KIND_GNN_E1) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 1>(a, smem, bx_, slot_); return; }
     if constexpr (F >= 32) {
-      if (a.kind == WG_KIND_GNN_E2) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 2>(a, smem, blockIdx.x, blockIdx.y); return; }
+      if (a.kind == WG_KIND_GNN_E2) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 2>(a, smem, bx_, slot_); return; }
     }
     if constexpr (F >= 64) {
-      if (a.kind == WG_KIND_GNN_E4) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 4>(a, smem, blockIdx.x, blockIdx.y); return; }
+      if (a.kind == WG_KIND_GNN_E4) { wgrad_body<F, XE, F, F, V2X_WG_DEPTH_MERGED, false, 4>(a, smem, bx_, slot_); return; }
     }
-    if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F, 3>(a, smem, blockIdx.x, blockIdx.y); return; }
-    if (a.kind == WG_KIND_EMBED_NONBR) { wgrad_body<XE, F, 0, F, 3, true>(a, smem, blockIdx.x, blockIdx.y); return; }
+    if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F, 3>(a, smem, bx_, slot_); return; }
+    if (a.kind == WG_KIND_EMBED_NONBR) { wgrad_body<XE, F, 0, F, 3, true>(a, smem, bx_, slot_); return; }
   }
-  if constexpr (MODE != 0) {
-    if (a.kind == WG_KIND_DENSE0) wgrad_body<F, XE, F, H1>(a, smem, blockIdx.x, blockIdx.y);
-    else if (a.kind == WG_KIND_DENSE1) wgrad_body<H1, 0, 0, H2P>(a, smem, blockIdx.x, blockIdx.y);
-    else if (a.kind == WG_KIND_DENSE2) wgrad_body<H2P, 0, 0, H3P>(a, smem, blockIdx.x, blockIdx.y);
-    else if (a.kind == WG_KIND_DENSE3) wgrad_body<H3P, 0, 0, CP>(a, smem, blockIdx.x, blockIdx.y);
+  if constexpr (MODE == 3) {
+    // (a half's block is 100 / 80 MFMAs, 1.2-1.4 us: with one block of loads in flight -- DEPTH 2 -- a wave waits 3.6 us per
+    //  block for memory, measured at the 512- / 1024-graph shares; three in flight next to 100 accumulators still fit)
+    if (a.kind == WG_KIND_DENSE0A) wgrad_body<F, XE, 0, H1, V2X_WG_DEPTH_D0>(a, smem, bx_, slot_);
+    else if (a.kind == WG_KIND_DENSE0B) wgrad_body<F, 0, 0, H1, V2X_WG_DEPTH_D0>(a, smem, bx_, slot_);
+    if constexpr (F == 64) {
+      if (a.kind == WG_KIND_DENSE0A_F) wgrad_body<F, XE, 0, H1, V2X_WG_DEPTH_D0, false, 0, true>(a, smem, bx_, slot_);
+      else if (a.kind == WG_KIND_DENSE0B_F) wgrad_body<F, 0, 0, H1, V2X_WG_DEPTH_D0, false, 0, true>(a, smem, bx_, slot_);
+    }
+  }
+  if constexpr (MODE == 1 || MODE == 2) {
+    if (a.kind == WG_KIND_DENSE0) wgrad_body<F, XE, F, H1>(a, smem, bx_, slot_);
+    else if (a.kind == WG_KIND_DENSE1) wgrad_body<H1, 0, 0, H2P>(a, smem, bx_, slot_);
+    else if (a.kind == WG_KIND_DENSE2) wgrad_body<H2P, 0, 0, H3P>(a, smem, bx_, slot_);
+    else if (a.kind == WG_KIND_DENSE3) wgrad_body<H3P, 0, 0, CP>(a, smem, bx_, slot_);
   }
 }
 
@@ -1702,6 +1760,52 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint32_t* src, const 
     if (VEC == 4) *reinterpret_cast<uint4*>(dst + r * words + c) = *reinterpret_cast<const uint4*>(src + s);
     else dst[r * words + c] = src[s];
   }
+}
+
+// Several gathers by the SAME index list in one launch (the replay minibatch: s, s', action, reward, CSR sources --
+// Agent.replay's per-sample loops, BS_brain.py:573-640): blockIdx.y selects the job.
+constexpr int GATHER_MAX_JOBS = 8;
+struct GatherJobs { const uint32_t* src[GATHER_MAX_JOBS]; uint32_t* dst[GATHER_MAX_JOBS]; int64_t words[GATHER_MAX_JOBS]; int vec[GATHER_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void k_gather_rows_multi(GatherJobs jobs, const int32_t* idx, int64_t n_idx) {
+  typedef const __attribute__((address_space(4))) uint64_t* CQ;
+  CQ kq = (CQ)__builtin_amdgcn_kernarg_segment_ptr();            // (runtime-indexed kernarg arrays would be copied to scratch)
+  const int jb = blockIdx.y;
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(kq[offsetof(GatherJobs, src) / 8 + jb]);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(kq[offsetof(GatherJobs, dst) / 8 + jb]);
+  const int64_t words = (int64_t)kq[offsetof(GatherJobs, words) / 8 + jb];
+  const int vec = ((const __attribute__((address_space(4))) int*)kq)[offsetof(GatherJobs, vec) / 4 + jb];
+  const int64_t per_row = vec ? words / 4 : words;
+  const int64_t total = n_idx * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per_row, c = (i - r * per_row) * (vec ? 4 : 1);
+    const int64_t s = (int64_t)idx[r] * words + c;
+    if (vec) *reinterpret_cast<uint4*>(dst + r * words + c) = *reinterpret_cast<const uint4*>(src + s);
+    else dst[r * words + c] = src[s];
+  }
+}
+
+// Q statistics of a minibatch of fitted targets y[B][N][C] (BS_brain.py:743-746: per link the mean of all entries and the mean of
+// the per-sample maxima), as float64 SUMS per link: out[0][k] = sum_b sum_c y, out[1][k] = sum_b max_c y.  One workgroup per link,
+// every thread a fixed subset of the samples, the partials combined through LDS in a fixed order: deterministic.
+__global__ __launch_bounds__(256) void k_q_stats(const float* y, int B, int N, int C, double* out) {
+  __shared__ double s_all[256], s_max[256];
+  const int k = blockIdx.x;
+  double a = 0.0, m = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* row = y + ((int64_t)b * N + k) * C;
+    float mx = row[0];
+    double s = (double)row[0];
+    for (int c = 1; c < C; ++c) { s += (double)row[c]; mx = fmaxf(mx, row[c]); }
+    a += s;
+    m += (double)mx;
+  }
+  s_all[threadIdx.x] = a; s_max[threadIdx.x] = m;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { s_all[threadIdx.x] += s_all[threadIdx.x + st]; s_max[threadIdx.x] += s_max[threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out[k] = s_all[0]; out[N + k] = s_max[0]; }
 }
 
 // one thread per (graph, node) row

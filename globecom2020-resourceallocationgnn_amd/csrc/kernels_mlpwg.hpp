@@ -202,7 +202,12 @@ __device__ __forceinline__ void wg_write(const float* sA, const float* sB, const
 
 // FRAG: h, agg and gha fragment-major (MlpArgs::frag_groups) -- a compile-time form: with the layout selected at run time
 // the strides are no longer immediates, every access gets its own 64-bit address and the kernel spills (120 us)
-template <int F, bool FRAG = false>
+// WG0 = false (round 6, small batches -- the shares of the metric's global batch): Dense-0's weight gradient is NOT taken here.
+// At <= 2 tiles per wave the launch is one wave's latency chain, and dW0 is 180 of a tile's 796 MFMAs and 45 of the 68
+// accumulator tiles that the end of the kernel exchanges through LDS and writes as slabs; the gated dz1 rows go to HBM instead
+// (MlpArgs::dz1, 320 bytes per node row) and dW0 becomes a role of the graph layers' weight-gradient launch (k_wgrad,
+// WG_KIND_DENSE0_FRAG), which at those sizes leaves a third of the chip idle.
+template <int F, bool FRAG = false, bool WG0 = true>
 __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
   using L = MlpLds<F>;
   using G = MlpWgLds<F>;
@@ -234,10 +239,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
   const int seg_begin = wg_begin, slot = seg_begin / T, tid_l = threadIdx.x;
   const int seg_end = min(wg_end, (slot + 1) * T);
   const int tile0 = slot * T;                         // global number of the slot's first tile
-  f32x4 acc0[KB1][5], acc1[5][3], acc2[3][2], acc3[2][1];
+  f32x4 acc0[WG0 ? KB1 : 1][5], acc1[5][3], acc2[3][2], acc3[2][1];
   float bs0[5], bs1[3], bs2[2], bs3[1];
 #pragma unroll
-  for (int kt = 0; kt < KB1; ++kt)
+  for (int kt = 0; kt < (WG0 ? KB1 : 1); ++kt)
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) acc0[kt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -284,8 +289,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
     float4 t2[2][2], t3[2][3], t5[2][5], t8[2][2 * FB];  // reverse weights of Dense 3..0
     float aT[2][4], b1[1][4], b2[2][4], b3[3][4], b5[5][4];
     // ================= forward (z0 is parked in LDS for Dense-0's weight gradient at the very end)
+    if constexpr (WG0) {
 #pragma unroll
-    for (int b = 0; b < KB1; ++b) st4(sZ0 + b * G::BLK + wofs, in.z0[b]);
+      for (int b = 0; b < KB1; ++b) st4(sZ0 + b * G::BLK + wofs, in.z0[b]);
+    }
     f32x4 z1[5];
 #pragma unroll
     for (int nt = 0; nt < 5; ++nt) z1[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -389,13 +396,22 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
     mark();
     // ---- Dense-0: data gradient to [dh | dagg], then dW0 += z0^T d1
     V2X_WAVE_SYNC();
+    if constexpr (WG0) {
 #pragma unroll
-    for (int b = 0; b < 5; ++b) st4(sN + b * G::BLK + wofs, d1[b]);
+      for (int b = 0; b < 5; ++b) st4(sN + b * G::BLK + wofs, d1[b]);
+    } else {                                             // dz1 rows for the Dense-0 role of the weight-gradient launch
+#pragma unroll
+      for (int b = 0; b < 5; ++b)
+        if (valid) st4(a.dz1 + row * H1 + b * 16 + 4 * kg, d1[b]);
+    }
     V2X_WAVE_SYNC();
     f32x4 o[2 * FB];
 #pragma unroll
     for (int nt = 0; nt < 2 * FB; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    chain_bwd<5, 2 * FB, true, 12>(smem + L::W1, LD1, skip_xe, j, kg, d1, o, t8, [&]() { wg_n_operand<5>(sN, lane, b5); wg_k_operand(sZ0, lane, 0, aT[0]); });
+    if constexpr (WG0)
+      chain_bwd<5, 2 * FB, true, 12>(smem + L::W1, LD1, skip_xe, j, kg, d1, o, t8, [&]() { wg_n_operand<5>(sN, lane, b5); wg_k_operand(sZ0, lane, 0, aT[0]); });
+    else
+      chain_bwd<5, 2 * FB, true, 10>(smem + L::W1, LD1, skip_xe, j, kg, d1, o, t8, [&]() { fwd_weights<5>(smem + L::W1, LD1, j, kg, 0, w5[0]); });
     const int64_t go = FRAG ? ((int64_t)slot * a.frag_groups + min(t, a.frag_groups - 1)) * (2 * FB * 256) + lane * 4 : row * (2 * F) + 4 * kg;
     constexpr int gs = FRAG ? 256 : 16;
 #pragma unroll
@@ -405,7 +421,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
     __builtin_amdgcn_sched_barrier(0);
     load_in(t_next, in);
     __builtin_amdgcn_sched_barrier(0);
-    wg_accum<KB1, 5, true, 10>(sZ0, sN, lane, acc0, bs0, b5, aT, [&]() { fwd_weights<5>(smem + L::W1, LD1, j, kg, 0, w5[0]); });
+    if constexpr (WG0)
+      wg_accum<KB1, 5, true, 10>(sZ0, sN, lane, acc0, bs0, b5, aT, [&]() { fwd_weights<5>(smem + L::W1, LD1, j, kg, 0, w5[0]); });
     V2X_WAVE_SYNC();
     mark();
   };
@@ -443,16 +460,19 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
   if (lane < 16) {
     float* b = sBias4 + wv * G::NBIAS + lane;
 #pragma unroll
-    for (int nt = 0; nt < 5; ++nt) b[nt * 16] = bs0[nt];
+    for (int nt = 0; nt < 5; ++nt) b[nt * 16] = WG0 ? bs0[nt] : 0.f;
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) b[(5 + nt) * 16] = bs1[nt];
     b[8 * 16] = bs2[0]; b[9 * 16] = bs2[1]; b[10 * 16] = bs3[0];
   }
+  constexpr int TB = WG0 ? 0 : G::T1;                   // first tile of the exchange (WG0 = false: Dense 1..3 only, 23 tiles)
   auto each = [&](auto&& fn) {                         // fn(tile registers, tile index): indices are compile-time after unrolling
+    if constexpr (WG0) {
 #pragma unroll
-    for (int kt = 0; kt < KB1; ++kt)
+      for (int kt = 0; kt < KB1; ++kt)
 #pragma unroll
-      for (int nt = 0; nt < 5; ++nt) fn(acc0[kt][nt], G::T0 + kt * 5 + nt);
+        for (int nt = 0; nt < 5; ++nt) fn(acc0[kt][nt], G::T0 + kt * 5 + nt);
+    }
 #pragma unroll
     for (int kt = 0; kt < 5; ++kt)
 #pragma unroll
@@ -467,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
   // (both waves of a pair work in both rounds: the even wave stores the first half of the tiles and adds the second,
   //  the odd wave the other way round -- a + b and b + a are the same float)
   f32x4* sSet = reinterpret_cast<f32x4*>(smem + (wv >> 1) * G::X_SET) + lane;
-  constexpr int XH = G::TILES / 2;
+  constexpr int XH = TB + (G::TILES - TB) / 2;
   auto put = [&](auto LOW) {
     each([&](const f32x4& t, int ti) {
       if ((ti < XH) == decltype(LOW)::value) {
@@ -500,7 +520,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
   const int first_wg = tile0 / w.tiles_per_wg;           // first workgroup with tiles of this slot
   const int my_slab = blockIdx.x - first_wg;
   float* slab = w.slab + (int64_t)my_slab * w.slab_stride;
-  wg_write<5, H1>(sA + G::T0 * 256, sB + G::T0 * 256, sBias, slab + w.l[0].layer_off + slot * w.l[0].slot_stride, w.l[0]);
+  if constexpr (WG0)
+    wg_write<5, H1>(sA + G::T0 * 256, sB + G::T0 * 256, sBias, slab + w.l[0].layer_off + slot * w.l[0].slot_stride, w.l[0]);
   wg_write<3, H2>(sA + G::T1 * 256, sB + G::T1 * 256, sBias + 5 * 16, slab + w.l[1].layer_off + slot * w.l[1].slot_stride, w.l[1]);
   wg_write<2, H3>(sA + G::T2 * 256, sB + G::T2 * 256, sBias + 8 * 16, slab + w.l[2].layer_off + slot * w.l[2].slot_stride, w.l[2]);
   wg_write<1, 0>(sA + G::T3 * 256, sB + G::T3 * 256, sBias + 10 * 16, slab + w.l[3].layer_off + slot * w.l[3].slot_stride, w.l[3]);

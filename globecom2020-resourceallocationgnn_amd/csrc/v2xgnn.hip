@@ -118,6 +118,7 @@ struct v2x_model {
   std::map<GraphKey, GraphEntry> graphs;
   bool capturing = false;
   // wide path, single-GPU training: the layers' weight gradients are collected and launched as ONE grid (wide_wgrad_flush)
+  bool dense0_out_now = false;                  // inside a backward pass whose MLP launch leaves Dense-0's weight gradient to k_wgrad
   bool wide_merge_now = false;                  // inside a backward pass that merges
   bool bucketed = false;                        // data parallelism wants each layer's gradient as soon as it is final
   bool fuse_adam_now = false;                   // ... and applies Adam in the weight-gradient epilogues (WideWgradArgs::adam)
@@ -992,7 +993,7 @@ MlpWgSplit mlp_wg_split(int n_idx, int n_slots) {
 }
 
 template <int F>
-int launch_mlp_train_wg_f(v2x_model* m, hipStream_t st, const MlpArgs& a, int n_slots) {
+int launch_mlp_train_wg_f(v2x_model* m, hipStream_t st, const MlpArgs& a, int n_slots, bool wg0) {
   const size_t lds = (size_t)MlpWgLds<F>::TOTAL * 4;
   const MlpWgSplit sp = mlp_wg_split(a.n_idx, n_slots);
   if (sp.n_slabs > m->slab_cap) FAIL(m, V2X_ESTATE, "mlp_train_wg: slabs not pre-sized (%d > %d)", sp.n_slabs, m->slab_cap);
@@ -1007,17 +1008,25 @@ int launch_mlp_train_wg_f(v2x_model* m, hipStream_t st, const MlpArgs& a, int n_
     ld.n_slabs = sp.n_slabs;              // remembered for the slab reduction
     t.w.l[i] = MlpWgLayer{ld.off, ld.slot_stride, ld.n_out, ld.pad};
   }
+  if constexpr (F == 64) {
+    if (!wg0) {             // Dense-0's weight gradient is a role of the graph layers' launch (dense0_rides): dz1 rows instead
+      if (a.frag_groups > 0) { auto k = k_mlp_train_wg<F, true, false>; LAUNCH(m, "k_mlp_train_wg123", k, dim3(sp.n_wgs), lds, st, t); }
+      else { auto k = k_mlp_train_wg<F, false, false>; LAUNCH(m, "k_mlp_train_wg123", k, dim3(sp.n_wgs), lds, st, t); }
+      return V2X_OK;
+    }
+  }
+  if (!wg0) FAIL(m, V2X_ESTATE, "mlp_train_wg: Dense-0 outside the launch needs feat_dim 64");
   if (a.frag_groups > 0) { auto k = k_mlp_train_wg<F, true>; LAUNCH(m, "k_mlp_train_wg", k, dim3(sp.n_wgs), lds, st, t); }
   else { auto k = k_mlp_train_wg<F>; LAUNCH(m, "k_mlp_train_wg", k, dim3(sp.n_wgs), lds, st, t); }
   return V2X_OK;
 }
 
-int launch_mlp_train_wg(v2x_model* m, hipStream_t st, const MlpArgs& a) {
+int launch_mlp_train_wg(v2x_model* m, hipStream_t st, const MlpArgs& a, bool wg0 = true) {
   const int gy = m->S == 1 ? 1 : m->N;
   switch (m->F) {
-    case 16: return launch_mlp_train_wg_f<16>(m, st, a, gy);
-    case 32: return launch_mlp_train_wg_f<32>(m, st, a, gy);
-    case 64: return launch_mlp_train_wg_f<64>(m, st, a, gy);
+    case 16: return launch_mlp_train_wg_f<16>(m, st, a, gy, wg0);
+    case 32: return launch_mlp_train_wg_f<32>(m, st, a, gy, wg0);
+    case 64: return launch_mlp_train_wg_f<64>(m, st, a, gy, wg0);
   }
   FAIL(m, V2X_EINVAL, "unsupported feat_dim %d", m->F);
 }
@@ -1061,7 +1070,7 @@ int wgrad_role(v2x_model* m, LayerDesc& ld, int kind, const IdxMap& x, int total
   static const int rows_embed = env_int("V2X_WG_CHUNK_EMBED", 0);       // the (light) embed role on its own chunking
   if (rows_embed > 0 && (kind == WG_KIND_EMBED || kind == WG_KIND_EMBED_NONBR)) rows_g = rows_embed;
   if (rows_override > 0) rows_g = rows_override;
-  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, gnn_kind ? rows_g : rows_dense);
+  const int nc = role_chunks(x.n_idx, x.grid_y, layer_work(ld), total_work, &chunk, (gnn_kind || rows_override > 0) ? rows_g : rows_dense);
   if (nc > m->slab_cap) FAIL(m, V2X_ESTATE, "wgrad: slabs not pre-sized (%d > %d)", nc, m->slab_cap);
   ld.n_slabs = nc;                       // remembered for the slab reduction
   memset(&a, 0, sizeof(a));
@@ -1086,13 +1095,34 @@ int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti
     maxt = std::max(maxt, (mu.w[i].kp / 16) * (mu.w[i].np / 16) + (mu.w[i].kind >= WG_KIND_GNN_E1 ? 4 : 0));
     nc = std::max(nc, mu.w[i].n_chunks);
   }
+  {                                     // phase stamps (V2X_FUSED_TS=1): of ONE role, V2X_WG_TS_ROLE (default: the first)
+    const int ts_role = env_int("V2X_WG_TS_ROLE", 0);
+    for (int i = 0; i < n_roles; ++i)
+      if (i != ts_role) mu.w[i].ts = nullptr;
+  }
   const size_t lds = (size_t)(2 * maxt * 64 * 4 + 4 * 9 * 16) * 4;      // accumulator exchange (two sets) + bias (per wave)
-  const dim3 grid(nc, x.grid_y, n_roles);
+  dim3 grid(nc, x.grid_y, n_roles);
+  {                                     // unequal chunk counts: a packed 1-D grid of the real workgroups (kernels.hpp WgradMulti)
+    bool uneven = false;
+    for (int i = 0; i < n_roles; ++i) uneven = uneven || mu.w[i].n_chunks != nc;
+    mu.packed = uneven ? 1 : 0;
+    int at = 0;
+    for (int i = 0; i <= WG_MAX_ROLES; ++i) {
+      mu.wg_begin[i] = at;
+      if (i < n_roles) at += mu.w[i].n_chunks * x.grid_y;
+    }
+    if (uneven) grid = dim3(at, 1, 1);
+  }
   bool dense = false, gnn = false;
-  for (int i = 0; i < n_roles; ++i) ((mu.w[i].kind >= WG_KIND_DENSE0 && mu.w[i].kind <= WG_KIND_DENSE3) ? dense : gnn) = true;
+  bool halves = false;
+  for (int i = 0; i < n_roles; ++i) {
+    if (mu.w[i].kind >= WG_KIND_DENSE0A) { halves = true; continue; }
+    ((mu.w[i].kind >= WG_KIND_DENSE0 && mu.w[i].kind <= WG_KIND_DENSE3) ? dense : gnn) = true;
+  }
 #define V2X_WG_CASE(FF)                                                              \
   if (m->F == FF) {                                                                  \
-    if (dense && gnn) { auto k = k_wgrad<FF, 2>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
+    if (halves) { auto k = k_wgrad<FF, 3>; LAUNCH(m, name, k, grid, lds, st, mu); }    \
+    else if (dense && gnn) { auto k = k_wgrad<FF, 2>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
     else if (dense) { auto k = k_wgrad<FF, 1>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
     else { auto k = k_wgrad<FF, 0>; LAUNCH(m, name, k, grid, lds, st, mu); }           \
     return V2X_OK;                                                                   \
@@ -1147,10 +1177,11 @@ int wide_wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, con
 // leaves >= 64 rows each (one 16-row block per wave), else the default chunking (0).  (Until round 3 the bound was 256
 // rows: a 512- or 1024-graph share of a fixed global batch -- 8 / 4 GPUs -- then fell back to 896-row chunks, i.e. 40 / 80
 // workgroups walking 8 blocks per wave: 33.8 / 34.1 us per launch against 19.2 / 20.6 us with 128- / 192-row chunks.)
-int merged_wg_rows(const v2x_model* m, int n_idx, int n_slots) {
+// extra_roles: roles of about a graph layer's weight that ride in the same grid (Dense-0 at small batches, dense0_rides)
+int merged_wg_rows(const v2x_model* m, int n_idx, int n_slots, int extra_roles = 0) {
   static const int rows_env = env_int("V2X_WG_CHUNK_MERGED", 0);
   if (rows_env > 0) return rows_env;
-  const int nc_fit = n_cus() / std::max(1, m->L * n_slots);
+  const int nc_fit = n_cus() / std::max(1, (m->L + extra_roles) * n_slots);
   static const int min_rows = env_int("V2X_WG_MERGED_MIN_ROWS", 64);
   if (nc_fit >= 1 && n_idx / nc_fit >= min_rows) return ((n_idx + nc_fit - 1) / nc_fit + 63) / 64 * 64;
   return 0;
@@ -1164,6 +1195,28 @@ int wgrad_gnn(v2x_model* m, hipStream_t st, int stage, const IdxMap& x, const fl
   memset(&mu, 0, sizeof(mu));
   CHK(wgrad_gnn_role(m, stage, x, layer_work(m->gnn[stage]), xe, h_prev, agg_prev, dpre, mu.w[0]));
   return launch_wgrad_multi(m, st, x, mu, 1, stage ? "k_wgrad_gnn" : "k_wgrad_embed");
+}
+
+// The embed layer's gradient rides on the graph layers' roles (wgrad_gnn_all)
+bool embed_rides(const v2x_model* m, const DevBatch& d) {
+  static const int merge_env = env_int("V2X_WG_EMBED_MERGE", 1);
+  const int NTf = m->F / 16;
+  return merge_env && !is_wide(m) && !d.nbr && m->L >= 1 && m->L <= NTf && NTf % m->L == 0 && m->L + 3 <= WG_MAX_ROLES;
+}
+// Small batches (the shares of the metric's global batch on 4 / 8 GPUs): k_mlp_train_wg is ONE wave's latency chain there (<= 2
+// tiles per wave) and the graph layers' weight-gradient launch leaves a third of the chip idle: Dense-0's weight gradient -- 180
+// of a tile's 796 MFMAs, 45 of the 68 accumulator tiles the MLP launch exchanges and writes at its end -- moves over as a role
+// of that launch (kernels_mlpwg.hpp WG0 = false, kernels.hpp WG_KIND_DENSE0_FRAG).  V2X_MLP_WG0=1: never, =0: whenever possible.
+bool dense0_rides(const v2x_model* m, const DevBatch& d, const IdxMap& x) {
+  const int env = env_int("V2X_MLP_WG0", -1);                     // (read per call: the tests switch it inside one process)
+  if (env == 1 || m->F != 64 || m->cfg.variable_graphs || !embed_rides(m, d)) return false;
+  if (x.n_idx % 16 || x.idx_base % 16) return false;             // whole 16-row groups (the fragment-major reader)
+  if (env == 0) return true;
+  // tiles per workgroup = 4 x tiles per wave.  Measured (profiles/r06_dense0_role_shares.txt): 512 / 1024 / 2048 graphs of 20 links
+  // (4 / 8 / 12 tiles per workgroup) 0.1201 -> 0.1131, 0.1512 -> 0.1463, 0.1929 -> 0.1880 ms per step; at 4096 (20-24 tiles) the chip
+  // is full either way and the heavier weight-gradient launch costs more than the MLP launch saves (0.2554 -> 0.2658)
+  const int max_tiles = env_int("V2X_MLP_WG0_TILES", 12);
+  return mlp_wg_split(x.n_idx, x.grid_y).tiles_per_wg <= max_tiles;
 }
 
 // all GNN stages (needs dpre[0..L]) in ceil((L+1)/4) launches
@@ -1189,19 +1242,38 @@ int wgrad_gnn_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch&
   // tiles divide evenly over the L stages: no workgroups of its own, and the heavy roles get one workgroup per CU --
   // n_cus / (L * slots) chunks per slot (batch 4096 x 20 slots x 2 stages: 6 chunks = 240 workgroups x 11 blocks per wave
   // instead of 5 chunks = 200 x 13 with 100 embed workgroups queueing behind them).
-  static const int merge_env = env_int("V2X_WG_EMBED_MERGE", 1);
   const int NTf = m->F / 16;
-  if (merge_env && !d.nbr && m->L >= 1 && m->L <= NTf && NTf % m->L == 0 && m->L + 1 <= WG_MAX_ROLES) {
+  if (embed_rides(m, d)) {
     const int en = NTf / m->L;
-    const int rows = merged_wg_rows(m, x.n_idx, x.grid_y);
+    const bool d0 = m->dense0_out_now;                           // + Dense-0 (k_mlp_train_wg left dz1 instead of dW0)
+    const int rows = merged_wg_rows(m, x.n_idx, x.grid_y, d0 ? 1 : 0);
     memset(&mu, 0, sizeof(mu));
     int total = 0, n = 0;
     for (int t = m->L; t >= 1; --t) total += layer_work(m->gnn[t]);
     for (int s = m->L; s >= 1; --s)
       CHK(wgrad_gnn_role(m, s, x, total, d.xe, m->h[s - 1], m->a[s - 1], m->dpre[s], mu.w[n++], en, rows));
+    if (d0) {
+      // Dense-0 in two halves along K, [h | x] (25 accumulator tiles) and [agg] (20): lighter than a graph layer's role (36 + the
+      // embed's; those go first: workgroups are dispatched in role order), so they take HALF as many row chunks -- at the 512- and 1024-graph shares 4 chunks per graph-layer role and 2
+      // per half is 240 workgroups, one per CU
+      const int F = m->F, L = m->L;
+      const int groups = m->frag_live ? d.B / FZ_TG : 0;
+      int chunk_g;
+      const int nc_g = role_chunks(x.n_idx, x.grid_y, 1, 1, &chunk_g, rows > 0 ? rows : 896);
+      const int rows_d = (((x.n_idx + std::max(1, nc_g / 2) - 1) / std::max(1, nc_g / 2)) + 63) / 64 * 64;
+      WgSeg sa[2] = {WgSeg{m->h[L], F, F, 0, 0}, WgSeg{d.xe, XE, XE, F, 0}};
+      CHK(wgrad_role(m, m->dense[0], groups ? WG_KIND_DENSE0A_F : WG_KIND_DENSE0A, x, total, sa, 2, m->dz1, H1, mu.w[n], rows_d));
+      mu.w[n].frag_groups = groups; mu.w[n].kp = F + XE;
+      ++n;
+      WgSeg sb[1] = {WgSeg{m->a[L], F, F, 0, 0}};
+      CHK(wgrad_role(m, m->dense[0], groups ? WG_KIND_DENSE0B_F : WG_KIND_DENSE0B, x, total, sb, 1, m->dz1, H1, mu.w[n], rows_d));
+      mu.w[n].frag_groups = groups; mu.w[n].kp = F; mu.w[n].k_off = F + XE; mu.w[n].no_bias = 1;
+      ++n;
+    }
     m->gnn[0].n_slabs = m->gnn[1].n_slabs;                     // every stage role writes its columns of every embed slab
-    return launch_wgrad_multi(m, st, x, mu, n, "k_wgrad_gnn");
+    return launch_wgrad_multi(m, st, x, mu, n, d0 ? "k_wgrad_gnn_d0" : "k_wgrad_gnn");
   }
+  if (m->dense0_out_now) FAIL(m, V2X_ESTATE, "wgrad: Dense-0 was left to a launch that cannot take it");
   int n = 0, s_first = m->L;
   for (int s = m->L; s >= 0; --s) {
     if (n == 0) { memset(&mu, 0, sizeof(mu)); s_first = s; }
@@ -1473,10 +1545,15 @@ int launch_pack(v2x_model* m, hipStream_t st) {
 // Fragment-major hand-off between the fused graph-layer kernels and k_mlp_train_wg (MlpArgs::frag_groups): whole batch in
 // whole 16-graph groups, per-node weights (a tile of the MLP kernel is then a group of one node), at least one graph layer.
 bool mlp_wg_path(const v2x_model* m);
+bool dense0_rides(const v2x_model* m, const DevBatch& d, const IdxMap& x);
 bool frag_layout(const v2x_model* m, const DevBatch& d, Range r) {
   static const int on = env_int("V2X_FRAG_HANDOFF", 1), per_stage = env_int("V2X_WG_PER_STAGE", 0);
+  // (V2X_FRAG_WITH_DENSE0_ROLE=0: row-major hand-over where Dense-0's weight gradient is a role of k_wgrad -- measured slower: the
+  //  fragment-major reader of that role costs nothing next to what the MLP launch and the fused kernels gain from 1 KiB accesses,
+  //  0.1131 against 0.1157 ms at the 512-graph share)
+  static const int frag_d0 = env_int("V2X_FRAG_WITH_DENSE0_ROLE", 1);
   return on && !per_stage && fused_path(m, d) && r.g0 == 0 && r.ng == d.B && mlp_wg_path(m) && m->S == m->N && m->L >= 1 &&
-         d.B % FZ_TG == 0;
+         d.B % FZ_TG == 0 && (frag_d0 || !dense0_rides(m, d, idx_map(m, d, r)));
 }
 
 int launch_fused_fwd(v2x_model* m, hipStream_t st, const DevBatch& d, bool frag_out = false) {
@@ -1815,7 +1892,10 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   struct MergeGuard { v2x_model* m; ~MergeGuard() { m->wide_merge_now = false; } } merge_guard{m};
   if (m->frag_live && !frag_layout(m, d, r)) FAIL(m, V2X_ESTATE, "backward: the saved forward is fragment-major, this backward cannot read it");
   a.frag_groups = m->frag_live ? d.B / FZ_TG : 0;
-  if (mlp_wg) CHK(launch_mlp_train_wg(m, st, a));
+  // (the weight-gradient launch below must be the merged one of wgrad_gnn_all: one stream, no per-stage split)
+  m->dense0_out_now = mlp_wg && !two && r.g0 == 0 && r.ng == d.B && dense0_rides(m, d, x);
+  struct D0Guard { v2x_model* m; ~D0Guard() { m->dense0_out_now = false; } } d0_guard{m};
+  if (mlp_wg) CHK(launch_mlp_train_wg(m, st, a, !m->dense0_out_now));
   else if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
   else CHK(launch_mlp(m, st, a, true));
   const bool merged = !mlp_wg && !two && wgrad_all_fits(m) && env_int("V2X_WG_SPLIT", 0) == 0;
@@ -2371,6 +2451,13 @@ int v2x_apply_gradients_range(v2x_model* m, int64_t offset, int64_t count, int a
                             advance_iteration != 0);
 }
 
+int v2x_forward_call(void* closure) {
+  v2x_forward_closure* c = (v2x_forward_closure*)closure;
+  v2x_model* nullm = nullptr;
+  if (!c) FAIL(nullm, V2X_EINVAL, "forward_call: null closure");
+  return v2x_forward(c->m, &c->b, c->q_out, c->q_on_device, c->stream);
+}
+
 int v2x_train_step(v2x_model* m, const v2x_batch* b, const float* y, int y_on_device, int32_t n_graphs_global,
                    float* loss_out, int loss_on_device, void* stream) {
   return fwd_bwd(m, b, y, y_on_device, n_graphs_global, loss_out, loss_on_device, stream, true);
@@ -2582,6 +2669,36 @@ int v2x_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_id
   return V2X_OK;
 }
 
+int v2x_gather_rows_multi(int32_t n_jobs, const void* const* src, void* const* dst, const int64_t* row_bytes, const int32_t* idx,
+                          int64_t n_idx, void* stream) {
+  v2x_model* nullm = nullptr;
+  if (n_jobs < 1 || n_jobs > GATHER_MAX_JOBS || !src || !dst || !row_bytes || !idx || n_idx <= 0)
+    FAIL(nullm, V2X_EINVAL, "gather_rows_multi: 1..%d jobs, non-null arrays, a non-empty selection", GATHER_MAX_JOBS);
+  GatherJobs jobs;
+  memset(&jobs, 0, sizeof(jobs));
+  int64_t most = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    if (!src[j] || !dst[j] || row_bytes[j] <= 0 || (row_bytes[j] & 3)) FAIL(nullm, V2X_EINVAL, "gather_rows_multi: job %d: null pointer or row_bytes not a multiple of 4", j);
+    jobs.src[j] = (const uint32_t*)src[j]; jobs.dst[j] = (uint32_t*)dst[j]; jobs.words[j] = row_bytes[j] / 4;
+    jobs.vec[j] = ((row_bytes[j] & 15) == 0 && ((uintptr_t)src[j] & 15) == 0 && ((uintptr_t)dst[j] & 15) == 0) ? 1 : 0;
+    most = std::max(most, n_idx * (jobs.vec[j] ? jobs.words[j] / 4 : jobs.words[j]));
+  }
+  const int blocks = (int)std::min<int64_t>((most + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_gather_rows_multi, dim3(blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs, idx, n_idx);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) FAIL(nullm, V2X_EHIP, "gather_rows_multi launch failed: %s", hipGetErrorString(e));
+  return V2X_OK;
+}
+
+int v2x_q_stats(const float* y, int32_t n_graphs, int32_t n_nodes, int32_t n_channels, double* out, void* stream) {
+  v2x_model* nullm = nullptr;
+  if (!y || !out || n_graphs <= 0 || n_nodes <= 0 || n_channels <= 0) FAIL(nullm, V2X_EINVAL, "q_stats: bad argument");
+  hipLaunchKernelGGL(k_q_stats, dim3(n_nodes), dim3(256), 0, (hipStream_t)stream, y, n_graphs, n_nodes, n_channels, out);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) FAIL(nullm, V2X_EHIP, "q_stats launch failed: %s", hipGetErrorString(e));
+  return V2X_OK;
+}
+
 int v2x_dqn_targets(const float* q, const float* q_next, const int32_t* action, const double* reward, double gamma,
                     int32_t n_graphs, int32_t n_nodes, int32_t n_channels, float* y_out, void* stream) {
   v2x_model* nullm = nullptr;
@@ -2667,9 +2784,13 @@ int v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap) {
   char gl[48];
   if (fused && split > 1) snprintf(gl, sizeof(gl), "fused(split%d)", split);
   else snprintf(gl, sizeof(gl), "%s", fused ? "fused" : (ragged_fused_path(m, d) ? "fused(ragged)" : "layerwise"));
-  snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s", gl, agg,
+  // dense0_dw: which launch takes Dense-0's weight gradient in a fit step -- the MLP launch itself, or (small batches) a role of
+  // the graph layers' weight-gradient launch (dense0_rides)
+  const bool d0 = mlp_wg_path(m) && !m->cfg.variable_graphs && dense0_rides(m, d, idx_map(m, d, Range{0, d.B}));
+  snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s dense0_dw=%s", gl, agg,
            mlp_wg_path(m) ? "train_wg" : (mlp_fused_training(m) ? "train" : "fwd+bwd"),
-           frag_layout(m, d, Range{0, d.B}) ? "fragment-major" : "row-major");
+           frag_layout(m, d, Range{0, d.B}) ? "fragment-major" : "row-major",
+           d0 ? "k_wgrad" : (mlp_wg_path(m) ? "k_mlp_train_wg" : (is_wide(m) ? "k_wide_wgrad" : "k_wgrad")));
   return V2X_OK;
 }
 

@@ -11,6 +11,7 @@
 #include <pthread.h>
 #include <stdatomic.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/v2xsim.h"
 
@@ -20,7 +21,7 @@ static const double V2V_H = 1.5, FC = 2.0, V2V_DECORR = 10.0, V2V_SHADOW_STD = 3
 static const double V2I_H_BS = 25.0, V2I_H_MS = 1.5, V2I_DECORR = 50.0, V2I_SHADOW_STD = 8.0;
 static const double BS_X = 750.0 / 2, BS_Y = 1299.0 / 2;
 
-int v2xsim_abi(void) { return 2; }
+int v2xsim_abi(void) { return 3; }
 /* ---- the thread pool --------------------------------------------------------------------------------------------------
  * Every entry point is "for each environment e: f(e)".  The loops run on a pool of threads that SLEEP between jobs (condition
  * variable): an OpenMP team spins for a while after each parallel region, and on the MI355X boxes the process may use 16 CPUs'
@@ -585,6 +586,336 @@ int v2xsim_advance_start(const v2xsim_advance_args* a) {
   return par_start(g_job.E, advance_one, &g_job);
 }
 int v2xsim_advance_wait(int id) { return par_wait(id); }
+
+/* ---- the reference's own rollout shape as ONE call: one simulator, T sequential transitions ------------------------------------
+ * Agent.generate_d2d_transition (BS_brain.py:409-553): observe -> epsilon-greedy action (a B = 1 predict when greedy, :308-352)
+ * -> rates on the current channels -> simulator step -> next observation, T = 50 times before every replay (:818-832).  One
+ * simulator step of 20 links is ~200 us of libm on one thread (3780 Gaussians, 400 path losses, 1680 fast-fading terms), so
+ * the loop the reference runs is bound by the simulator, not by the predict: here a step is cut over a small team of threads
+ * that spin for the duration of the call (they sleep between calls: cgroup CPU quota, see the pool above):
+ *   stream thread   step k: mobility with its turn draws, then the step's n_u uniforms of the environment's MT19937 stream --
+ *                   the only inherently sequential part (~30 us); depends on nothing but its own previous step, so it runs up to
+ *                   RO_RING - 1 steps ahead into a ring
+ *   K workers       step k: Gaussians (pairs split), barrier, shadowing / path loss / fast fading (link rows split), barrier,
+ *                   observable interference + observation (worker 0)
+ *   caller          transition k: epsilon draw and random actions on numpy's process-wide MT19937 (draw for draw: random_sample,
+ *                   randint's masked rejection), or the predict through a callback + first-maximiser argmax; rates on the channels of
+ *                   state k (v2xsim_reward's arithmetic); then waits for state k + 1
+ * The workers compute state k + 1 while the caller is inside transition k (nothing in a step depends on the actions), into
+ * the buffer of state k - 1, which the caller has left.  Every element is computed by the same expressions as
+ * v2xsim_advance / v2xsim_reward: states, rates and both random streams are bit-identical to T single steps
+ * (tests/test_rl_batched_env.py).  g_threads <= 2: everything on the caller, same results.                                 */
+static inline uint32_t np_interval(uint32_t* mt, int32_t* pos, uint32_t max);   /* below: numpy's masked rejection */
+#define RO_RING 4
+#define RO_MAXW 8
+typedef struct {
+  double *v2v_abs, *v2i_abs, *v2v_ff, *v2i_ff, *interf_db, *state, *adj;
+  float* xe; int32_t *mask, *col; uint8_t regular;
+} ro_state;
+typedef struct { double* xy; int8_t* dirs; double *u, *g; } ro_slot;
+typedef struct {
+  const v2xsim_rollout_args* a;
+  int n, rb, n_u, n_sh, T, K;
+  ro_state st[2];
+  ro_slot ring[RO_RING];
+  uint32_t mt[624]; int32_t mtpos;                 /* the environment's stream (owned by the stream thread during the call) */
+  double *si, *sv;                                 /* shadowing, updated in place by the workers */
+  _Atomic int stream_done, main_pos, workers_done, bar, stop;
+} ro_ctx;
+
+static void ro_spin(_Atomic int* v, int want) {    /* until *v >= want */
+  while (atomic_load_explicit(v, memory_order_acquire) < want) __builtin_ia32_pause();
+}
+/* stream part of step k: positions of state k + 1 and the step's uniforms */
+static void ro_stream_step(ro_ctx* c, int k) {
+  const v2xsim_rollout_args* a = c->a;
+  const int n = c->n;
+  ro_slot* s = &c->ring[k % RO_RING];
+  const double* xy_prev = k == 0 ? a->xy : c->ring[(k - 1) % RO_RING].xy;
+  const int8_t* d_prev = k == 0 ? a->dirs : c->ring[(k - 1) % RO_RING].dirs;
+  memcpy(s->xy, xy_prev, (size_t)n * 2 * sizeof(double));
+  memcpy(s->dirs, d_prev, (size_t)n);
+  positions_env(n, c->mt, &c->mtpos, s->xy, s->dirs, a->vel, a->timestep, a->n_lanes, a->up, a->down, a->left, a->right, a->width, a->height);
+  for (int i = 0; i < c->n_u; ++i) s->u[i] = mt_double(c->mt, &c->mtpos);
+}
+/* worker `w` of `K`, the three phases of step k (channels_env / interference_env / observe_env cut by index ranges) */
+static void ro_gauss(ro_ctx* c, int k, int w, int K) {
+  const ro_slot* s = &c->ring[k % RO_RING];
+  const int pairs = c->n_u / 2, p0 = (int)((int64_t)pairs * w / K), p1 = (int)((int64_t)pairs * (w + 1) / K);
+  for (int q = p0; q < p1; ++q) {
+    const double x2pi = s->u[2 * q] * TWOPI;
+    const double g2rad = sqrt(-2.0 * log(1.0 - s->u[2 * q + 1]));
+    s->g[2 * q] = cos(x2pi) * g2rad;
+    s->g[2 * q + 1] = sin(x2pi) * g2rad;
+  }
+}
+static void ro_channels(ro_ctx* c, int k, int w, int K) {
+  const v2xsim_rollout_args* a = c->a;
+  const int n = c->n, rb = c->rb, n_sh = c->n_sh, na = n * rb, nb = n * n * rb;
+  const ro_slot* s = &c->ring[k % RO_RING];
+  ro_state* o = &c->st[(k + 1) & 1];
+  const double *g = s->g, *pe = s->xy, *ve = a->vel;
+  const double* f = g + n_sh;
+  const double rs2 = 1 / sqrt(2.0);
+  const int i0 = (int)((int64_t)n * w / K), i1 = (int)((int64_t)n * (w + 1) / K);
+  for (int i = i0; i < i1; ++i) {                  /* V2I: shadowing, path loss, fast fading of link i */
+    const double dd = 0.002 * ve[i];
+    c->si[i] = exp(-1 * (dd / V2I_DECORR)) * c->si[i] + sqrt(1 - exp(-2 * (dd / V2I_DECORR))) * (g[i] * V2I_SHADOW_STD);
+    o->v2i_abs[i] = v2i_pathloss(pe[2 * i], pe[2 * i + 1]) + c->si[i];
+    for (int r = 0; r < rb; ++r) {
+      const int q = i * rb + r;
+      const double re = rs2 * f[q], im = rs2 * f[na + q];
+      o->v2i_ff[q] = o->v2i_abs[i] - 20 * log10(hypot(re, im));
+    }
+  }
+  for (int i = i0; i < i1; ++i)                    /* V2V rows i */
+    for (int j = 0; j < n; ++j) {
+      const double ddm = 0.002 * ve[i] + 0.002 * ve[j];
+      const int ij = i * n + j;
+      c->sv[ij] = exp(-1 * (ddm / V2V_DECORR)) * c->sv[ij] + sqrt(1 - exp(-2 * (ddm / V2V_DECORR))) * (g[n + ij] * V2V_SHADOW_STD);
+      o->v2v_abs[ij] = v2v_pathloss(pe[2 * i], pe[2 * i + 1], pe[2 * j], pe[2 * j + 1]) + c->sv[ij] + (i == j ? 50.0 : 0.0);
+      for (int r = 0; r < rb; ++r) {
+        const int q = ij * rb + r;
+        const double re = rs2 * f[2 * na + q], im = rs2 * f[2 * na + nb + q];
+        o->v2v_ff[q] = o->v2v_abs[ij] - 20 * log10(hypot(re, im));
+      }
+    }
+}
+static void ro_observe(ro_ctx* c, int k) {
+  const v2xsim_rollout_args* a = c->a;
+  ro_state* o = &c->st[(k + 1) & 1];
+  interference_env(c->n, c->rb, a->dest, o->v2v_ff, a->p_v2i, a->veh_gain, a->veh_nf, a->sig2, o->interf_db);
+  observe_env(c->n, c->rb, a->dest, o->v2v_ff, o->v2i_ff, a->p_v2v, o->state, o->adj, o->xe, o->mask, o->col, &o->regular);
+}
+static void ro_barrier(ro_ctx* c, int* phase) {    /* among the K workers */
+  ++*phase;
+  atomic_fetch_add_explicit(&c->bar, 1, memory_order_acq_rel);
+  ro_spin(&c->bar, *phase * c->K);
+}
+static void ro_worker(ro_ctx* c, int w) {
+  int phase = 0;
+  for (int k = 0; k < c->T; ++k) {
+    ro_spin(&c->stream_done, k + 1);               /* the step's positions and uniforms */
+    ro_spin(&c->main_pos, k);                      /* the caller has left state k - 1, whose buffer state k + 1 takes */
+    ro_gauss(c, k, w, c->K);
+    ro_barrier(c, &phase);
+    ro_channels(c, k, w, c->K);
+    ro_barrier(c, &phase);
+    if (w == 0) {
+      ro_observe(c, k);
+      atomic_store_explicit(&c->workers_done, k + 1, memory_order_release);
+    }
+  }
+}
+static void ro_stream(ro_ctx* c) {
+  for (int k = 0; k < c->T; ++k) {
+    ro_spin(&c->workers_done, k - (RO_RING - 1));  /* the ring slot's previous tenant (step k - RO_RING) has been consumed */
+    ro_stream_step(c, k);
+    atomic_store_explicit(&c->stream_done, k + 1, memory_order_release);
+  }
+}
+/* the team: threads that live across calls and sleep between them */
+static struct {
+  pthread_mutex_t mu; pthread_cond_t cv_go, cv_idle;
+  pthread_t th[RO_MAXW + 1]; int n_started;
+  ro_ctx* job; uint32_t gen; int n_members, n_left;
+  pthread_mutex_t call_mu;                         /* one rollout at a time */
+} RT = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, 0, PTHREAD_MUTEX_INITIALIZER };
+static void* ro_team_main(void* arg) {
+  const int id = (int)(intptr_t)arg;               /* 0: the stream thread, 1 .. K: worker id - 1 */
+  uint32_t seen = 0;
+  pthread_mutex_lock(&RT.mu);
+  for (;;) {
+    while (RT.gen == seen) pthread_cond_wait(&RT.cv_go, &RT.mu);
+    seen = RT.gen;
+    ro_ctx* c = RT.job;
+    const int member = id < RT.n_members;
+    pthread_mutex_unlock(&RT.mu);
+    if (member) {
+      if (id == 0) ro_stream(c); else ro_worker(c, id - 1);
+    }
+    pthread_mutex_lock(&RT.mu);
+    if (member && --RT.n_left == 0) pthread_cond_broadcast(&RT.cv_idle);
+  }
+  return 0;
+}
+static void ro_after_fork(void) {
+  pthread_mutex_init(&RT.mu, 0); pthread_cond_init(&RT.cv_go, 0); pthread_cond_init(&RT.cv_idle, 0);
+  pthread_mutex_init(&RT.call_mu, 0);
+  RT.n_started = 0; RT.n_left = 0; RT.job = 0;
+}
+static int ro_team_start(ro_ctx* c, int members) {  /* -> members actually running (0: no thread could be started) */
+  static int atfork_set = 0;
+  pthread_mutex_lock(&RT.mu);
+  if (!atfork_set) { pthread_atfork(0, 0, ro_after_fork); atfork_set = 1; }
+  while (RT.n_started < members) {
+    if (pthread_create(&RT.th[RT.n_started], 0, ro_team_main, (void*)(intptr_t)RT.n_started) != 0) break;
+    pthread_detach(RT.th[RT.n_started]);
+    ++RT.n_started;
+  }
+  if (RT.n_started < members) { pthread_mutex_unlock(&RT.mu); return 0; }
+  RT.job = c; RT.n_members = members; RT.n_left = members;
+  ++RT.gen;
+  pthread_cond_broadcast(&RT.cv_go);
+  pthread_mutex_unlock(&RT.mu);
+  return members;
+}
+static void ro_team_join(void) {
+  pthread_mutex_lock(&RT.mu);
+  while (RT.n_left > 0) pthread_cond_wait(&RT.cv_idle, &RT.mu);
+  RT.job = 0;
+  pthread_mutex_unlock(&RT.mu);
+}
+
+/* numpy's legacy RandomState.randint(0, hi) for hi <= 2^32: masked rejection on one 32-bit output per try
+ * (_rand_int64 -> random_bounded_uint64_fill -> buffered_bounded_masked_uint32, numpy/random/src/distributions/distributions.c) */
+static inline int64_t np_randint(uint32_t* mt, int32_t* pos, uint32_t hi) {
+  const uint32_t rng = hi - 1;
+  if (rng == 0) return 0;
+  return (int64_t)np_interval(mt, pos, rng);
+}
+
+static double* ro_buf; static size_t ro_buf_len;     /* the call's working memory, kept between calls */
+int v2xsim_rollout(v2xsim_rollout_args* a) {
+  if (!a || a->n < 3 || a->n > 31 || a->rb < 1 || a->rb > a->n || 3 * a->rb + 1 > 16 || a->T < 1 || a->n_actions < 1) return -1;
+  const int n = a->n, rb = a->rb, T = a->T, W = 3 * rb + 1, ne = n * (n - 2), m = rb < n ? rb : n;
+  const int n_draws = n + n * n + 2 * n * rb + 2 * n * n * rb;
+  if (n_draws & 1) return -1;
+  if (pthread_mutex_trylock(&RT.call_mu) != 0) return -3;
+  /* working memory: two state buffers + the ring, carved out of one block */
+  const size_t per_state = (size_t)n * n + n + (size_t)n * n * rb + (size_t)n * rb + (size_t)n * rb + (size_t)n * W + (size_t)n * n   /* doubles */
+                           + ((size_t)n * 16 * 4 + (size_t)n * 4 + (size_t)(ne > 0 ? ne : 1) * 4 + 7) / 8 + 2;
+  const size_t per_slot = (size_t)n * 2 + ((size_t)n + 7) / 8 + 2 * (size_t)n_draws + 2;
+  const size_t need = 2 * per_state + RO_RING * per_slot + (size_t)n + (size_t)n * n + 16;
+  if (ro_buf_len < need) {
+    free(ro_buf);
+    ro_buf = (double*)malloc(need * sizeof(double));
+    ro_buf_len = ro_buf ? need : 0;
+    if (!ro_buf) { pthread_mutex_unlock(&RT.call_mu); return -2; }
+  }
+  ro_ctx c;
+  memset(&c, 0, sizeof(c));
+  c.a = a; c.n = n; c.rb = rb; c.n_u = n_draws; c.n_sh = n + n * n; c.T = T;
+  double* p = ro_buf;
+  for (int b = 0; b < 2; ++b) {
+    ro_state* s = &c.st[b];
+    s->v2v_abs = p; p += (size_t)n * n;
+    s->v2i_abs = p; p += n;
+    s->v2v_ff = p; p += (size_t)n * n * rb;
+    s->v2i_ff = p; p += (size_t)n * rb;
+    s->interf_db = p; p += (size_t)n * rb;
+    s->state = p; p += (size_t)n * W;
+    s->adj = p; p += (size_t)n * n;
+    s->xe = (float*)p; p += ((size_t)n * 16 * 4 + 7) / 8;
+    s->mask = (int32_t*)p; p += ((size_t)n * 4 + 7) / 8;
+    s->col = (int32_t*)p; p += ((size_t)(ne > 0 ? ne : 1) * 4 + 7) / 8;
+  }
+  for (int r = 0; r < RO_RING; ++r) {
+    ro_slot* s = &c.ring[r];
+    s->xy = p; p += (size_t)n * 2;
+    s->dirs = (int8_t*)p; p += ((size_t)n + 7) / 8;
+    s->u = p; p += n_draws;
+    s->g = p; p += n_draws;
+  }
+  c.si = p; p += n;
+  c.sv = p; p += (size_t)n * n;
+  /* state 0 = the environment as it stands (channels read in place, never written: buffer 0 is first written as state 2) */
+  ro_state s0 = { a->v2v_abs, a->v2i_abs, a->v2v_ff, a->v2i_ff, a->interf_db, a->state, a->adj, a->xe, a->mask, a->col, *a->regular };
+  memcpy(c.mt, a->keys, sizeof(c.mt));
+  c.mtpos = *a->mtpos;
+  memcpy(c.si, a->v2i_shadow, (size_t)n * sizeof(double));
+  memcpy(c.sv, a->v2v_shadow, (size_t)n * n * sizeof(double));
+  int K = g_threads - 2;
+  if (K > RO_MAXW) K = RO_MAXW;
+  if (K > n) K = n;
+  c.K = K > 0 ? K : 1;
+  const int team = K >= 1 ? ro_team_start(&c, 1 + c.K) : 0;
+  if (!team) c.K = 1;
+  int rc = T, phase = 0;
+  double eps = a->eps_min;
+  for (int t = 0; t < T; ++t) {
+    const ro_state* cur = t == 0 ? &s0 : &c.st[t & 1];
+    atomic_store_explicit(&c.main_pos, t, memory_order_release);
+    if (!team) {                                   /* no helpers: the step right here */
+      ro_stream_step(&c, t);
+      ro_gauss(&c, t, 0, 1); ro_channels(&c, t, 0, 1); ro_observe(&c, t);
+      atomic_store(&c.stream_done, t + 1); atomic_store(&c.workers_done, t + 1);
+      (void)phase;
+    }
+    /* ---- epsilon-greedy action (BS_brain.py:308-352) */
+    const int64_t step_no = a->step_no0 + t;
+    eps = (double)step_no < a->eps_steps ? a->eps_max - a->eps_per_step * (double)step_no : a->eps_min;
+    int64_t* act = a->t_action + (int64_t)t * n;
+    if (mt_double(a->np_key, a->np_pos) < eps) {
+      for (int i = 0; i < n; ++i) act[i] = np_randint(a->np_key, a->np_pos, (uint32_t)a->n_actions);
+    } else {
+      if (!cur->regular || !a->predict) { rc = -4 - t; break; }          /* a link that is its own receiver: the caller's general path */
+      memcpy(a->xe_pin, cur->xe, (size_t)n * 16 * sizeof(float));
+      memcpy(a->col_pin, cur->col, (size_t)ne * sizeof(int32_t));
+      if (a->predict(a->predict_ctx) != 0) { rc = -1000 - t; break; }
+      for (int i = 0; i < n; ++i) {                /* first maximiser (np.argmax) */
+        const float* q = a->q_pin + (int64_t)i * a->n_actions;
+        int best = 0;
+        for (int ch = 1; ch < a->n_actions; ++ch) if (q[ch] > q[best]) best = ch;
+        act[i] = best;
+      }
+      ++*a->n_greedy;
+    }
+    /* ---- rates on the channels of state t (compute_reward_with_channel_selection) */
+    {
+      reward_ctx r = { n, rb, act, a->dest, cur->v2v_ff, cur->v2i_ff, cur->v2i_abs, a->p_v2v, a->p_v2i, a->veh_gain, a->bs_gain, a->bs_nf,
+                       a->veh_nf, a->sig2, a->t_v2v_rate + (int64_t)t * n, a->t_v2i_rate + (int64_t)t * m, a->interference, a->v2i_interf,
+                       a->v2v_interf };
+      reward_one(0, &r);
+    }
+    memcpy(a->t_xe + (int64_t)t * n * 16, cur->xe, (size_t)n * 16 * sizeof(float));
+    memcpy(a->t_col + (int64_t)t * ne, cur->col, (size_t)ne * sizeof(int32_t));
+    memcpy(a->t_mask + (int64_t)t * n, cur->mask, (size_t)n * sizeof(int32_t));
+    a->t_regular[t] = cur->regular;
+    ro_spin(&c.workers_done, t + 1);               /* state t + 1 */
+    memcpy(a->t_xe_next + (int64_t)t * n * 16, c.st[(t + 1) & 1].xe, (size_t)n * 16 * sizeof(float));
+  }
+  const int done = rc == T ? T : (rc <= -1000 ? -1000 - rc : -4 - rc);     /* transitions completed */
+  if (team) {
+    if (done < T) {
+      /* an early exit: let the team run out (it never waits for more than main_pos) and throw its extra steps away -- the
+       * environment is committed at state `done`, recomputed below from the stream state of that step */
+      atomic_store_explicit(&c.main_pos, T, memory_order_release);
+    }
+    ro_team_join();
+  }
+  if (done < T) {
+    /* states beyond `done` were computed ahead with draws the environment has not officially taken: redo the committed prefix
+     * sequentially from the inputs (cheap next to the failure that brought us here) */
+    memcpy(c.mt, a->keys, sizeof(c.mt)); c.mtpos = *a->mtpos;
+    memcpy(c.si, a->v2i_shadow, (size_t)n * sizeof(double));
+    memcpy(c.sv, a->v2v_shadow, (size_t)n * n * sizeof(double));
+    for (int t = 0; t < done; ++t) { ro_stream_step(&c, t); ro_gauss(&c, t, 0, 1); ro_channels(&c, t, 0, 1); ro_observe(&c, t); }
+  }
+  if (done > 0) {                                  /* commit state `done` to the caller's arrays */
+    const ro_state* f = &c.st[done & 1];
+    const ro_slot* sl = &c.ring[(done - 1) % RO_RING];
+    memcpy(a->keys, c.mt, sizeof(c.mt)); *a->mtpos = c.mtpos;
+    memcpy(a->xy, sl->xy, (size_t)n * 2 * sizeof(double));
+    memcpy(a->dirs, sl->dirs, (size_t)n);
+    memcpy(a->v2i_shadow, c.si, (size_t)n * sizeof(double));
+    memcpy(a->v2v_shadow, c.sv, (size_t)n * n * sizeof(double));
+    memcpy(a->v2v_abs, f->v2v_abs, (size_t)n * n * sizeof(double));
+    memcpy(a->v2i_abs, f->v2i_abs, (size_t)n * sizeof(double));
+    memcpy(a->v2v_ff, f->v2v_ff, (size_t)n * n * rb * sizeof(double));
+    memcpy(a->v2i_ff, f->v2i_ff, (size_t)n * rb * sizeof(double));
+    memcpy(a->interf_db, f->interf_db, (size_t)n * rb * sizeof(double));
+    memcpy(a->state, f->state, (size_t)n * W * sizeof(double));
+    memcpy(a->adj, f->adj, (size_t)n * n * sizeof(double));
+    memcpy(a->xe, f->xe, (size_t)n * 16 * sizeof(float));
+    memcpy(a->mask, f->mask, (size_t)n * sizeof(int32_t));
+    memcpy(a->col, f->col, (size_t)ne * sizeof(int32_t));
+    *a->regular = f->regular;
+  }
+  a->eps_last = eps;
+  pthread_mutex_unlock(&RT.call_mu);
+  return rc;
+}
 
 /* ---- Memory.sample's draw (BS_brain.py:261): numpy's legacy np.random.choice(n, k, replace=False) --------------------------------
  * = RandomState.permutation(n)[:k] = shuffle(arange(n))[:k]: for i = n-1 .. 1: j = random_interval(i); swap(x[i], x[j]), with

@@ -30,6 +30,12 @@ class Batch(C.Structure):
                 ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p)]
 
 
+class ForwardClosure(C.Structure):
+    """v2x_forward_closure of include/v2xgnn.h"""
+    _fields_ = [("m", C.c_void_p), ("b", Batch), ("q_out", C.c_void_p), ("q_on_device", C.c_int32), ("pad_", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
 class Feed(C.Structure):
     _fields_ = [("n_graphs", C.c_int32), ("n_nodes", C.c_int32), ("feat_dim", C.c_int32), ("node_in", C.c_int32),
                 ("edge_in", C.c_int32), ("node", C.POINTER(C.c_void_p)), ("edge", C.POINTER(C.c_void_p)),
@@ -52,6 +58,7 @@ SYMBOLS = [
     ("v2x_param_ptr", _P, [_P]),
     ("v2x_grad_ptr", _P, [_P]),
     ("v2x_forward", C.c_int, [_P, C.POINTER(Batch), _P, C.c_int, _P]),
+    ("v2x_forward_call", C.c_int, [_P]),
     ("v2x_train_step", C.c_int, [_P, C.POINTER(Batch), _P, C.c_int, _I, _P, C.c_int, _P]),
     ("v2x_forward_backward", C.c_int, [_P, C.POINTER(Batch), _P, C.c_int, _I, _P, C.c_int, _P]),
     ("v2x_apply_gradients", C.c_int, [_P, _P]),
@@ -68,6 +75,8 @@ SYMBOLS = [
     ("v2x_adam_step", C.c_int, [_P, _P, _P, _P, _L, _L, _F, _F, _F, _F, _P]),
     ("v2x_device_addressable", C.c_int, [_P]),
     ("v2x_gather_rows", C.c_int, [_P, _P, _P, _L, _L, _P]),
+    ("v2x_gather_rows_multi", C.c_int, [_I, _P, _P, _P, _P, _L, _P]),
+    ("v2x_q_stats", C.c_int, [_P, _I, _I, _I, _P, _P]),
     ("v2x_dqn_targets", C.c_int, [_P, _P, _P, _P, C.c_double, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     ("v2x_dqn_step", C.c_int, [_P, _P, _P, _P, _P, _P, C.c_double, C.c_int32, _P, _P, C.c_int, _P]),
     ("v2x_pack_feed", C.c_int, [C.POINTER(Feed), C.c_int, _P, _P, _P, _P, _P]),

@@ -292,6 +292,8 @@ class Agent(object):
         # observations straight in the engine's packed layout (no float64 state / dense adjacency on the way to the GPU or to
         # the replay memory) when the simulator offers them and the memory lives in HBM; V2X_RL_PACKED=0: the array path
         packed = self._packed_rollouts()
+        if packed and E == 1 and self._native_rollout_ok():
+            return self._rollout_one_simulator(num_transitions)
         for it in range(n_iter):
             if packed:
                 rewards[it * E:(it + 1) * E] = self._packed_iteration(last=it == n_iter - 1)
@@ -328,7 +330,7 @@ class Agent(object):
                                         np.concatenate((nxt[e].reshape(1, -1), adj[e].reshape(1, -1)), axis=-1)])
         return rewards[:num_transitions] if n_iter * E == num_transitions else rewards
 
-    def _packed_iteration(self, last=False):
+    def _packed_iteration(self, last=False, force_greedy=False):
         """One iteration of _generate_batched on packed observations: same epsilon draws in the same order, same Q-values
         (the same kernels on the same float32 rows and CSR), same stored transitions.
         While the GPU is still busy with the previous fit (the predict below has to wait for it anyway) the host does what
@@ -346,7 +348,9 @@ class Agent(object):
         for e in range(E):
             step_no = base + e
             self.epsilon = MAX_EPSILON - per_step * step_no if step_no < steps else MIN_EPSILON
-            if draw() < self.epsilon:
+            if force_greedy:                           # (the native rollout took this transition's epsilon draw and found it greedy)
+                greedy.append(e)
+            elif draw() < self.epsilon:
                 actions[e] = _random_channels(n, 1, C)
             else:
                 greedy.append(e)
@@ -386,6 +390,89 @@ class Agent(object):
         if len(samples) > self.memory.capacity:
             del samples[:len(samples) - self.memory.capacity]
         return reward
+
+    def _native_rollout_ok(self):
+        """ONE simulator on the native library and the gfx950 engine: the whole rollout is one library call (v2xsim_rollout)"""
+        return (os.environ.get("V2X_RL_NATIVE_ROLLOUT", "1") != "0" and native_sim.available() and hasattr(self.env, 'native_rollout')
+                and self.env._one_call_step() and self._rollout_closure() is not None)
+
+    def _rollout_closure(self):
+        """The predict of the native rollout: page-locked buffers for ONE graph (the kernels read the observation over the bus,
+        the library copies Q back: GnnEngine.forward_to_host's path) behind a v2x_forward_closure, and the address of
+        v2x_forward_call.  A brain without the C ABI (tests) may provide `rollout_predict_callback(xe, col, q)` instead."""
+        io = getattr(self, '_native_io', None)
+        if io is not None:
+            return io
+        n, C = self.num_D2D, self.num_CH
+        ne = n * (n - 2)
+        custom = getattr(self.brain, 'rollout_predict_callback', None)
+        if custom is not None:
+            import ctypes
+            xe, col, q = np.zeros((n, 16), np.float32), np.zeros(max(ne, 1), np.int32), np.zeros((n, C), np.float32)
+            cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(lambda _ctx: int(custom(xe, col, q) or 0))
+            io = self._native_io = {"xe": xe, "col": col, "q": q, "cb": cb, "fn": ctypes.cast(cb, ctypes.c_void_p).value, "ctx": None}
+            return io
+        engine = getattr(getattr(self.brain, 'model', None), 'engine', None)
+        rep = self.device_replay
+        if engine is None or rep is None or not hasattr(engine, '_lib') or not hasattr(engine._lib, 'v2x_forward_call'):
+            return None
+        import ctypes
+        from .. import lib as _lib
+        torch = rep.torch
+        pins = {"xe": torch.empty((n, 16), dtype=torch.float32).pin_memory(), "col": torch.empty(max(ne, 1), dtype=torch.int32).pin_memory(),
+                "q": torch.empty((n, C), dtype=torch.float32).pin_memory()}
+        if os.environ.get("V2X_RL_ZERO_COPY", "1") == "0" or any(engine._lib.v2x_device_addressable(pins[k_].data_ptr()) != 1 for k_ in ("xe", "col")):
+            return None                                        # no unified addressing: the per-transition path copies
+        if rep.n_edges is None:
+            rep.n_edges = ne
+        rp = rep.row_ptr(1)
+        cl = _lib.ForwardClosure()
+        cl.m = engine._h
+        cl.b.n_graphs, cl.b.n_rows, cl.b.n_edges, cl.b.max_nodes, cl.b.max_edges, cl.b.on_device = 1, n, ne, n, ne, 1
+        cl.b.xe, cl.b.row_ptr, cl.b.col_idx = pins["xe"].data_ptr(), rp.data_ptr(), pins["col"].data_ptr()
+        cl.q_out, cl.q_on_device = pins["q"].data_ptr(), 0
+        io = self._native_io = {"pins": pins, "rp": rp, "closure": cl, "engine": engine,
+                                "xe": pins["xe"].numpy(), "col": pins["col"].numpy(), "q": pins["q"].numpy(),
+                                "fn": ctypes.cast(engine._lib.v2x_forward_call, ctypes.c_void_p).value, "ctx": ctypes.addressof(cl)}
+        return io
+
+    def _rollout_one_simulator(self, num_transitions):
+        """generate_d2d_transition on ONE batched simulator as one library call: the reference's loop shape (50 sequential
+        transitions, a B = 1 predict for every greedy one, BS_brain.py:409-553) with the simulator step cut over the library's
+        threads and computed while the predict is in flight.  Same epsilon draws, same random actions, same Q-values, same
+        stored transitions as _packed_iteration called num_transitions times (tests/test_rl_batched_env.py)."""
+        env, rep, io = self.env, self.device_replay, self._rollout_closure()
+        n = self.num_D2D
+        rewards = np.zeros(num_transitions)
+        steps = self.num_Episodes * 0.8 * self.num_Train_Step * self.num_transition
+        per_step = (MAX_EPSILON - MIN_EPSILON) / steps
+        done = 0
+        while done < num_transitions:
+            if "closure" in io:
+                io["closure"].stream = io["engine"]._stream()
+            out = env.native_rollout(num_transitions - done, self.num_CH,
+                                     dict(eps_max=MAX_EPSILON, eps_min=MIN_EPSILON, eps_per_step=per_step, eps_steps=steps, step_no0=self.num_step,
+                                          predict=io["fn"], predict_ctx=io["ctx"], xe_pin=io["xe"], col_pin=io["col"], q_pin=io["q"]))
+            k = out["done"]
+            if k > 0:
+                self.epsilon = out["eps_last"]
+                self.num_step += k
+                reward = self.v2v_weight * out["v2v_rate"].sum(axis=(1, 2)) + self.v2i_weight * out["v2i_rate"].sum(axis=1)
+                rewards[done:done + k] = reward
+                rep.add_many_packed(out["xe"], out["xe_next"], out["col"], out["mask"], out["regular"], out["action"], reward)
+                samples = self.memory.samples
+                samples.extend([None] * k)
+                if len(samples) > self.memory.capacity:
+                    del samples[:len(samples) - self.memory.capacity]
+                done += k
+            if done < num_transitions:
+                if out["rc"] <= -1000:
+                    raise RuntimeError("native rollout: the predict of transition %d failed" % done)
+                # a graph with a link that is its own receiver needs the general CSR builder: this transition the slow way.
+                # (its epsilon draw is already taken from np.random: the greedy branch, without drawing again)
+                rewards[done] = self._packed_iteration(force_greedy=True)[0]
+                done += 1
+        return rewards
 
     def _packed_rollouts(self):
         """the batched rollout takes observations in the engine's packed layout (see _generate_batched)"""
@@ -538,9 +625,14 @@ class Agent(object):
         # the per-sample maxima, per link.  Deferred on one GPU: the two divisions (by the number of actions, by the batch) are
         # the same IEEE operations on the host at the end of the episode -- three launches per step instead of seven.
         torch = rep.torch
-        y3 = y.view(len(idx), n, -1)
-        s_all = y3.sum(dim=(0, 2), dtype=torch.float64)
-        s_max = y3.amax(dim=2).sum(dim=0, dtype=torch.float64)
+        if hasattr(rep, 'q_stats') and y.is_cuda:
+            # (one launch of the library instead of three reductions + elementwise launches of the host framework)
+            st = rep.q_stats(y, len(idx), self.num_CH)
+            s_all, s_max = st[0], st[1]
+        else:
+            y3 = y.view(len(idx), n, -1)
+            s_all = y3.sum(dim=(0, 2), dtype=torch.float64)
+            s_max = y3.amax(dim=2).sum(dim=0, dtype=torch.float64)
         multi = trainer is not None and trainer.world > 1
         if defer and hasattr(loss, 'cpu') and not multi:
             return loss, (s_all, s_max)

@@ -87,7 +87,9 @@ class BatchedEnviron(object):
             # sleeps between jobs; the OpenMP teams of rounds 3-4 kept spinning, ran the process into its CPU quota and got it
             # parked for 25-50 ms a few times per hundred steps (csrc/v2xsim.c).  V2X_SIM_THREADS overrides.
             cap = int(os.environ.get("V2X_SIM_THREADS", "0")) or min(16, max(1, _usable_cpus() - 1))
-            native_sim.set_threads(max(1, min(self.E, cap)))
+            # (ONE simulator: its steps are cut over a team of threads inside v2xsim_rollout -- the caller, a stream thread and
+            #  up to 6 workers -- instead of environments over the pool)
+            native_sim.set_threads(max(1, min(self.E if self.E > 1 else 8, cap)))
             if not self._shared:                               # the streams' MT19937 states, where the library can advance them
                 self._mt_keys = np.empty((self.E, 624), np.uint32)
                 self._mt_pos = np.zeros(self.E, np.int32)
@@ -539,6 +541,91 @@ class BatchedEnviron(object):
         self._obs = (o["v2v_ff"], o["v2i_ff"], o["state"], o["adj"], o["xe"], o["mask"], o["col"], o["regular"].astype(bool))
         if self.lookahead and start_next:
             self._ahead = self._start_job(True)
+
+    def native_rollout(self, T, n_actions, policy):
+        """T sequential transitions of this ONE simulator (E == 1) in one library call (v2xsim_rollout, include/v2xsim.h): the
+        reference's own loop shape, Agent.generate_d2d_transition with 50 transitions before every replay (BS_brain.py:409-553,
+        :818-832).  policy: eps_max, eps_min, eps_per_step, eps_steps, step_no0 (the epsilon schedule as the agent evaluates it),
+        predict / predict_ctx (addresses of a C callback `int (*)(void*)` and its closure: scores the graph in xe_pin / col_pin
+        into q_pin), xe_pin [n, 16] float32, col_pin [n (n-2)] int32, q_pin [n, n_actions] float32.  Epsilon draws and random
+        actions are taken from numpy's process-wide generator exactly as np.random.random() / np.random.randint would.
+        -> dict(done, rc, xe, xe_next, col, mask, regular, action, v2v_rate [done, n, 1], v2i_rate [done, m], eps_last, n_greedy);
+        the simulator stands at the state after `done` transitions (done < T: transition `done` needs the caller's general path --
+        a link that is its own receiver -- or its predict failed, rc says which)."""
+        if self.E != 1 or not self._one_call_step() or not self.packed_ok(self.n_RB):
+            raise RuntimeError("native_rollout: one simulator of 3..31 links on the native library")
+        self._drop_lookahead()
+        n, rb, p = self.n_Veh, self.n_RB, self._proto
+        m, ne, W = min(rb, n), n * (n - 2), 3 * rb + 1
+        self.observe_packed(rb)
+        ob = self._observation(rb)
+        if ob is None:
+            ob = native_sim.observe_packed(self.dest, np.ascontiguousarray(self.V2V_channels_with_fastfading),
+                                           np.ascontiguousarray(self.V2I_channels_with_fastfading),
+                                           self.V2V_power_dB_List[self.fixed_v2v_power_index], rb)
+        f64, c = np.float64, np.ascontiguousarray
+        st = {"xy": c(self.pos, f64).copy(), "dirs": c(self.dirs, np.int8).copy(),
+              "v2i_shadow": c(self._v2i_shadow, f64).copy(), "v2v_shadow": c(self._v2v_shadow, f64).copy(),
+              "v2v_abs": c(self.V2V_channels_abs, f64).copy(), "v2i_abs": c(self.V2I_channels_abs, f64).copy(),
+              "v2v_ff": c(self.V2V_channels_with_fastfading, f64).copy(), "v2i_ff": c(self.V2I_channels_with_fastfading, f64).copy(),
+              "interf_db": np.zeros((1, n, 1, rb)),             # (output only: Compute_Interference of the final state)
+              "state": c(ob[0], f64).copy(), "adj": c(ob[1], f64).copy(), "xe": c(ob[2], np.float32).copy(),
+              "mask": c(ob[3], np.int32).copy(), "col": c(ob[4], np.int32).copy(), "regular": np.asarray(ob[5]).astype(np.uint8).copy(),
+              "interference": np.zeros(rb), "v2i_interf": np.zeros(rb), "v2v_interf": np.zeros(n)}
+        out = {"xe": np.empty((T, n, 16), np.float32), "xe_next": np.empty((T, n, 16), np.float32),
+               "col": np.empty((T, max(ne, 1)), np.int32), "mask": np.empty((T, n), np.int32), "regular": np.zeros(T, np.uint8),
+               "action": np.zeros((T, n), np.int64), "v2v_rate": np.zeros((T, n, 1)), "v2i_rate": np.zeros((T, m))}
+        name, key, pos, has_gauss, cached = np.random.get_state()
+        if name != 'MT19937':
+            raise RuntimeError("np.random is not on MT19937")
+        key, npos = np.ascontiguousarray(key, np.uint32).copy(), np.array([pos], np.int32)
+        n_greedy = np.zeros(1, np.int32)
+        tabs = [c(np.asarray(t, f64)) for t in (p.up_lanes, p.down_lanes, p.left_lanes, p.right_lanes)]
+        vel, dest = c(self.vel, f64), c(self.dest, np.int64)
+        a = native_sim.RolloutArgs()
+        a.n, a.rb, a.n_lanes, a.T, a.n_actions = n, rb, len(tabs[0]), int(T), int(n_actions)
+        a.timestep, a.width, a.height = p.timestep, p.width, p.height
+        a.up, a.down, a.left, a.right = (t.ctypes.data for t in tabs)
+        a.vel, a.dest = vel.ctypes.data, dest.ctypes.data
+        a.p_v2v, a.p_v2i = self.V2V_power_dB_List[self.fixed_v2v_power_index], self.V2I_power_dB
+        a.veh_gain, a.veh_nf, a.sig2, a.bs_gain, a.bs_nf = self.vehAntGain, self.vehNoiseFigure, self.sig2, self.bsAntGain, self.bsNoiseFigure
+        a.keys, a.mtpos = self._mt_keys.ctypes.data, self._mt_pos.ctypes.data
+        for k_, v_ in st.items():
+            setattr(a, k_, v_.ctypes.data)
+        a.np_key, a.np_pos = key.ctypes.data, npos.ctypes.data
+        a.eps_max, a.eps_min, a.eps_per_step = float(policy["eps_max"]), float(policy["eps_min"]), float(policy["eps_per_step"])
+        a.eps_steps, a.step_no0 = float(policy["eps_steps"]), int(policy["step_no0"])
+        a.predict, a.predict_ctx = policy.get("predict"), policy.get("predict_ctx")
+        pins = [policy.get(k_) for k_ in ("xe_pin", "col_pin", "q_pin")]
+        if a.predict:
+            if (pins[0].dtype != np.float32 or pins[0].size < n * 16 or pins[1].dtype != np.int32 or pins[1].size < max(ne, 1)
+                    or pins[2].dtype != np.float32 or pins[2].size < n * n_actions):
+                raise ValueError("native_rollout: xe_pin / col_pin / q_pin have the wrong type or size")
+            a.xe_pin, a.col_pin, a.q_pin = (t.ctypes.data for t in pins)
+        a.t_xe, a.t_xe_next, a.t_col, a.t_mask = (out[k_].ctypes.data for k_ in ("xe", "xe_next", "col", "mask"))
+        a.t_regular, a.t_action = out["regular"].ctypes.data, out["action"].ctypes.data
+        a.t_v2v_rate, a.t_v2i_rate = out["v2v_rate"].ctypes.data, out["v2i_rate"].ctypes.data
+        a.n_greedy = n_greedy.ctypes.data
+        if any(s_.gauss_next is not None for s_ in self.streams):
+            raise RuntimeError("a stream holds a cached gauss value")
+        rc = native_sim.rollout(a)
+        np.random.set_state((name, key, int(npos[0]), has_gauss, cached))
+        if rc in (-1, -2, -3):
+            raise RuntimeError("v2xsim_rollout failed (%d)" % rc)
+        done = T if rc == T else (-1000 - rc if rc <= -1000 else -4 - rc)
+        if done > 0:                                           # the simulator's public arrays: the state after `done` transitions
+            self.pos[:] = st["xy"]
+            self.dirs[:] = st["dirs"]
+            self._v2i_shadow, self._v2v_shadow = st["v2i_shadow"], st["v2v_shadow"]
+            self.V2V_channels_abs, self.V2I_channels_abs = st["v2v_abs"], st["v2i_abs"]
+            self.V2V_channels_with_fastfading, self.V2I_channels_with_fastfading = st["v2v_ff"], st["v2i_ff"]
+            self.V2V_Interference_all = st["interf_db"]
+            self._obs = (st["v2v_ff"], st["v2i_ff"], st["state"], st["adj"], st["xe"], st["mask"], st["col"], st["regular"].astype(bool))
+            self.V2I_Interference, self.V2V_Interference = st["v2i_interf"].reshape(1, rb), st["v2v_interf"].reshape(1, n, 1)
+        res = {k_: v_[:done] for k_, v_ in out.items()}
+        res["regular"] = res["regular"].astype(bool)
+        res.update(done=done, rc=rc, eps_last=float(a.eps_last), n_greedy=int(n_greedy[0]))
+        return res
 
     def _observation(self, n_channels):
         """the cached observation of the current channels (state, adj, xe, mask, col, regular), or None"""

@@ -25,7 +25,7 @@ def _load():
     if not os.path.exists(path):
         return None
     lib = C.CDLL(path)
-    if lib.v2xsim_abi() != 2:
+    if lib.v2xsim_abi() != 3:
         return None
     dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int64)
     lib.v2xsim_channels.argtypes = [C.c_int, C.c_int, C.c_int, dp, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp]
@@ -50,6 +50,8 @@ def _load():
     lib.v2xsim_np_choice_noreplace.restype = C.c_int
     lib.v2xsim_np_shuffle_skip.argtypes = [u32p, i32p, C.c_int64]
     lib.v2xsim_np_shuffle_skip.restype = C.c_int
+    lib.v2xsim_rollout.argtypes = [C.POINTER(RolloutArgs)]
+    lib.v2xsim_rollout.restype = C.c_int
     for f in (lib.v2xsim_observe_packed, lib.v2xsim_positions, lib.v2xsim_advance):
         f.restype = None
     for f in (lib.v2xsim_channels, lib.v2xsim_reward, lib.v2xsim_interference, lib.v2xsim_observe, lib.v2xsim_set_threads,
@@ -73,8 +75,29 @@ class AdvanceArgs(C.Structure):
                                              "xe", "mask", "col", "regular", "scratch")])
 
 
+class RolloutArgs(C.Structure):
+    """v2xsim_rollout_args of include/v2xsim.h (same order)"""
+    _fields_ = ([(k, C.c_int32) for k in ("n", "rb", "n_lanes", "T", "n_actions", "pad_")]
+                + [(k, C.c_double) for k in ("timestep", "width", "height")]
+                + [(k, C.c_void_p) for k in ("up", "down", "left", "right", "vel", "dest")]
+                + [(k, C.c_double) for k in ("p_v2v", "p_v2i", "veh_gain", "veh_nf", "sig2", "bs_gain", "bs_nf")]
+                + [(k, C.c_void_p) for k in ("keys", "mtpos", "xy", "dirs", "v2i_shadow", "v2v_shadow", "v2v_abs", "v2i_abs", "v2v_ff",
+                                             "v2i_ff", "interf_db", "state", "adj", "xe", "mask", "col", "regular",
+                                             "interference", "v2i_interf", "v2v_interf", "np_key", "np_pos")]
+                + [(k, C.c_double) for k in ("eps_max", "eps_min", "eps_per_step", "eps_steps")]
+                + [("step_no0", C.c_int64)]
+                + [(k, C.c_void_p) for k in ("predict", "predict_ctx", "xe_pin", "col_pin", "q_pin", "t_xe", "t_xe_next", "t_col", "t_mask",
+                                             "t_regular", "t_action", "t_v2v_rate", "t_v2i_rate", "n_greedy")]
+                + [("eps_last", C.c_double)])
+
+
 def available():
     return _load() is not None
+
+
+def rollout(args):
+    """v2xsim_rollout (include/v2xsim.h): T sequential transitions of ONE simulator in one call; -> its return code"""
+    return int(_load().v2xsim_rollout(C.byref(args)))
 
 
 def _d(a):

@@ -232,6 +232,43 @@ class DeviceReplay(object):
         _lib.check(self._lib, rc, None)
         return out
 
+    def _gather_many(self, jobs, idx_dev, k):
+        """_gather of several storage tensors by the same index list as ONE launch (v2x_gather_rows_multi): the five gathers
+        of a minibatch were five launches and five library calls per replay step."""
+        torch = self.torch
+        outs = []
+        n = len(jobs)
+        key = ("jobs", k, tuple(name for _, name in jobs))
+        tab = self._bufs.get(key)
+        if tab is None or any(tab[3][j] != jobs[j][0].data_ptr() for j in range(n)):      # (storage re-allocated by _grow: new table)
+            src_p, dst_p, rb = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+            for j, (src, name) in enumerate(jobs):
+                bk = (name, k)
+                if bk not in self._bufs:
+                    self._bufs[bk] = torch.empty((k,) + tuple(src.shape[1:]), dtype=src.dtype, device=self.device)
+                src_p[j], dst_p[j] = src.data_ptr(), self._bufs[bk].data_ptr()
+                rb[j] = src[0].numel() * src.element_size() if src.dim() > 1 else src.element_size()
+            tab = self._bufs[key] = (src_p, dst_p, rb, [src.data_ptr() for src, _ in jobs])
+        rc = self._lib.v2x_gather_rows_multi(n, tab[0], tab[1], tab[2], idx_dev.data_ptr(), k, current_stream_ptr(self.device.index))
+        _lib.check(self._lib, rc, None)
+        for _, name in jobs:
+            outs.append(self._bufs[(name, k)])
+        return outs
+
+    def q_stats(self, y, k, n_channels):
+        """[2, n] float64 device tensor: per link the SUM of all entries of the k fitted targets y [k * n, C] and the sum of their
+        per-sample maxima (BS_brain.py:743-746 divides by k * C and by k) -- one launch (v2x_q_stats)."""
+        # every call gets a row of its own (a deferred caller reads a whole episode's rows at the end): rows are never reused, an
+        # exhausted block is simply replaced -- views of the old one keep it alive
+        blk = self._bufs.get(('qstats',))
+        if blk is None or blk[1] == blk[0].shape[0]:
+            blk = self._bufs[('qstats',)] = [self.torch.empty((64, 2, self.n), dtype=self.torch.float64, device=self.device), 0]
+        out = blk[0][blk[1]]
+        blk[1] += 1
+        rc = self._lib.v2x_q_stats(y.data_ptr(), k, self.n, n_channels, out.data_ptr(), current_stream_ptr(self.device.index))
+        _lib.check(self._lib, rc, None)
+        return out
+
     def _upload_indices(self, slots):
         """The storage slots of a minibatch where the gather kernels can read them: one of four PINNED host buffers, which the
         device addresses directly (unified addressing) -- 16 KB read over the bus by the kernels themselves instead of a copy
@@ -290,12 +327,13 @@ class DeviceReplay(object):
         else:
             slots = self.logical_to_slot(idx)
             idx_dev = self._upload_indices(slots)
-        xe = self._gather(self.xe, idx_dev, k, 'xe').view(k * self.n, 16)
-        xe_next = self._gather(self.xe_next, idx_dev, k, 'xe_next').view(k * self.n, 16)
-        action = self._gather(self.action, idx_dev, k, 'action')
-        reward = self._gather(self.reward, idx_dev, k, 'reward')
-        if self._regular[slots].all():                             # every sampled graph has in-degree n-2: CSR as stored
-            col = self._gather(self.col, idx_dev, k, 'col').view(-1)
+        regular = bool(self._regular[slots].all())
+        xe, xe_next, action, reward, last = self._gather_many(
+            [(self.xe, 'xe'), (self.xe_next, 'xe_next'), (self.action, 'action'), (self.reward, 'reward'),
+             (self.col, 'col') if regular else (self.mask, 'mask')], idx_dev, k)
+        xe, xe_next = xe.view(k * self.n, 16), xe_next.view(k * self.n, 16)
+        if regular:                                                # every sampled graph has in-degree n-2: CSR as stored
+            col = last.view(-1)
             self._indices_consumed()
             rp, max_edges = self.row_ptr(k), self.n_edges
             dbs = self._db_cache.get(k)                # the gather buffers are reused: so are the batch descriptors
@@ -303,7 +341,7 @@ class DeviceReplay(object):
                 dbs = self._db_cache[k] = tuple(DeviceBatch.from_tensors(k, self.n, t, rp, col, max_edges) for t in (xe, xe_next))
             return dbs[0], dbs[1], action, reward
         else:                                                      # expand the source masks (ascending sources per row)
-            masks = self._gather(self.mask, idx_dev, k, 'mask')                                  # [k, n(q)]
+            masks = last                                                                          # [k, n(q)]
             self._indices_consumed()
             bits = ((masks[:, :, None] >> torch.arange(self.n, device=self.device, dtype=torch.int32)) & 1).bool()
             col = bits.nonzero()[:, 2].to(torch.int32).contiguous()                               # (graph, q, p) order

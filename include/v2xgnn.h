@@ -122,6 +122,15 @@ float* v2x_grad_ptr(v2x_model* m);
  * driven by v2x_forward_backward / v2x_train_step / v2x_dqn_step (they run their own forward).      */
 int  v2x_forward(v2x_model* m, const v2x_batch* b, float* q_out, int q_on_device, void* stream);
 
+/* v2x_forward as a plain callback `int (*)(void*)` for host code that takes one: the closure holds the arguments (the batch
+ * descriptor may point into page-locked host buffers the caller refills between calls, on_device = 1, see
+ * v2x_device_addressable; q_on_device = 0 copies Q back and synchronises).  The rollout of ONE simulator as a single
+ * library call (include/v2xsim.h, v2xsim_rollout: BS_brain.py:308-352 inside :409-553) scores its observations through it.   */
+typedef struct v2x_forward_closure {
+  v2x_model* m; v2x_batch b; float* q_out; int32_t q_on_device; int32_t pad_; void* stream;
+} v2x_forward_closure;
+int  v2x_forward_call(void* closure);
+
 /* one fit step = forward + Huber + backward + Keras-Adam (Model.fit, BS_brain.py:218-223).
  *   y[R][C] targets;  loss_out[n_nodes] per-output Huber means (History 'D{k}_Decide_Output_loss'),
  *   may be NULL.  n_graphs_global: B of the GLOBAL batch (== b->n_graphs on one GPU): the
@@ -191,6 +200,14 @@ int  v2x_device_addressable(const void* p);
 /* dst[i][0..row_bytes) = src[idx[i]][0..row_bytes)   (row_bytes a multiple of 4)               */
 int  v2x_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_idx, int64_t row_bytes,
                      void* stream);
+/* up to 8 such gathers by the SAME index list as one launch (a replay minibatch: s, s', actions, rewards, CSR sources):
+ * dst[j][i][0..row_bytes[j]) = src[j][idx[i]][0..row_bytes[j]).  src / dst / row_bytes: [host] arrays of n_jobs entries.       */
+int  v2x_gather_rows_multi(int32_t n_jobs, const void* const* src, void* const* dst, const int64_t* row_bytes,
+                           const int32_t* idx, int64_t n_idx, void* stream);
+/* Q statistics of the fitted targets y[n_graphs][n_nodes][n_channels] (BS_brain.py:730-746) as float64 sums per link:
+ * out[0][k] = sum over samples and channels, out[1][k] = sum over samples of the per-sample maximum; the caller divides
+ * (by n_graphs * n_channels, by n_graphs).  out: [dev] [2][n_nodes] doubles.  Deterministic (fixed summation order).       */
+int  v2x_q_stats(const float* y, int32_t n_graphs, int32_t n_nodes, int32_t n_channels, double* out, void* stream);
 /* y = q (online net on s), except y[b][k][action[b][k]] = reward[b] + gamma * max_c q_next[b][k][c]
  * (q_next: target net on s'); evaluated like the reference's numpy-1.x scalar expression (float64
  * product and sum, rounded to fp32 once).  q, q_next, y: [n_graphs*n_nodes][n_channels]; action: [n_graphs][n_nodes];

@@ -13,7 +13,7 @@
 extern "C" {
 #endif
 
-int v2xsim_abi(void);                       /* 2 */
+int v2xsim_abi(void);                       /* 3 */
 void v2xsim_set_threads(int n);             /* threads a loop may use, the caller included */
 int v2xsim_max_threads(void);
 
@@ -68,6 +68,41 @@ typedef struct {
 void v2xsim_advance(const v2xsim_advance_args* a);
 int v2xsim_advance_start(const v2xsim_advance_args* a);
 int v2xsim_advance_wait(int ticket);
+
+/* The reference's own rollout shape as ONE call (Agent.generate_d2d_transition, BS_brain.py:409-553, called with 50 transitions
+ * before every replay, :818-832): ONE simulator, T sequential transitions -- epsilon draw / random actions on numpy's process-wide
+ * MT19937 (np_key / np_pos: get_state / set_state around the call; random_sample and randint(0, n_actions) draw for draw), or the
+ * predict through `predict(predict_ctx)` (the caller's closure scores the ONE graph whose packed observation this call has put
+ * into xe_pin [n][16] / col_pin [n (n-2)] and leaves Q in q_pin [n][n_actions]; 0 = ok) with np.argmax's first maximiser;
+ * v2xsim_reward's rates on the current channels; one v2xsim_advance step -- cut over a team of threads (v2xsim_set_threads)
+ * that work ahead of the caller while it waits for the predict.  The environment (E = 1 arrays of v2xsim_advance_args, here
+ * updated IN PLACE to the state after the last transition) and both random streams end exactly where T single steps leave
+ * them; the t_* arrays receive the T transitions.  Returns T; -1 bad sizes; -2 no memory; -3 another rollout is running;
+ * -4 - t: transition t wanted a predict on a graph with a link that is its own receiver (regular == 0) or predict is null;
+ * -1000 - t: the predict of transition t failed.  After an early return the environment stands at the state after the transitions
+ * that were completed (t of them), numpy's stream after the failed transition's epsilon draw.                                */
+typedef int (*v2xsim_predict_fn)(void* ctx);
+typedef struct {
+  int32_t n, rb, n_lanes, T, n_actions, pad_;
+  double timestep, width, height;
+  const double *up, *down, *left, *right;
+  const double* vel; const int64_t* dest;
+  double p_v2v, p_v2i, veh_gain, veh_nf, sig2, bs_gain, bs_nf;
+  /* the environment, in and out */
+  uint32_t* keys; int32_t* mtpos; double* xy; int8_t* dirs; double* v2i_shadow; double* v2v_shadow;
+  double *v2v_abs, *v2i_abs, *v2v_ff, *v2i_ff, *interf_db, *state, *adj;
+  float* xe; int32_t* mask; int32_t* col; uint8_t* regular;
+  double *interference, *v2i_interf, *v2v_interf;      /* [rb], [rb], [n]: v2xsim_reward's side outputs of the LAST transition */
+  /* the policy */
+  uint32_t* np_key; int32_t* np_pos;
+  double eps_max, eps_min, eps_per_step, eps_steps; int64_t step_no0;
+  v2xsim_predict_fn predict; void* predict_ctx; float* xe_pin; int32_t* col_pin; const float* q_pin;
+  /* out: the T transitions, and what the agent keeps */
+  float* t_xe; float* t_xe_next; int32_t* t_col; int32_t* t_mask; uint8_t* t_regular; int64_t* t_action;
+  double* t_v2v_rate; double* t_v2i_rate;               /* [T][n], [T][min(rb, n)] */
+  int32_t* n_greedy; double eps_last;
+} v2xsim_rollout_args;
+int v2xsim_rollout(v2xsim_rollout_args* a);
 
 /* Memory.sample's draw (BS_brain.py:261): numpy's legacy np.random.choice(n, k, replace=False) = permutation(n)[:k] on the
  * process-wide RandomState's MT19937 state (key[624], pos: get_state / set_state around the call), draw for draw; scratch [n]

@@ -406,10 +406,13 @@ def test_host_batches_are_validated_before_any_copy():
 
 
 @pytest.mark.parametrize("N,F,B,use_graph", [(20, 64, 48, False), (20, 64, 48, True), (4, 16, 64, False)])
-def test_two_phase_step_equals_single_call(N, F, B, use_graph):
+def test_two_phase_step_equals_single_call(N, F, B, use_graph, monkeypatch):
     """v2x_forward_backward_phase (data-parallel overlap: Dense bucket final after phase 0, graph-layer bucket after
-    phase 1) leaves the same gradient and losses as v2x_forward_backward."""
+    phase 1) leaves the same gradient and losses as v2x_forward_backward.  (V2X_MLP_WG0=1: at this batch size the single call
+    would otherwise hand Dense-0's weight gradient to k_wgrad -- another summation order, tests/test_gpu_dense0_role.py -- while
+    the phases keep it in the MLP launch, whose end completes the Dense bucket.)"""
     import torch
+    monkeypatch.setenv("V2X_MLP_WG0", "1")
     spec = GnnSpec(n_nodes=N, feat_dim=F)
     rng = np.random.default_rng(17)
     weights = oc.params_to_list(f32_params(spec, rng))

@@ -422,3 +422,45 @@ def test_forward_to_host_refuses_pageable_host_memory():
     want = eng.forward(DeviceBatch.from_tensors(B, n, xe.cuda(), rp.cuda(), col.cuda(), 2 * n)).cpu().numpy()
     assert np.array_equal(got, want)
     eng.close()
+
+
+@pytest.mark.parametrize("n_veh,feat,batch", [(4, 16, 64), (20, 64, 96)])
+def test_native_rollout_of_one_simulator_is_the_per_transition_rollout_bitwise(n_veh, feat, batch, monkeypatch):
+    """the reference's loop shape (ONE simulator, 50 sequential transitions with a B = 1 predict each,
+    BS_brain.py:409-553, :818-832) as one library call per rollout (v2xsim_rollout; the predict is v2x_forward_call on pinned
+    buffers; the simulator step is computed by a team of threads while the predict is in flight) against the same agent with
+    V2X_RL_NATIVE_ROLLOUT=0 (one _packed_iteration per transition): rewards, the bytes of the replay memory, losses, Q
+    statistics, weights, both random streams -- bit for bit over two episodes (a reset in between)."""
+    from v2xgnn.rl import Agent, RL_Config, native_sim
+    from v2xgnn.rl.train import start_env_batched
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+
+    def run(native):
+        random.seed(41)
+        np.random.seed(41)
+        monkeypatch.setenv("V2X_RL_NATIVE_ROLLOUT", "1" if native else "0")
+        native_sim.set_threads(6 if native else 1)
+        env = start_env_batched(n_veh, 1, 41, lookahead=not native)
+        cfg = RL_Config()
+        cfg.set_train_value(feat, 0.5, batch, 1, 0.1)
+        agent = Agent(n_veh, env.n_RB, env.n_Neighbor, feat, env, cfg, seed=41, device_replay=True)
+        loss, reward_step, _, q_mean, q_max, _, _ = agent.train(2, 8)
+        rep = agent.device_replay
+        rep.flush()
+        k = rep.size
+        mem = [t[:k].cpu().numpy() for t in (rep.xe, rep.xe_next, rep.col, rep.mask, rep.action, rep.reward)]
+        return env, agent, loss, reward_step, q_mean, np.concatenate([a.ravel() for a in agent.brain.model.get_weights()]), mem, np.random.get_state()
+
+    env_n, ag_n, loss_n, rew_n, qm_n, w_n, mem_n, np_n = run(True)
+    env_p, ag_p, loss_p, rew_p, qm_p, w_p, mem_p, np_p = run(False)
+    native_sim.set_threads(1)
+    assert getattr(ag_n, "_native_io", None) is not None and "closure" in ag_n._native_io
+    assert getattr(ag_p, "_native_io", None) is None
+    assert ag_n.num_step == ag_p.num_step == 2 * 8 * 50 and ag_n.epsilon == ag_p.epsilon
+    assert np.array_equal(rew_n, rew_p)
+    for a, b in zip(mem_n, mem_p):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert np.array_equal(loss_n, loss_p) and np.array_equal(qm_n, qm_p) and np.array_equal(w_n, w_p)
+    assert np.array_equal(env_n.pos, env_p.pos) and np.array_equal(env_n._mt_keys, env_p._mt_keys)
+    assert np_n[2] == np_p[2] and np.array_equal(np_n[1], np_p[1])

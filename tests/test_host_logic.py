@@ -44,9 +44,14 @@ def test_simulator_library_exports_every_declared_symbol():
     lib = C.CDLL(path)
     for name in sorted(declared):
         assert hasattr(lib, name), "libv2xsim.so does not export %s" % name
-    assert lib.v2xsim_abi() == 2 and native_sim.available()
+    assert lib.v2xsim_abi() == 3 and native_sim.available()
     a = native_sim.AdvanceArgs()
     assert [f[0] for f in a._fields_][:4] == ["E", "n", "rb", "n_lanes"] and C.sizeof(a) == 4 * 4 + 3 * 8 + 6 * 8 + 5 * 8 + 24 * 8
+    # v2xsim_rollout_args: 6 int32, 3 + 7 + 4 doubles, 6 + 22 + 14 pointers, step_no0, eps_last -- field for field the header's order
+    r = native_sim.RolloutArgs()
+    assert C.sizeof(r) == 6 * 4 + (3 + 7 + 4) * 8 + (6 + 22 + 14) * 8 + 8 + 8
+    names = re.findall(r'\b([A-Za-z_0-9]+)\s*[;,]', re.search(r'typedef struct \{([^}]*)\} v2xsim_rollout_args;', hdr, re.S).group(1).replace('*', ' '))
+    assert names == [f[0] for f in r._fields_], (names, [f[0] for f in r._fields_])
 
 
 def test_no_cpu_fallback():

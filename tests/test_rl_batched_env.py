@@ -562,3 +562,100 @@ def test_two_host_threads_stepping_two_simulators():
         for s in seq:
             for a, b in zip(seq[s][0], par[s][0]):
                 assert np.array_equal(a, b), (rep, s)
+
+
+@pytest.mark.parametrize("threads,n", [(1, 20), (6, 20), (4, 8), (12, 12)])
+def test_native_rollout_is_T_single_steps(threads, n):
+    """v2xsim_rollout (the reference's loop shape -- ONE simulator, T sequential transitions with a B = 1 predict
+    each, BS_brain.py:409-553 -- as one library call with the simulator step cut over a team of threads that works ahead of the
+    caller): transitions, rates, the simulator's every array, its MT19937 stream AND numpy's process-wide stream (epsilon draws,
+    random actions) bit-identical to T iterations of observe -> epsilon-greedy -> act in Python.  The predict is a ctypes
+    callback here (a deterministic function of the packed observation); on the GPU it is v2x_forward_call."""
+    import ctypes
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    T, C = 37, 4
+    ne = n * (n - 2)
+
+    def fake_q(xe, col):
+        s = xe[:, :13].astype(np.float64).sum(axis=1)[:, None] * (np.arange(C)[None, :] + 1.0) + col[:C].sum()
+        return np.sin(s).astype(np.float32)
+
+    def make():
+        env = BatchedEnviron(*_lanes(), 750, 1299, n_envs=1, seeds=[1234 + n], lookahead=False)
+        env.new_random_game(n)
+        env.act(np.zeros((1, n, 1), int))
+        return env
+    pol = dict(eps_max=0.9, eps_min=0.01, eps_per_step=0.8 / 30, eps_steps=30.0, step_no0=3)
+    # ---- T single steps in Python
+    native_sim.set_threads(1)
+    ref = make()
+    np.random.seed(99)
+    rec = {k: [] for k in ("xe", "xe_next", "col", "mask", "action", "v2v", "v2i")}
+    n_greedy = 0
+    for t in range(T):
+        xe, mask, col, regular = ref.observe_packed(C)
+        assert regular.all()
+        step_no = pol["step_no0"] + t
+        eps = pol["eps_max"] - pol["eps_per_step"] * step_no if step_no < pol["eps_steps"] else pol["eps_min"]
+        if np.random.random() < eps:
+            a = np.random.randint(0, C, size=(n, 1))
+        else:
+            a = np.argmax(fake_q(xe[0], col[0]), axis=1)[:, None]
+            n_greedy += 1
+        v2v, v2i, _ = ref.act(a[None])
+        for k, v in zip(("xe", "col", "mask", "action", "v2v", "v2i"), (xe[0], col[0], mask[0], a[:, 0], v2v[0], v2i[0])):
+            rec[k].append(np.array(v, copy=True))
+        rec["xe_next"].append(ref.observe_packed(C)[0][0].copy())
+    ref_np = np.random.get_state()
+    assert 0 < n_greedy < T
+    # ---- the same as one library call
+    native_sim.set_threads(threads)
+    env = make()
+    np.random.seed(99)
+    xe_pin, col_pin, q_pin = np.zeros((n, 16), np.float32), np.zeros(ne, np.int32), np.zeros((n, C), np.float32)
+
+    def predict(_ctx):
+        q_pin[:] = fake_q(xe_pin, col_pin)
+        return 0
+    cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(predict)
+    out = env.native_rollout(T, C, dict(pol, predict=ctypes.cast(cb, ctypes.c_void_p).value, predict_ctx=None,
+                                        xe_pin=xe_pin, col_pin=col_pin, q_pin=q_pin))
+    native_sim.set_threads(1)
+    assert out["done"] == T and out["n_greedy"] == n_greedy
+    for k, o in (("xe", "xe"), ("xe_next", "xe_next"), ("col", "col"), ("mask", "mask"), ("action", "action"), ("v2v", "v2v_rate"), ("v2i", "v2i_rate")):
+        assert np.array_equal(np.stack(rec[k]), out[o]), k
+    got_np = np.random.get_state()
+    assert got_np[2] == ref_np[2] and np.array_equal(got_np[1], ref_np[1])
+    for k in ("pos", "dirs", "_v2i_shadow", "_v2v_shadow", "V2V_channels_abs", "V2I_channels_abs", "V2V_channels_with_fastfading",
+              "V2I_channels_with_fastfading", "V2V_Interference_all", "_mt_keys", "_mt_pos", "V2I_Interference", "V2V_Interference"):
+        assert np.array_equal(np.asarray(getattr(env, k)), np.asarray(getattr(ref, k))), k
+    for a, b in zip(env.observe_packed(C), ref.observe_packed(C)):
+        assert np.array_equal(a, b)
+    # ... and both go on identically
+    act = np.ones((1, n, 1), int)
+    for _ in range(3):
+        ra, rb_ = env.act(act), ref.act(act)
+        assert all(np.array_equal(x, y) for x, y in zip(ra, rb_))
+    # a failing predict: the simulator stands where the completed transitions left it
+    env2, ref2 = make(), make()
+    np.random.seed(7)
+    calls = [0]
+
+    def flaky(_ctx):
+        calls[0] += 1
+        if calls[0] == 3:
+            return 1
+        q_pin[:] = fake_q(xe_pin, col_pin)
+        return 0
+    cb2 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(flaky)
+    native_sim.set_threads(threads)
+    out2 = env2.native_rollout(T, C, dict(pol, eps_max=0.3, predict=ctypes.cast(cb2, ctypes.c_void_p).value, predict_ctx=None,
+                                          xe_pin=xe_pin, col_pin=col_pin, q_pin=q_pin))
+    native_sim.set_threads(1)
+    assert out2["rc"] <= -1000 and 0 <= out2["done"] < T and out2["done"] == -1000 - out2["rc"]
+    for t in range(out2["done"]):
+        ref2.act(out2["action"][t][None, :, None])
+    for k in ("pos", "V2V_channels_with_fastfading", "_mt_keys", "_mt_pos"):
+        assert np.array_equal(np.asarray(getattr(env2, k)), np.asarray(getattr(ref2, k))), k

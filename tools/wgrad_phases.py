@@ -11,7 +11,7 @@ os.environ["V2X_FUSED_TS"] = "1"
 import bench  # noqa: E402
 from v2xgnn import GnnSpec, PackedBatch, GnnEngine  # noqa: E402
 
-N, F, B = 20, 64, 4096
+N, F, B = 20, 64, int(os.environ.get("PHASES_BATCH", "4096"))
 rng = np.random.default_rng(1001)
 x, e, adj, y = bench.synth_batch(rng, B, N)
 eng = GnnEngine(GnnSpec(n_nodes=N, feat_dim=F))

@@ -559,6 +559,10 @@ struct MlpArgs {
   // tile), so that a wave's access is 1 KiB contiguous instead of 64 pieces of 16 bytes from 16 rows (the texture
   // path handles a wave's request line by line).  0: row-major, else the number of groups per slot.
   int frag_groups;
+  // k_mlp_train_wg inside a DQN replay step (v2x_dqn_step): the targets are formed in the kernel -- y = q (THIS forward's
+  // output, as Keras' fit sees the prediction it was handed, BS_brain.py:664-692, :728) except y[action[row]] = tq[row] -- and
+  // written where q would go; `y` is not read.  The separate online MLP forward and the target kernel's pass over q drop out.
+  const float* tq; const int32_t* action;
 };
 
 template <int F>    // F == 0: "tail" form without the Dense-0 image (wide features: Dense-0 runs in k_wide_gemm)
@@ -1785,13 +1789,18 @@ __global__ __launch_bounds__(256) void k_gather_rows_multi(GatherJobs jobs, cons
 }
 
 // Q statistics of a minibatch of fitted targets y[B][N][C] (BS_brain.py:743-746: per link the mean of all entries and the mean of
-// the per-sample maxima), as float64 SUMS per link: out[0][k] = sum_b sum_c y, out[1][k] = sum_b max_c y.  One workgroup per link,
-// every thread a fixed subset of the samples, the partials combined through LDS in a fixed order: deterministic.
-__global__ __launch_bounds__(256) void k_q_stats(const float* y, int B, int N, int C, double* out) {
+// the per-sample maxima), as float64 SUMS per link: out[0][k] = sum_b sum_c y, out[1][k] = sum_b max_c y.  QS_PARTS workgroups
+// per link, each a fixed range of the samples (every thread a fixed subset, combined through LDS in a fixed order); the last
+// one to arrive adds the parts in index order: deterministic.  (One workgroup per link was 17 us at 4096 samples x 20 links: 20
+// workgroups walking rows 320 bytes apart.)  part: [N][QS_PARTS][2] doubles, cnt: [N] ints, zero before the first launch.
+constexpr int QS_PARTS = 8;
+__global__ __launch_bounds__(256) void k_q_stats(const float* y, int B, int N, int C, double* out, double* part, unsigned* cnt) {
   __shared__ double s_all[256], s_max[256];
-  const int k = blockIdx.x;
+  __shared__ unsigned s_last;
+  const int k = blockIdx.x, pz = blockIdx.y;
+  const int b0 = (int)((int64_t)B * pz / QS_PARTS), b1 = (int)((int64_t)B * (pz + 1) / QS_PARTS);
   double a = 0.0, m = 0.0;
-  for (int b = threadIdx.x; b < B; b += 256) {
+  for (int b = b0 + threadIdx.x; b < b1; b += 256) {
     const float* row = y + ((int64_t)b * N + k) * C;
     float mx = row[0];
     double s = (double)row[0];
@@ -1805,7 +1814,34 @@ __global__ __launch_bounds__(256) void k_q_stats(const float* y, int B, int N, i
     if ((int)threadIdx.x < st) { s_all[threadIdx.x] += s_all[threadIdx.x + st]; s_max[threadIdx.x] += s_max[threadIdx.x + st]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { out[k] = s_all[0]; out[N + k] = s_max[0]; }
+  if (threadIdx.x == 0) {
+    part[((int64_t)k * QS_PARTS + pz) * 2] = s_all[0];
+    part[((int64_t)k * QS_PARTS + pz) * 2 + 1] = s_max[0];
+    __threadfence();
+    s_last = atomicAdd(cnt + k, 1u) == QS_PARTS - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __threadfence();
+    double ta = 0.0, tm = 0.0;
+    for (int q = 0; q < QS_PARTS; ++q) {
+      ta += __builtin_nontemporal_load(part + ((int64_t)k * QS_PARTS + q) * 2);
+      tm += __builtin_nontemporal_load(part + ((int64_t)k * QS_PARTS + q) * 2 + 1);
+    }
+    out[k] = ta; out[N + k] = tm;
+    cnt[k] = 0u;                                                  // re-armed for the next launch
+  }
+}
+
+// the replaced entry of the target rule alone (MlpArgs::tq): tq[row] = r[graph] + gamma * max_c q_next[row][c], evaluated like
+// k_dqn_targets below
+__global__ __launch_bounds__(256) void k_dqn_tq(const float* qn, const double* reward, double gamma, int n_rows, int n_nodes, int C,
+                                                float* tq) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_rows) return;
+  float mx = qn[(int64_t)row * C];
+  for (int c = 1; c < C; ++c) mx = fmaxf(mx, qn[(int64_t)row * C + c]);
+  tq[row] = (float)(reward[row / n_nodes] + gamma * (double)mx);
 }
 
 // one thread per (graph, node) row

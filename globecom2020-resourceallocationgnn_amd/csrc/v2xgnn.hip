@@ -119,6 +119,8 @@ struct v2x_model {
   bool capturing = false;
   // wide path, single-GPU training: the layers' weight gradients are collected and launched as ONE grid (wide_wgrad_flush)
   bool dense0_out_now = false;                  // inside a backward pass whose MLP launch leaves Dense-0's weight gradient to k_wgrad
+  // inside a DQN replay step whose MLP launch forms the targets itself (MlpArgs::tq): replaced entries, actions, where y goes
+  const float* dqn_tq = nullptr; const int32_t* dqn_action = nullptr; float* dqn_y = nullptr;
   bool wide_merge_now = false;                  // inside a backward pass that merges
   bool bucketed = false;                        // data parallelism wants each layer's gradient as soon as it is final
   bool fuse_adam_now = false;                   // ... and applies Adam in the weight-gradient epilogues (WideWgradArgs::adam)
@@ -1892,6 +1894,10 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   struct MergeGuard { v2x_model* m; ~MergeGuard() { m->wide_merge_now = false; } } merge_guard{m};
   if (m->frag_live && !frag_layout(m, d, r)) FAIL(m, V2X_ESTATE, "backward: the saved forward is fragment-major, this backward cannot read it");
   a.frag_groups = m->frag_live ? d.B / FZ_TG : 0;
+  if (m->dqn_tq) {
+    if (!mlp_wg) FAIL(m, V2X_ESTATE, "backward: in-kernel DQN targets need the k_mlp_train_wg path");
+    a.tq = m->dqn_tq; a.action = m->dqn_action; a.q = m->dqn_y;
+  }
   // (the weight-gradient launch below must be the merged one of wgrad_gnn_all: one stream, no per-stage split)
   m->dense0_out_now = mlp_wg && !two && r.g0 == 0 && r.ng == d.B && dense0_rides(m, d, x);
   struct D0Guard { v2x_model* m; ~D0Guard() { m->dense0_out_now = false; } } d0_guard{m};
@@ -2501,15 +2507,31 @@ int v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, const
   key.ptrs[11] = target->q;
   key.gen = target->ws_gen;                              // the graph bakes in EVERY workspace pointer of the target (h, a, z,
   key.scalar = gamma;                                    // masks, ...), not q only
+  // Narrow models (k_mlp_train_wg): the online network's decision MLP runs ONCE, inside the training launch, which forms the
+  // targets from its own forward output (MlpArgs::tq) -- as Keras' fit re-computes the prediction it was handed as target, so
+  // that the untouched entries carry exactly zero error (BS_brain.py:664-692, :728); the separate MLP forward of the online
+  // network, and the target kernel's pass over q, are gone (38 us of a 520-us step at 20 links, batch 4096).  V2X_DQN_FUSED_TARGETS=0:
+  // the three-launch form (forward, k_dqn_targets, training launch on y).
+  static const int fuse_env = env_int("V2X_DQN_FUSED_TARGETS", 1);
+  const bool fuse_targets = fuse_env && mlp_wg_path(online) && !is_wide(online) && online->C == 4;
   CHK(run_maybe_graph(online, st, key, [&]() -> int {
     target->capturing = online->capturing;
     int rc = run_forward(target, st, dn, all, true);
     target->capturing = false;
     if (rc) { online->err = target->err; return rc; }
-    CHK(run_forward(online, st, ds, all, true));
-    hipLaunchKernelGGL(k_dqn_targets, dim3((ds.R + 255) / 256), dim3(256), 0, st, online->q, target->q, action, reward, gamma,
-                       ds.R, online->N, online->C, y);
-    return run_backward(online, st, st, ds, all, y, n_graphs_global);
+    if (!fuse_targets) {
+      CHK(run_forward(online, st, ds, all, true));
+      hipLaunchKernelGGL(k_dqn_targets, dim3((ds.R + 255) / 256), dim3(256), 0, st, online->q, target->q, action, reward, gamma,
+                         ds.R, online->N, online->C, y);
+      return run_backward(online, st, st, ds, all, y, n_graphs_global);
+    }
+    CHK(run_forward(online, st, ds, all, false));                          // graph layers only
+    float* tq = online->dq;                                                // (a workspace this path does not use otherwise: [R][C])
+    hipLaunchKernelGGL(k_dqn_tq, dim3((ds.R + 255) / 256), dim3(256), 0, st, target->q, reward, gamma, ds.R, online->N, online->C, tq);
+    online->dqn_tq = tq; online->dqn_action = action; online->dqn_y = y;
+    rc = run_backward(online, st, st, ds, all, y, n_graphs_global);
+    online->dqn_tq = nullptr; online->dqn_action = nullptr; online->dqn_y = nullptr;
+    return rc;
   }));
   CHK(launch_reduce_adam(online, st, 1, true, nullptr, loss_job(online, ds, n_graphs_global)));
   online->have_fwd = target->have_fwd = true;
@@ -2693,7 +2715,30 @@ int v2x_gather_rows_multi(int32_t n_jobs, const void* const* src, void* const* d
 int v2x_q_stats(const float* y, int32_t n_graphs, int32_t n_nodes, int32_t n_channels, double* out, void* stream) {
   v2x_model* nullm = nullptr;
   if (!y || !out || n_graphs <= 0 || n_nodes <= 0 || n_channels <= 0) FAIL(nullm, V2X_EINVAL, "q_stats: bad argument");
-  hipLaunchKernelGGL(k_q_stats, dim3(n_nodes), dim3(256), 0, (hipStream_t)stream, y, n_graphs, n_nodes, n_channels, out);
+  // scratch of the two-level sum: per (device, stream) -- launches on one stream are ordered, two streams must not share the
+  // arrival counters --, grown on demand, zeroed when allocated (the kernel re-arms its counters)
+  static std::mutex mu;
+  static std::map<std::pair<int, void*>, std::pair<void*, int>> scratch;          // -> (buffer, links it holds)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) FAIL(nullm, V2X_EHIP, "q_stats: no device");
+  double* part = nullptr;
+  unsigned* cnt = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto& e = scratch[std::make_pair(dev, stream)];
+    if (e.second < n_nodes) {
+      if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) FAIL(nullm, V2X_EHIP, "q_stats: synchronise failed");
+      if (e.first) (void)hipFree(e.first);
+      const int cap = std::max(n_nodes, 64);
+      const size_t bytes = (size_t)cap * QS_PARTS * 2 * sizeof(double) + (size_t)cap * sizeof(unsigned);
+      if (hipMalloc(&e.first, bytes) != hipSuccess) { e.first = nullptr; e.second = 0; FAIL(nullm, V2X_ENOMEM, "q_stats: scratch"); }
+      if (hipMemset(e.first, 0, bytes) != hipSuccess) FAIL(nullm, V2X_EHIP, "q_stats: memset failed");
+      e.second = cap;
+    }
+    part = (double*)e.first;
+    cnt = (unsigned*)(part + (size_t)e.second * QS_PARTS * 2);
+  }
+  hipLaunchKernelGGL(k_q_stats, dim3(n_nodes, QS_PARTS), dim3(256), 0, (hipStream_t)stream, y, n_graphs, n_nodes, n_channels, out, part, cnt);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) FAIL(nullm, V2X_EHIP, "q_stats launch failed: %s", hipGetErrorString(e));
   return V2X_OK;

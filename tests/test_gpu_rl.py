@@ -464,3 +464,41 @@ def test_native_rollout_of_one_simulator_is_the_per_transition_rollout_bitwise(n
     assert np.array_equal(loss_n, loss_p) and np.array_equal(qm_n, qm_p) and np.array_equal(w_n, w_p)
     assert np.array_equal(env_n.pos, env_p.pos) and np.array_equal(env_n._mt_keys, env_p._mt_keys)
     assert np_n[2] == np_p[2] and np.array_equal(np_n[1], np_p[1])
+
+
+def test_multi_gather_and_q_statistics_kernels():
+    """v2x_gather_rows_multi (the five gathers of a replay minibatch as one launch) against torch indexing, and v2x_q_stats (the Q
+    statistics of BS_brain.py:743-746 as float64 sums per link, two-level with a fixed order) against torch's float64 sums; twice
+    in a row (the kernel re-arms its arrival counters) and bit-identical between the two calls."""
+    import ctypes as C
+    import torch
+    import v2xgnn
+    lib = v2xgnn.load_library()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n_store, k = 1000, 333
+    srcs = [torch.randn((n_store, 20, 16), generator=g), torch.randint(0, 9, (n_store, 20), generator=g, dtype=torch.int32),
+            torch.randn(n_store, generator=g, dtype=torch.float64), torch.randint(0, 99, (n_store, 7), generator=g, dtype=torch.int32)]
+    srcs = [t.cuda() for t in srcs]
+    idx = torch.randint(0, n_store, (k,), generator=g, dtype=torch.int32).cuda()
+    dsts = [torch.empty((k,) + tuple(t.shape[1:]), dtype=t.dtype, device="cuda") for t in srcs]
+    n = len(srcs)
+    sp, dp, rb = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+    for j, (s, d) in enumerate(zip(srcs, dsts)):
+        sp[j], dp[j] = s.data_ptr(), d.data_ptr()
+        rb[j] = s[0].numel() * s.element_size() if s.dim() > 1 else s.element_size()
+    assert lib.v2x_gather_rows_multi(n, sp, dp, rb, idx.data_ptr(), k, None) == 0
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d, s[idx.long()])
+    assert lib.v2x_gather_rows_multi(9, sp, dp, rb, idx.data_ptr(), k, None) == -1
+    for B, N, Cc in ((4096, 20, 4), (7, 4, 4), (300, 31, 4)):
+        y = torch.randn((B * N, Cc), generator=g).cuda() * 3 + 1
+        out1 = torch.zeros((2, N), dtype=torch.float64, device="cuda")
+        out2 = torch.zeros_like(out1)
+        assert lib.v2x_q_stats(y.data_ptr(), B, N, Cc, out1.data_ptr(), None) == 0
+        assert lib.v2x_q_stats(y.data_ptr(), B, N, Cc, out2.data_ptr(), None) == 0
+        torch.cuda.synchronize()
+        y3 = y.view(B, N, Cc)
+        want = torch.stack([y3.sum(dim=(0, 2), dtype=torch.float64), y3.amax(dim=2).sum(dim=0, dtype=torch.float64)])
+        assert torch.equal(out1, out2)
+        assert torch.allclose(out1, want, rtol=1e-12, atol=1e-9), (B, N)

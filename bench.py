@@ -958,6 +958,8 @@ def other_workloads(args, ctx):
         if not args.no_cpu_baseline and "error" not in out[wl]:
             try:
                 out[wl]["cpu_baseline"] = cpu_leg_share(wl)
+                if not args.other_kernels:            # (the prose of the sample: 128 / 256 graphs of the share, numpy fp32 CSR oracle)
+                    out[wl]["cpu_baseline"]["sample"] = out[wl]["cpu_baseline"]["sample"].split(":")[0][:120]
             except Exception as exc:
                 out[wl]["cpu_baseline"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
     for g in (2, 4, 8):

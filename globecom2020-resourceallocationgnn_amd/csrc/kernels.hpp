@@ -560,9 +560,12 @@ struct MlpArgs {
   // path handles a wave's request line by line).  0: row-major, else the number of groups per slot.
   int frag_groups;
   // k_mlp_train_wg inside a DQN replay step (v2x_dqn_step): the targets are formed in the kernel -- y = q (THIS forward's
-  // output, as Keras' fit sees the prediction it was handed, BS_brain.py:664-692, :728) except y[action[row]] = tq[row] -- and
-  // written where q would go; `y` is not read.  The separate online MLP forward and the target kernel's pass over q drop out.
-  const float* tq; const int32_t* action;
+  // output, as Keras' fit sees the prediction it was handed, BS_brain.py:664-692, :728) except y[action[row]] = the replaced
+  // entry -- and written where q would go.  tq non-null says so; `y` then points at tq: one float4 per row, {replaced entry,
+  // action (bits), -, -} (k_dqn_tq), read by the SAME unconditional float4 load as a row of targets (a load under a branch
+  // would put a vmcnt(0) at the join in front of the next tile's prefetch: measured + 1.7 K cycles per tile).  The separate
+  // online MLP forward and the target kernel's pass over q drop out.
+  const float* tq;
 };
 
 template <int F>    // F == 0: "tail" form without the Dense-0 image (wide features: Dense-0 runs in k_wide_gemm)
@@ -1833,15 +1836,16 @@ __global__ __launch_bounds__(256) void k_q_stats(const float* y, int B, int N, i
   }
 }
 
-// the replaced entry of the target rule alone (MlpArgs::tq): tq[row] = r[graph] + gamma * max_c q_next[row][c], evaluated like
-// k_dqn_targets below
-__global__ __launch_bounds__(256) void k_dqn_tq(const float* qn, const double* reward, double gamma, int n_rows, int n_nodes, int C,
-                                                float* tq) {
+// the replaced entry of the target rule and the action, one float4 per row (MlpArgs::tq): tq[row] = {r[graph] + gamma * max_c
+// q_next[row][c] (evaluated like k_dqn_targets below), action[row] as bits, 0, 0}
+__global__ __launch_bounds__(256) void k_dqn_tq(const float* qn, const int32_t* action, const double* reward, double gamma, int n_rows,
+                                                int n_nodes, int C, float* tq) {
   const int row = blockIdx.x * 256 + threadIdx.x;
   if (row >= n_rows) return;
   float mx = qn[(int64_t)row * C];
   for (int c = 1; c < C; ++c) mx = fmaxf(mx, qn[(int64_t)row * C + c]);
-  tq[row] = (float)(reward[row / n_nodes] + gamma * (double)mx);
+  const float t = (float)(reward[row / n_nodes] + gamma * (double)mx);
+  *reinterpret_cast<float4*>(tq + (int64_t)row * 4) = make_float4(t, __int_as_float(action[row]), 0.f, 0.f);
 }
 
 // one thread per (graph, node) row

@@ -272,11 +272,7 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
     in.z0[FB] = ld4(a.xe + row * XE + 4 * kg);
 #pragma unroll
     for (int b = 0; b < FB; ++b) in.z0[FB + 1 + b] = ld4(a.agg + ho + b * hs);
-    if (a.tq) {                                          // DQN step: (replaced entry, action) instead of the targets' row
-      in.y = (f32x4){a.tq[row], __int_as_float(a.action[row]), 0.f, 0.f};
-    } else {
-      in.y = ld4(a.y + row * a.C + cq);
-    }
+    in.y = ld4(a.y + row * a.C + cq);                    // (DQN step: the row of MlpArgs::tq = {replaced entry, action, -, -})
   };
   // `in` holds tile t on entry and tile t_next on exit: the next tile's rows are requested when only Dense-0's weight
   // gradient is left to do (180 MFMAs, ~2.5 us: enough to cover the HBM round trip) -- the chain's registers are dead
@@ -335,16 +331,15 @@ __global__ __launch_bounds__(256, 1) void k_mlp_train_wg(MlpTrainWgArgs args) {
       bias[0] = ld4(smem + L::B4 + 4 * kg);
     });
     const f32x4 qv = qa[0] + bias[0];
-    f32x4 y4 = in.y;
-    if (a.tq) {                                          // (workgroup-uniform) y = q with the taken action's entry replaced
-      const int act = __float_as_int(in.y[1]);
-      const float t = in.y[0];
+    // targets: the row that was loaded, or (DQN step, workgroup-uniform) q itself with the taken action's entry replaced -- as
+    // selects, no branch: the prefetch of the next tile must not meet a join
+    const bool dqn = a.tq != nullptr;
+    const int act = __float_as_int(in.y[1]);
+    const float tq_v = in.y[0];
+    f32x4 y4;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) y4[c] = c == act ? t : qv[c];
-      if (valid && 4 * kg < a.C) st4(a.q + row * a.C + 4 * kg, y4);
-    } else if (valid && 4 * kg < a.C) {
-      st4(a.q + row * a.C + 4 * kg, qv);
-    }
+    for (int c = 0; c < 4; ++c) y4[c] = dqn ? (c == act ? tq_v : qv[c]) : in.y[c];
+    if (valid && 4 * kg < a.C) st4(a.q + row * a.C + 4 * kg, dqn ? y4 : qv);
     // ================= Huber (delta = 1); rows past the end carry a zero gradient through everything below
     f32x4 g4 = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (4 * kg < a.C) {

@@ -120,7 +120,7 @@ struct v2x_model {
   // wide path, single-GPU training: the layers' weight gradients are collected and launched as ONE grid (wide_wgrad_flush)
   bool dense0_out_now = false;                  // inside a backward pass whose MLP launch leaves Dense-0's weight gradient to k_wgrad
   // inside a DQN replay step whose MLP launch forms the targets itself (MlpArgs::tq): replaced entries, actions, where y goes
-  const float* dqn_tq = nullptr; const int32_t* dqn_action = nullptr; float* dqn_y = nullptr;
+  const float* dqn_tq = nullptr; float* dqn_y = nullptr;
   bool wide_merge_now = false;                  // inside a backward pass that merges
   bool bucketed = false;                        // data parallelism wants each layer's gradient as soon as it is final
   bool fuse_adam_now = false;                   // ... and applies Adam in the weight-gradient epilogues (WideWgradArgs::adam)
@@ -1896,7 +1896,7 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   a.frag_groups = m->frag_live ? d.B / FZ_TG : 0;
   if (m->dqn_tq) {
     if (!mlp_wg) FAIL(m, V2X_ESTATE, "backward: in-kernel DQN targets need the k_mlp_train_wg path");
-    a.tq = m->dqn_tq; a.action = m->dqn_action; a.q = m->dqn_y;
+    a.tq = m->dqn_tq; a.y = m->dqn_tq; a.q = m->dqn_y;
   }
   // (the weight-gradient launch below must be the merged one of wgrad_gnn_all: one stream, no per-stage split)
   m->dense0_out_now = mlp_wg && !two && r.g0 == 0 && r.ng == d.B && dense0_rides(m, d, x);
@@ -2526,11 +2526,11 @@ int v2x_dqn_step(v2x_model* online, v2x_model* target, const v2x_batch* s, const
       return run_backward(online, st, st, ds, all, y, n_graphs_global);
     }
     CHK(run_forward(online, st, ds, all, false));                          // graph layers only
-    float* tq = online->dq;                                                // (a workspace this path does not use otherwise: [R][C])
-    hipLaunchKernelGGL(k_dqn_tq, dim3((ds.R + 255) / 256), dim3(256), 0, st, target->q, reward, gamma, ds.R, online->N, online->C, tq);
-    online->dqn_tq = tq; online->dqn_action = action; online->dqn_y = y;
+    float* tq = online->dq;                                                // (a workspace this path does not use otherwise: [R][4])
+    hipLaunchKernelGGL(k_dqn_tq, dim3((ds.R + 255) / 256), dim3(256), 0, st, target->q, action, reward, gamma, ds.R, online->N, online->C, tq);
+    online->dqn_tq = tq; online->dqn_y = y;
     rc = run_backward(online, st, st, ds, all, y, n_graphs_global);
-    online->dqn_tq = nullptr; online->dqn_action = nullptr; online->dqn_y = nullptr;
+    online->dqn_tq = nullptr; online->dqn_y = nullptr;
     return rc;
   }));
   CHK(launch_reduce_adam(online, st, 1, true, nullptr, loss_job(online, ds, n_graphs_global)));

@@ -73,6 +73,7 @@ struct v2x_model {
   unsigned short* gate_bits = nullptr;   // ReLU' gates of the fused forward for the fused backward: [L][gate_stride]
   int64_t gate_stride = 0;               // ushorts per stage: N x ceil(B / 16) x 64 <= 4 R + 64 N
   hipStream_t side = nullptr;   // weight-gradient kernels run here, forked/joined around the data chain
+  hipStream_t cap = nullptr;    // hipGraphs are recorded on this stream and launched on the caller's (run_maybe_graph)
   std::vector<hipEvent_t> ev;   // fork / per-stage / join events of the side stream
   float* loss_dev = nullptr;
   float* loss_part = nullptr;  // 64 partial sums + the arrival counter of the split loss reduction
@@ -1973,8 +1974,13 @@ int emit_loss(v2x_model* m, float* loss_out, int loss_on_device, hipStream_t st)
 }
 
 // Run `body` either eagerly or through a cached hipGraph keyed on the pointers / sizes it bakes in.
+// Capture happens on a PRIVATE stream (m->cap), not on the caller's: a hipGraph does not remember the stream it was recorded on,
+// and the caller's stream is the one the host framework's collectives synchronise with -- RCCL's watchdog thread polls events
+// that were last recorded on it, and polling such an event while the stream is capturing is an error that takes the process down
+// (hipErrorCapturedEvent: seen once in five runs of tools/dp_host_overhead.py, round 6).  `st` is the caller's local stream
+// variable, taken by reference: the body's lambdas read it, so it names the capture stream while the body records.
 template <typename Body>
-int run_maybe_graph(v2x_model* m, hipStream_t st, const GraphKey& key, Body body) {
+int run_maybe_graph(v2x_model* m, hipStream_t& st, const GraphKey& key, Body body) {
   const bool want = m->cfg.use_graph && !m->prof && st != nullptr;
   if (!want) return body();
   auto it = m->graphs.find(key);
@@ -1989,11 +1995,14 @@ int run_maybe_graph(v2x_model* m, hipStream_t st, const GraphKey& key, Body body
   // make sure every lazily-sized buffer and function attribute exists before capture: run once eagerly
   // is not possible without side effects on optimizer state, so callers pre-size buffers (see below).
   hipGraph_t g = nullptr;
-  HIPCHK(m, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  hipStream_t const user = st, cap = m->cap ? m->cap : st;
+  HIPCHK(m, hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
   m->capturing = true;
+  st = cap;
   const int r = body();
+  st = user;
   m->capturing = false;
-  hipError_t e = hipStreamEndCapture(st, &g);
+  hipError_t e = hipStreamEndCapture(cap, &g);
   if (r != V2X_OK) { if (g) hipGraphDestroy(g); return r; }
   if (e != hipSuccess) FAIL(m, V2X_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
   hipGraphExec_t ge = nullptr;
@@ -2164,6 +2173,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     m->flag_host = f.host; m->flag_dev = f.dev;
   }
   if (hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess) return fail("side stream");
+  if (hipStreamCreateWithFlags(&m->cap, hipStreamNonBlocking) != hipSuccess) return fail("capture stream");
   m->ev.resize(2 * m->L + 6);
   for (auto& e : m->ev)
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail("event");
@@ -2184,6 +2194,7 @@ void v2x_destroy(v2x_model* m) {
   if (m->nbmask) hipFree(m->nbmask);
   for (auto& e : m->ev) if (e) hipEventDestroy(e);
   if (m->side) hipStreamDestroy(m->side);
+  if (m->cap) hipStreamDestroy(m->cap);
   for (float* p : ptrs) if (p) hipFree(p);
   for (float* p : m->h) if (p) hipFree(p);
   for (float* p : m->a) if (p) hipFree(p);

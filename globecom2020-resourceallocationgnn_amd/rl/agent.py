@@ -342,18 +342,25 @@ class Agent(object):
         xe, mask, col, regular = env.observe_packed(C)
         steps = self.num_Episodes * 0.8 * self.num_Train_Step * self.num_transition
         per_step = (MAX_EPSILON - MIN_EPSILON) / steps
-        actions = np.zeros((E, n, 1), int)
-        greedy = []
-        draw, base = np.random.random, self.num_step
-        for e in range(E):
-            step_no = base + e
-            self.epsilon = MAX_EPSILON - per_step * step_no if step_no < steps else MIN_EPSILON
-            if force_greedy:                           # (the native rollout took this transition's epsilon draw and found it greedy)
-                greedy.append(e)
-            elif draw() < self.epsilon:
-                actions[e] = _random_channels(n, 1, C)
-            else:
-                greedy.append(e)
+        if (not force_greedy and E >= 4 and os.environ.get("V2X_RL_NATIVE_POLICY", "0") == "1" and native_sim.available()):
+            # the E epsilon draws and the exploring simulators' randint draws in one library call on numpy's own generator state
+            # (draw for draw the loop below).  OFF by default: measured at 50 simulators, batch 4096 -- 0.87-0.93 ms per train step
+            # with it, 0.88 without: this part of the rollout runs while the GPU is still fitting and is not on the critical path
+            actions, greedy, self.epsilon = native_sim.np_policy_draws(E, n, C, MAX_EPSILON, MIN_EPSILON, per_step, steps, self.num_step)
+            greedy = list(greedy)
+        else:
+            actions = np.zeros((E, n, 1), int)
+            greedy = []
+            draw, base = np.random.random, self.num_step
+            for e in range(E):
+                step_no = base + e
+                self.epsilon = MAX_EPSILON - per_step * step_no if step_no < steps else MIN_EPSILON
+                if force_greedy:                       # (the native rollout took this transition's epsilon draw and found it greedy)
+                    greedy.append(e)
+                elif draw() < self.epsilon:
+                    actions[e] = _random_channels(n, 1, C)
+                else:
+                    greedy.append(e)
         rep.stage_early(xe, col, mask)
         if last and getattr(self, '_predraw_ok', False):
             mem_len = min(self.memory.capacity, len(self.memory.samples) + E)

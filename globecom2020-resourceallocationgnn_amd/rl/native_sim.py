@@ -52,6 +52,9 @@ def _load():
     lib.v2xsim_np_shuffle_skip.restype = C.c_int
     lib.v2xsim_rollout.argtypes = [C.POINTER(RolloutArgs)]
     lib.v2xsim_rollout.restype = C.c_int
+    lib.v2xsim_np_policy_draws.argtypes = [u32p, i32p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                           C.c_int64, ip, u8p, dp]
+    lib.v2xsim_np_policy_draws.restype = C.c_int
     for f in (lib.v2xsim_observe_packed, lib.v2xsim_positions, lib.v2xsim_advance):
         f.restype = None
     for f in (lib.v2xsim_channels, lib.v2xsim_reward, lib.v2xsim_interference, lib.v2xsim_observe, lib.v2xsim_set_threads,
@@ -244,6 +247,26 @@ def advance_start(args):
 def advance_wait(ticket=0):
     """returns when job `ticket` is done (0: whatever is in flight)"""
     return _load().v2xsim_advance_wait(int(ticket)) == 0
+
+
+def np_policy_draws(E, n, n_actions, eps_max, eps_min, eps_per_step, eps_steps, step_no0):
+    """The epsilon-greedy draws of one iteration over E simulators on np.random's process-wide generator (v2xsim_np_policy_draws):
+    -> (actions [E, n, 1] int64 -- rows of greedy simulators zero --, indices of the greedy simulators, the last epsilon).  Same
+    draws, same values, same generator state afterwards as the loop of np.random.random() / np.random.randint(0, n_actions, (n, 1))."""
+    lib = _load()
+    name, key, pos, has_gauss, cached = np.random.get_state()
+    if name != 'MT19937':
+        raise RuntimeError("np.random is not on MT19937")
+    key = np.ascontiguousarray(key, np.uint32).copy()
+    p = np.array([pos], np.int32)
+    actions, greedy, eps = np.zeros((E, n, 1), np.int64), np.zeros(E, np.uint8), np.zeros(1)
+    rc = lib.v2xsim_np_policy_draws(key.ctypes.data_as(C.POINTER(C.c_uint32)), p.ctypes.data_as(C.POINTER(C.c_int32)), int(E), int(n),
+                                    int(n_actions), float(eps_max), float(eps_min), float(eps_per_step), float(eps_steps), int(step_no0),
+                                    actions.ctypes.data_as(C.POINTER(C.c_int64)), greedy.ctypes.data_as(C.POINTER(C.c_uint8)), _d(eps))
+    if rc < 0:
+        raise ValueError("np_policy_draws: bad argument")
+    np.random.set_state((name, key, int(p[0]), has_gauss, cached))
+    return actions, np.nonzero(greedy)[0], float(eps[0])
 
 
 _choice_scratch = {}

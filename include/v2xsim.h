@@ -104,6 +104,12 @@ typedef struct {
 } v2xsim_rollout_args;
 int v2xsim_rollout(v2xsim_rollout_args* a);
 
+/* The epsilon-greedy draws of one iteration over E simulators (BS_brain.py:308-352 per simulator, in order) on numpy's process-wide
+ * MT19937: epsilon of step step_no0 + e, one random_sample(); below epsilon n randint(0, n_actions) draws -> actions[e][0..n) and
+ * greedy[e] = 0, else greedy[e] = 1.  Returns the number of greedy simulators (-1: bad argument); *eps_last = the last epsilon. */
+int v2xsim_np_policy_draws(uint32_t* np_key, int32_t* np_pos, int32_t E, int32_t n, int32_t n_actions, double eps_max, double eps_min,
+                           double eps_per_step, double eps_steps, int64_t step_no0, int64_t* actions, uint8_t* greedy, double* eps_last);
+
 /* Memory.sample's draw (BS_brain.py:261): numpy's legacy np.random.choice(n, k, replace=False) = permutation(n)[:k] on the
  * process-wide RandomState's MT19937 state (key[624], pos: get_state / set_state around the call), draw for draw; scratch [n]
  * int32, draws [n] uint32; 0 or -1 (sizes).  v2xsim_np_shuffle_skip: the draws of np.random.shuffle(np.arange(n)) only. */

@@ -306,3 +306,47 @@ def test_choice_ahead_notices_a_draw_in_its_window(monkeypatch):
     np.random.normal()                                            # (leaves a cached gauss value: position may be unchanged on a refill boundary)
     with pytest.raises(RuntimeError, match="np.random was used"):
         ca.result()
+
+
+def test_native_policy_draws_are_the_python_loops_draws():
+    """v2xsim_np_policy_draws: the epsilon draws and the exploring simulators' random actions of one batched iteration on numpy's
+    process-wide generator -- the same draws in the same order, the same actions and greedy set, the same generator state afterwards
+    as the loop of np.random.random() / np.random.randint(0, C, (n, 1)) (BS_brain.py:308-352 per simulator), incl. action counts
+    that are not a power of two (randint's masked rejection) and a cached Gaussian in the state."""
+    from v2xgnn.rl import native_sim
+    if not native_sim.available():
+        pytest.skip("libv2xsim.so not built")
+    for E, n, C, step0 in ((50, 20, 4, 0), (7, 4, 4, 123), (33, 31, 5, 40), (1, 3, 3, 9), (50, 20, 1, 5)):
+        eps_steps = 0.8 * 5 * 20 * 50
+        per_step = (1.0 - 0.01) / eps_steps
+        np.random.seed(E * 1000 + n)
+        np.random.normal()
+        want_a, want_g = np.zeros((E, n, 1), np.int64), []
+        for e in range(E):
+            step_no = step0 + e * (1 if E < 50 else 90)
+            eps = 1.0 - per_step * step_no if step_no < eps_steps else 0.01
+            if np.random.random() < eps:
+                want_a[e] = np.random.randint(0, C, size=(n, 1))
+            else:
+                want_g.append(e)
+        after = (np.random.random(2), np.random.normal(size=2))
+        if E == 50:
+            continue                                             # (the library takes consecutive step numbers: compared for the others)
+        np.random.seed(E * 1000 + n)
+        np.random.normal()
+        a, g, eps_last = native_sim.np_policy_draws(E, n, C, 1.0, 0.01, per_step, eps_steps, step0)
+        assert np.array_equal(a, want_a) and list(g) == want_g and eps_last == eps
+        assert np.array_equal(np.random.random(2), after[0]) and np.array_equal(np.random.normal(size=2), after[1])
+    # a long mixed run: consecutive steps across the end of the schedule
+    np.random.seed(4)
+    eps_steps, per_step = 300.0, 0.99 / 300.0
+    want = []
+    for e in range(400):
+        eps = 1.0 - per_step * e if e < eps_steps else 0.01
+        want.append(np.random.randint(0, 4, size=(6, 1)) if np.random.random() < eps else None)
+    tail = np.random.random(3)
+    np.random.seed(4)
+    a, g, _ = native_sim.np_policy_draws(400, 6, 4, 1.0, 0.01, per_step, eps_steps, 0)
+    assert list(g) == [e for e, w in enumerate(want) if w is None] and 0 < len(g) < 400
+    assert all(np.array_equal(a[e], w) for e, w in enumerate(want) if w is not None)
+    assert np.array_equal(np.random.random(3), tail)

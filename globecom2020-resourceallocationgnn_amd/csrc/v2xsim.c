@@ -276,17 +276,19 @@ void v2xsim_reward(int E, int n, int rb, const int64_t* ch, const int64_t* dest,
 }
 
 /* Compute_Interference (Environment.py:460-493, observable part): out[E][n][rb] in dB */
+static inline void interference_row(int n, int rb, int k, const int64_t* dest, const double* vv, double p_v2i, double veh_gain,
+                                    double veh_nf, double sig2, double* out) {
+  const int64_t rx = dest[k];
+  for (int r = 0; r < rb; ++r) {
+    double v = sig2;
+    /* numpy indexes vehicle number r as the block's V2I transmitter; r < n is the caller's precondition (rb <= n) */
+    v += pow(10.0, (p_v2i - vv[((int64_t)r * n + rx) * rb + r] + 2 * veh_gain - veh_nf) / 10);
+    out[(int64_t)k * rb + r] = 10 * log10(v);
+  }
+}
 static void interference_env(int n, int rb, const int64_t* dest, const double* vv, double p_v2i, double veh_gain, double veh_nf,
                              double sig2, double* out) {
-  for (int k = 0; k < n; ++k) {
-    const int64_t rx = dest[k];
-    for (int r = 0; r < rb; ++r) {
-      double v = sig2;
-      /* numpy indexes vehicle number r as the block's V2I transmitter; r < n is the caller's precondition (rb <= n) */
-      v += pow(10.0, (p_v2i - vv[((int64_t)r * n + rx) * rb + r] + 2 * veh_gain - veh_nf) / 10);
-      out[(int64_t)k * rb + r] = 10 * log10(v);
-    }
-  }
+  for (int k = 0; k < n; ++k) interference_row(n, rb, k, dest, vv, p_v2i, veh_gain, veh_nf, sig2, out);
 }
 typedef struct { int n, rb; const int64_t* dest; const double* v2v_ff; double p_v2i, veh_gain, veh_nf, sig2; double* out; } interf_ctx;
 static void interference_one(int e, void* p) {
@@ -304,32 +306,36 @@ void v2xsim_interference(int E, int n, int rb, const int64_t* dest, const double
  * given, the same observation in the engine's packed form (include/v2xgnn.h, rl/replay.py): xe[n][16] float32 = the state row
  * cast to float32 + zero padding (packing.pack_xe), mask[q] = bit p set when p sends to q, col[n (n-2)] = the CSR sources by
  * destination (ascending) when every link has in-degree n-2 ("regular": no link is its own receiver), zeros otherwise.    */
-static void observe_env(int n, int C, const int64_t* d, const double* vv, const double* vi, double power, double* st, double* ad,
-                        float* xe, int32_t* mask, int32_t* col, uint8_t* regular) {
+/* the observation row of link k (state[k][3C+1], and its packed float32 copy xe[k][16] when xe is given) */
+static inline void observe_row(int n, int C, int k, const int64_t* d, const double* vv, const double* vi, double power, double* st, float* xe) {
   const double A = 80, Bc = 60;
   const int W = 3 * C + 1;
+  const int64_t rx = d[k];
+  for (int c = 0; c < C; ++c) {
+    const double chv = (vv[(k * n + rx) * C + c] - A) / Bc;
+    double tot = 0.0;
+    for (int p = 0; p < n; ++p) tot += vv[(p * n + rx) * C + c];          /* np.sum over p, ascending */
+    const double edge = (((tot - vv[(rx * n + rx) * C + c]) - (n - 1) * A) / Bc - chv) / (n - 2);
+    st[k * W + c] = chv;
+    st[k * W + C + c] = (vi[k * C + c] - A) / Bc;
+    st[k * W + 2 * C + 1 + c] = edge;
+  }
+  st[k * W + 2 * C] = power;
+  if (xe)
+    for (int c = 0; c < 16; ++c) xe[k * 16 + c] = c < W ? (float)st[k * W + c] : 0.0f;
+}
+static void observe_env(int n, int C, const int64_t* d, const double* vv, const double* vi, double power, double* st, double* ad,
+                        float* xe, int32_t* mask, int32_t* col, uint8_t* regular) {
   for (int p = 0; p < n; ++p)
     for (int q = 0; q < n; ++q) ad[p * n + q] = p == q ? 0.0 : 1.0;
   for (int k = 0; k < n; ++k) {
-    const int64_t rx = d[k];
-    ad[rx * n + k] = 0.0;
-    for (int c = 0; c < C; ++c) {
-      const double chv = (vv[(k * n + rx) * C + c] - A) / Bc;
-      double tot = 0.0;
-      for (int p = 0; p < n; ++p) tot += vv[(p * n + rx) * C + c];          /* np.sum over p, ascending */
-      const double edge = (((tot - vv[(rx * n + rx) * C + c]) - (n - 1) * A) / Bc - chv) / (n - 2);
-      st[k * W + c] = chv;
-      st[k * W + C + c] = (vi[k * C + c] - A) / Bc;
-      st[k * W + 2 * C + 1 + c] = edge;
-    }
-    st[k * W + 2 * C] = power;
+    ad[d[k] * n + k] = 0.0;
+    observe_row(n, C, k, d, vv, vi, power, st, xe);
   }
   if (!xe) return;
   int reg = 1;
-  for (int k = 0; k < n; ++k) {
-    for (int c = 0; c < 16; ++c) xe[k * 16 + c] = c < W ? (float)st[k * W + c] : 0.0f;
+  for (int k = 0; k < n; ++k)
     if (d[k] == k) reg = 0;
-  }
   *regular = (uint8_t)reg;
   int o = 0;
   for (int q = 0; q < n; ++q) {
@@ -607,7 +613,7 @@ int v2xsim_advance_wait(int id) { return par_wait(id); }
  * (tests/test_rl_batched_env.py).  g_threads <= 2: everything on the caller, same results.                                 */
 static inline uint32_t np_interval(uint32_t* mt, int32_t* pos, uint32_t max);   /* below: numpy's masked rejection */
 #define RO_RING 4
-#define RO_MAXW 8
+#define RO_MAXW 12
 typedef struct {
   double *v2v_abs, *v2i_abs, *v2v_ff, *v2i_ff, *interf_db, *state, *adj;
   float* xe; int32_t *mask, *col; uint8_t regular;
@@ -616,11 +622,15 @@ typedef struct { double* xy; int8_t* dirs; double *u, *g; } ro_slot;
 typedef struct {
   const v2xsim_rollout_args* a;
   int n, rb, n_u, n_sh, T, K;
-  ro_state st[2];
+  ro_state* st; int ns;                           /* state s lives in st[s % ns]: ns = 2 (a state's buffer is re-used two steps
+                                                     later), or T + 1 when every state of the call is kept (batch_predict) */
   ro_slot ring[RO_RING];
   uint32_t mt[624]; int32_t mtpos;                 /* the environment's stream (owned by the stream thread during the call) */
   double *si, *sv;                                 /* shadowing, updated in place by the workers */
+  double* gw[RO_MAXW];                             /* batch mode: a private Gaussian scratch per worker [n_u] */
+  int batch;
   _Atomic int stream_done, main_pos, workers_done, bar, stop;
+  _Atomic int steps_of[RO_MAXW];                   /* batch mode: steps worker w has finished (the stream thread's ring follows the slowest) */
 } ro_ctx;
 
 static void ro_spin(_Atomic int* v, int want) {    /* until *v >= want */
@@ -653,7 +663,7 @@ static void ro_channels(ro_ctx* c, int k, int w, int K) {
   const v2xsim_rollout_args* a = c->a;
   const int n = c->n, rb = c->rb, n_sh = c->n_sh, na = n * rb, nb = n * n * rb;
   const ro_slot* s = &c->ring[k % RO_RING];
-  ro_state* o = &c->st[(k + 1) & 1];
+  ro_state* o = &c->st[(k + 1) % c->ns];
   const double *g = s->g, *pe = s->xy, *ve = a->vel;
   const double* f = g + n_sh;
   const double rs2 = 1 / sqrt(2.0);
@@ -681,11 +691,69 @@ static void ro_channels(ro_ctx* c, int k, int w, int K) {
       }
     }
 }
-static void ro_observe(ro_ctx* c, int k) {
+/* observable interference + observation rows of worker w's links.  The parts of an observation that depend on the receivers
+ * only -- adjacency, masks, CSR sources, the regular flag -- do not change inside a call: both state buffers carry the copies
+ * of the caller's (v2xsim_rollout) */
+static void ro_observe(ro_ctx* c, int k, int w, int K) {
   const v2xsim_rollout_args* a = c->a;
-  ro_state* o = &c->st[(k + 1) & 1];
-  interference_env(c->n, c->rb, a->dest, o->v2v_ff, a->p_v2i, a->veh_gain, a->veh_nf, a->sig2, o->interf_db);
-  observe_env(c->n, c->rb, a->dest, o->v2v_ff, o->v2i_ff, a->p_v2v, o->state, o->adj, o->xe, o->mask, o->col, &o->regular);
+  ro_state* o = &c->st[(k + 1) % c->ns];
+  const int n = c->n, i0 = (int)((int64_t)n * w / K), i1 = (int)((int64_t)n * (w + 1) / K);
+  for (int i = i0; i < i1; ++i) {
+    interference_row(n, c->rb, i, a->dest, o->v2v_ff, a->p_v2i, a->veh_gain, a->veh_nf, a->sig2, o->interf_db);
+    observe_row(n, c->rb, i, a->dest, o->v2v_ff, o->v2i_ff, a->p_v2v, o->state, o->xe);
+  }
+}
+/* batch mode (every state of the call has its own buffer): a worker owns a FIXED range of the V2V link pairs and of the V2I
+ * links through all T steps -- the Gaussians its elements need (computed into a scratch of its own: pairs that straddle a range
+ * boundary are simply computed by both neighbours), their shadowing recursion, path loss and fast fading -- and needs nobody
+ * but the stream thread until the very end: no barrier per step (three per step made the call as slow as its most-descheduled
+ * worker on a shared host).  Same expressions per element as ro_gauss / ro_channels.                                          */
+static void ro_gauss_range(const double* u, double* g, int lo, int hi) {          /* Gaussians lo .. hi-1 (whole pairs around them) */
+  for (int q = lo >> 1; 2 * q < hi; ++q) {
+    const double x2pi = u[2 * q] * TWOPI;
+    const double g2rad = sqrt(-2.0 * log(1.0 - u[2 * q + 1]));
+    g[2 * q] = cos(x2pi) * g2rad;
+    g[2 * q + 1] = sin(x2pi) * g2rad;
+  }
+}
+static void ro_step_owned(ro_ctx* c, int k, int w, int K) {
+  const v2xsim_rollout_args* a = c->a;
+  const int n = c->n, rb = c->rb, n_sh = c->n_sh, na = n * rb, nb = n * n * rb;
+  const ro_slot* s = &c->ring[k % RO_RING];
+  ro_state* o = &c->st[(k + 1) % c->ns];
+  double* g = c->gw[w];
+  const double *pe = s->xy, *ve = a->vel;
+  const double rs2 = 1 / sqrt(2.0);
+  const int i0 = (int)((int64_t)n * w / K), i1 = (int)((int64_t)n * (w + 1) / K);              /* V2I links */
+  const int p0 = (int)((int64_t)n * n * w / K), p1 = (int)((int64_t)n * n * (w + 1) / K);      /* V2V pairs ij */
+  ro_gauss_range(s->u, g, i0, i1);
+  ro_gauss_range(s->u, g, n + p0, n + p1);
+  ro_gauss_range(s->u, g, n_sh + i0 * rb, n_sh + i1 * rb);
+  ro_gauss_range(s->u, g, n_sh + na + i0 * rb, n_sh + na + i1 * rb);
+  ro_gauss_range(s->u, g, n_sh + 2 * na + p0 * rb, n_sh + 2 * na + p1 * rb);
+  ro_gauss_range(s->u, g, n_sh + 2 * na + nb + p0 * rb, n_sh + 2 * na + nb + p1 * rb);
+  const double* f = g + n_sh;
+  for (int i = i0; i < i1; ++i) {
+    const double dd = 0.002 * ve[i];
+    c->si[i] = exp(-1 * (dd / V2I_DECORR)) * c->si[i] + sqrt(1 - exp(-2 * (dd / V2I_DECORR))) * (g[i] * V2I_SHADOW_STD);
+    o->v2i_abs[i] = v2i_pathloss(pe[2 * i], pe[2 * i + 1]) + c->si[i];
+    for (int r = 0; r < rb; ++r) {
+      const int q = i * rb + r;
+      const double re = rs2 * f[q], im = rs2 * f[na + q];
+      o->v2i_ff[q] = o->v2i_abs[i] - 20 * log10(hypot(re, im));
+    }
+  }
+  for (int ij = p0; ij < p1; ++ij) {
+    const int i = ij / n, j = ij - i * n;
+    const double ddm = 0.002 * ve[i] + 0.002 * ve[j];
+    c->sv[ij] = exp(-1 * (ddm / V2V_DECORR)) * c->sv[ij] + sqrt(1 - exp(-2 * (ddm / V2V_DECORR))) * (g[n + ij] * V2V_SHADOW_STD);
+    o->v2v_abs[ij] = v2v_pathloss(pe[2 * i], pe[2 * i + 1], pe[2 * j], pe[2 * j + 1]) + c->sv[ij] + (i == j ? 50.0 : 0.0);
+    for (int r = 0; r < rb; ++r) {
+      const int q = ij * rb + r;
+      const double re = rs2 * f[2 * na + q], im = rs2 * f[2 * na + nb + q];
+      o->v2v_ff[q] = o->v2v_abs[ij] - 20 * log10(hypot(re, im));
+    }
+  }
 }
 static void ro_barrier(ro_ctx* c, int* phase) {    /* among the K workers */
   ++*phase;
@@ -694,6 +762,18 @@ static void ro_barrier(ro_ctx* c, int* phase) {    /* among the K workers */
 }
 static void ro_worker(ro_ctx* c, int w) {
   int phase = 0;
+  if (c->batch) {                                  /* all steps on the own ranges, ONE barrier, then the observation rows of all states */
+    for (int k = 0; k < c->T; ++k) {
+      ro_spin(&c->stream_done, k + 1);
+      ro_step_owned(c, k, w, c->K);
+      atomic_store_explicit(&c->steps_of[w], k + 1, memory_order_release);
+    }
+    ro_barrier(c, &phase);
+    for (int k = 0; k < c->T; ++k) ro_observe(c, k, w, c->K);
+    ro_barrier(c, &phase);
+    if (w == 0) atomic_store_explicit(&c->workers_done, c->T, memory_order_release);
+    return;
+  }
   for (int k = 0; k < c->T; ++k) {
     ro_spin(&c->stream_done, k + 1);               /* the step's positions and uniforms */
     ro_spin(&c->main_pos, k);                      /* the caller has left state k - 1, whose buffer state k + 1 takes */
@@ -701,14 +781,16 @@ static void ro_worker(ro_ctx* c, int w) {
     ro_barrier(c, &phase);
     ro_channels(c, k, w, c->K);
     ro_barrier(c, &phase);
-    if (w == 0) {
-      ro_observe(c, k);
-      atomic_store_explicit(&c->workers_done, k + 1, memory_order_release);
-    }
+    ro_observe(c, k, w, c->K);
+    ro_barrier(c, &phase);
+    if (w == 0) atomic_store_explicit(&c->workers_done, k + 1, memory_order_release);
   }
 }
 static void ro_stream(ro_ctx* c) {
   for (int k = 0; k < c->T; ++k) {
+    if (c->batch) {                                /* the ring slot's previous tenant: consumed by EVERY worker */
+      for (int w = 0; w < c->K; ++w) ro_spin(&c->steps_of[w], k - (RO_RING - 1));
+    } else
     ro_spin(&c->workers_done, k - (RO_RING - 1));  /* the ring slot's previous tenant (step k - RO_RING) has been consumed */
     ro_stream_step(c, k);
     atomic_store_explicit(&c->stream_done, k + 1, memory_order_release);
@@ -801,28 +883,71 @@ int v2xsim_np_policy_draws(uint32_t* np_key, int32_t* np_pos, int32_t E, int32_t
 }
 
 static double* ro_buf; static size_t ro_buf_len;     /* the call's working memory, kept between calls */
+static ro_state* ro_sts; static int ro_sts_len;
+
+/* one transition's policy draws on numpy's generator -> 1 when it explores (act filled), 0 when it is greedy */
+static int ro_policy_draw(const v2xsim_rollout_args* a, int t, int64_t* act, double* eps_out) {
+  const int64_t step_no = a->step_no0 + t;
+  const double eps = (double)step_no < a->eps_steps ? a->eps_max - a->eps_per_step * (double)step_no : a->eps_min;
+  *eps_out = eps;
+  if (mt_double(a->np_key, a->np_pos) < eps) {
+    for (int i = 0; i < a->n; ++i) act[i] = np_randint(a->np_key, a->np_pos, (uint32_t)a->n_actions);
+    return 1;
+  }
+  return 0;
+}
+static void ro_argmax(const v2xsim_rollout_args* a, const float* q, int64_t* act) {       /* first maximiser (np.argmax) */
+  for (int i = 0; i < a->n; ++i) {
+    const float* qi = q + (int64_t)i * a->n_actions;
+    int best = 0;
+    for (int ch = 1; ch < a->n_actions; ++ch) if (qi[ch] > qi[best]) best = ch;
+    act[i] = best;
+  }
+}
+/* rates on the channels of state t + the transition's record (everything but xe_next) */
+static void ro_record(const v2xsim_rollout_args* a, int t, const ro_state* cur, const int64_t* act) {
+  const int n = a->n, rb = a->rb, ne = n * (n - 2), m = rb < n ? rb : n;
+  reward_ctx r = { n, rb, act, a->dest, cur->v2v_ff, cur->v2i_ff, cur->v2i_abs, a->p_v2v, a->p_v2i, a->veh_gain, a->bs_gain, a->bs_nf,
+                   a->veh_nf, a->sig2, a->t_v2v_rate + (int64_t)t * n, a->t_v2i_rate + (int64_t)t * m, a->interference, a->v2i_interf,
+                   a->v2v_interf };
+  reward_one(0, &r);
+  memcpy(a->t_xe + (int64_t)t * n * 16, cur->xe, (size_t)n * 16 * sizeof(float));
+  memcpy(a->t_col + (int64_t)t * ne, cur->col, (size_t)ne * sizeof(int32_t));
+  memcpy(a->t_mask + (int64_t)t * n, cur->mask, (size_t)n * sizeof(int32_t));
+  a->t_regular[t] = cur->regular;
+}
+
 int v2xsim_rollout(v2xsim_rollout_args* a) {
   if (!a || a->n < 3 || a->n > 31 || a->rb < 1 || a->rb > a->n || 3 * a->rb + 1 > 16 || a->T < 1 || a->n_actions < 1) return -1;
-  const int n = a->n, rb = a->rb, T = a->T, W = 3 * rb + 1, ne = n * (n - 2), m = rb < n ? rb : n;
+  const int n = a->n, rb = a->rb, T = a->T, W = 3 * rb + 1, ne = n * (n - 2);
   const int n_draws = n + n * n + 2 * n * rb + 2 * n * n * rb;
   if (n_draws & 1) return -1;
   if (pthread_mutex_trylock(&RT.call_mu) != 0) return -3;
-  /* working memory: two state buffers + the ring, carved out of one block */
+  const int batch = a->batch_predict != 0;
+  const int ns = batch ? T + 1 : 2;
+  /* working memory: the state buffers + the ring, carved out of one block */
   const size_t per_state = (size_t)n * n + n + (size_t)n * n * rb + (size_t)n * rb + (size_t)n * rb + (size_t)n * W + (size_t)n * n   /* doubles */
-                           + ((size_t)n * 16 * 4 + (size_t)n * 4 + (size_t)(ne > 0 ? ne : 1) * 4 + 7) / 8 + 2;
+                           + ((size_t)n * 16 * 4 + (size_t)n * 4 + (size_t)(ne > 0 ? ne : 1) * 4 + 7) / 8 + 4;
   const size_t per_slot = (size_t)n * 2 + ((size_t)n + 7) / 8 + 2 * (size_t)n_draws + 2;
-  const size_t need = 2 * per_state + RO_RING * per_slot + (size_t)n + (size_t)n * n + 16;
+  const size_t need = (size_t)ns * per_state + RO_RING * per_slot + (size_t)n + (size_t)n * n + 16
+                      + (batch ? ((size_t)T + 7) / 8 + 80 + (size_t)RO_MAXW * n_draws : 0);
   if (ro_buf_len < need) {
     free(ro_buf);
     ro_buf = (double*)malloc(need * sizeof(double));
     ro_buf_len = ro_buf ? need : 0;
     if (!ro_buf) { pthread_mutex_unlock(&RT.call_mu); return -2; }
   }
+  if (ro_sts_len < ns) {
+    free(ro_sts);
+    ro_sts = (ro_state*)malloc((size_t)ns * sizeof(ro_state));
+    ro_sts_len = ro_sts ? ns : 0;
+    if (!ro_sts) { pthread_mutex_unlock(&RT.call_mu); return -2; }
+  }
   ro_ctx c;
   memset(&c, 0, sizeof(c));
-  c.a = a; c.n = n; c.rb = rb; c.n_u = n_draws; c.n_sh = n + n * n; c.T = T;
+  c.a = a; c.n = n; c.rb = rb; c.n_u = n_draws; c.n_sh = n + n * n; c.T = T; c.st = ro_sts; c.ns = ns;
   double* p = ro_buf;
-  for (int b = 0; b < 2; ++b) {
+  for (int b = 0; b < ns; ++b) {
     ro_state* s = &c.st[b];
     s->v2v_abs = p; p += (size_t)n * n;
     s->v2i_abs = p; p += n;
@@ -834,6 +959,10 @@ int v2xsim_rollout(v2xsim_rollout_args* a) {
     s->xe = (float*)p; p += ((size_t)n * 16 * 4 + 7) / 8;
     s->mask = (int32_t*)p; p += ((size_t)n * 4 + 7) / 8;
     s->col = (int32_t*)p; p += ((size_t)(ne > 0 ? ne : 1) * 4 + 7) / 8;
+    memcpy(s->adj, a->adj, (size_t)n * n * sizeof(double));         /* what depends on the receivers only: constant over the call */
+    memcpy(s->mask, a->mask, (size_t)n * sizeof(int32_t));
+    memcpy(s->col, a->col, (size_t)ne * sizeof(int32_t));
+    s->regular = *a->regular;
   }
   for (int r = 0; r < RO_RING; ++r) {
     ro_slot* s = &c.ring[r];
@@ -844,7 +973,11 @@ int v2xsim_rollout(v2xsim_rollout_args* a) {
   }
   c.si = p; p += n;
   c.sv = p; p += (size_t)n * n;
-  /* state 0 = the environment as it stands (channels read in place, never written: buffer 0 is first written as state 2) */
+  if (batch)
+    for (int w = 0; w < RO_MAXW; ++w) { c.gw[w] = p; p += n_draws; }
+  c.batch = batch;
+  uint8_t* explores = (uint8_t*)p;                 /* batch_predict: per transition, 1 = random actions drawn */
+  /* state 0 = the environment as it stands (channels read in place, never written: buffer 0 is first written as state 2 / never) */
   ro_state s0 = { a->v2v_abs, a->v2i_abs, a->v2v_ff, a->v2i_ff, a->interf_db, a->state, a->adj, a->xe, a->mask, a->col, *a->regular };
   memcpy(c.mt, a->keys, sizeof(c.mt));
   c.mtpos = *a->mtpos;
@@ -854,52 +987,77 @@ int v2xsim_rollout(v2xsim_rollout_args* a) {
   if (K > RO_MAXW) K = RO_MAXW;
   if (K > n) K = n;
   c.K = K > 0 ? K : 1;
+  if (batch) atomic_store(&c.main_pos, T);        /* every state has a buffer of its own: the team never waits for the caller */
   const int team = K >= 1 ? ro_team_start(&c, 1 + c.K) : 0;
   if (!team) c.K = 1;
-  int rc = T, phase = 0;
+  int rc = T;
   double eps = a->eps_min;
-  for (int t = 0; t < T; ++t) {
-    const ro_state* cur = t == 0 ? &s0 : &c.st[t & 1];
-    atomic_store_explicit(&c.main_pos, t, memory_order_release);
-    if (!team) {                                   /* no helpers: the step right here */
-      ro_stream_step(&c, t);
-      ro_gauss(&c, t, 0, 1); ro_channels(&c, t, 0, 1); ro_observe(&c, t);
-      atomic_store(&c.stream_done, t + 1); atomic_store(&c.workers_done, t + 1);
-      (void)phase;
+#define RO_STATE(t_) ((t_) == 0 ? (const ro_state*)&s0 : (const ro_state*)&c.st[(t_) % ns])
+  if (batch) {
+    /* ---- all policy draws first (they need no Q-value: a greedy transition draws nothing but its epsilon), the states meanwhile
+     * on the team; then ONE predict of the T observations (the network does not change inside a rollout and a graph's Q-values do
+     * not depend on the batch around it), then argmax / rates / records transition by transition */
+    uint32_t np_key0[624];
+    memcpy(np_key0, a->np_key, sizeof(np_key0));
+    const int32_t np_pos0 = *a->np_pos;
+    int first_greedy = -1;
+    for (int t = 0; t < T; ++t) {
+      explores[t] = (uint8_t)ro_policy_draw(a, t, a->t_action + (int64_t)t * n, &eps);
+      if (!explores[t]) { ++*a->n_greedy; if (first_greedy < 0) first_greedy = t; }
     }
-    /* ---- epsilon-greedy action (BS_brain.py:308-352) */
-    const int64_t step_no = a->step_no0 + t;
-    eps = (double)step_no < a->eps_steps ? a->eps_max - a->eps_per_step * (double)step_no : a->eps_min;
-    int64_t* act = a->t_action + (int64_t)t * n;
-    if (mt_double(a->np_key, a->np_pos) < eps) {
-      for (int i = 0; i < n; ++i) act[i] = np_randint(a->np_key, a->np_pos, (uint32_t)a->n_actions);
-    } else {
-      if (!cur->regular || !a->predict) { rc = -4 - t; break; }          /* a link that is its own receiver: the caller's general path */
-      memcpy(a->xe_pin, cur->xe, (size_t)n * 16 * sizeof(float));
-      memcpy(a->col_pin, cur->col, (size_t)ne * sizeof(int32_t));
-      if (a->predict(a->predict_ctx) != 0) { rc = -1000 - t; break; }
-      for (int i = 0; i < n; ++i) {                /* first maximiser (np.argmax) */
-        const float* q = a->q_pin + (int64_t)i * a->n_actions;
-        int best = 0;
-        for (int ch = 1; ch < a->n_actions; ++ch) if (q[ch] > q[best]) best = ch;
-        act[i] = best;
+    if (!team)
+      for (int t = 0; t < T; ++t) { ro_stream_step(&c, t); ro_step_owned(&c, t, 0, 1); ro_observe(&c, t, 0, 1); }
+    else
+      ro_spin(&c.workers_done, T);
+    int n_ok = T;                                  /* transitions that can be completed */
+    if (first_greedy >= 0) {
+      if (!*a->regular || !a->predict) { rc = -4 - first_greedy; n_ok = first_greedy; }
+      else {
+        for (int t = 0; t < T; ++t) {
+          memcpy(a->xe_pin + (int64_t)t * n * 16, RO_STATE(t)->xe, (size_t)n * 16 * sizeof(float));
+          memcpy(a->col_pin + (int64_t)t * ne, RO_STATE(t)->col, (size_t)ne * sizeof(int32_t));
+        }
+        if (a->predict(a->predict_ctx) != 0) { rc = -1000 - first_greedy; n_ok = first_greedy; }
       }
-      ++*a->n_greedy;
     }
-    /* ---- rates on the channels of state t (compute_reward_with_channel_selection) */
-    {
-      reward_ctx r = { n, rb, act, a->dest, cur->v2v_ff, cur->v2i_ff, cur->v2i_abs, a->p_v2v, a->p_v2i, a->veh_gain, a->bs_gain, a->bs_nf,
-                       a->veh_nf, a->sig2, a->t_v2v_rate + (int64_t)t * n, a->t_v2i_rate + (int64_t)t * m, a->interference, a->v2i_interf,
-                       a->v2v_interf };
-      reward_one(0, &r);
+    for (int t = 0; t < n_ok; ++t) {
+      int64_t* act = a->t_action + (int64_t)t * n;
+      if (!explores[t]) ro_argmax(a, a->q_pin + (int64_t)t * n * a->n_actions, act);
+      ro_record(a, t, RO_STATE(t), act);
+      memcpy(a->t_xe_next + (int64_t)t * n * 16, c.st[(t + 1) % ns].xe, (size_t)n * 16 * sizeof(float));
     }
-    memcpy(a->t_xe + (int64_t)t * n * 16, cur->xe, (size_t)n * 16 * sizeof(float));
-    memcpy(a->t_col + (int64_t)t * ne, cur->col, (size_t)ne * sizeof(int32_t));
-    memcpy(a->t_mask + (int64_t)t * n, cur->mask, (size_t)n * sizeof(int32_t));
-    a->t_regular[t] = cur->regular;
-    ro_spin(&c.workers_done, t + 1);               /* state t + 1 */
-    memcpy(a->t_xe_next + (int64_t)t * n * 16, c.st[(t + 1) & 1].xe, (size_t)n * 16 * sizeof(float));
+    if (n_ok < T) {                                /* numpy's stream: where the failed transition's epsilon draw left it */
+      memcpy(a->np_key, np_key0, sizeof(np_key0));
+      *a->np_pos = np_pos0;
+      *a->n_greedy = 0;
+      for (int t = 0; t <= n_ok; ++t)
+        if (!ro_policy_draw(a, t, a->t_action + (int64_t)t * n, &eps)) ++*a->n_greedy;
+    }
+  } else {
+    for (int t = 0; t < T; ++t) {
+      const ro_state* cur = RO_STATE(t);
+      atomic_store_explicit(&c.main_pos, t, memory_order_release);
+      if (!team) {                                 /* no helpers: the step right here */
+        ro_stream_step(&c, t);
+        ro_gauss(&c, t, 0, 1); ro_channels(&c, t, 0, 1); ro_observe(&c, t, 0, 1);
+        atomic_store(&c.stream_done, t + 1); atomic_store(&c.workers_done, t + 1);
+      }
+      /* ---- epsilon-greedy action (BS_brain.py:308-352) */
+      int64_t* act = a->t_action + (int64_t)t * n;
+      if (!ro_policy_draw(a, t, act, &eps)) {
+        if (!cur->regular || !a->predict) { rc = -4 - t; break; }        /* a link that is its own receiver: the caller's general path */
+        memcpy(a->xe_pin, cur->xe, (size_t)n * 16 * sizeof(float));
+        memcpy(a->col_pin, cur->col, (size_t)ne * sizeof(int32_t));
+        if (a->predict(a->predict_ctx) != 0) { rc = -1000 - t; break; }
+        ro_argmax(a, a->q_pin, act);
+        ++*a->n_greedy;
+      }
+      ro_record(a, t, cur, act);                   /* rates on the channels of state t (compute_reward_with_channel_selection) */
+      ro_spin(&c.workers_done, t + 1);             /* state t + 1 */
+      memcpy(a->t_xe_next + (int64_t)t * n * 16, c.st[(t + 1) % ns].xe, (size_t)n * 16 * sizeof(float));
+    }
   }
+#undef RO_STATE
   const int done = rc == T ? T : (rc <= -1000 ? -1000 - rc : -4 - rc);     /* transitions completed */
   if (team) {
     if (done < T) {
@@ -915,10 +1073,10 @@ int v2xsim_rollout(v2xsim_rollout_args* a) {
     memcpy(c.mt, a->keys, sizeof(c.mt)); c.mtpos = *a->mtpos;
     memcpy(c.si, a->v2i_shadow, (size_t)n * sizeof(double));
     memcpy(c.sv, a->v2v_shadow, (size_t)n * n * sizeof(double));
-    for (int t = 0; t < done; ++t) { ro_stream_step(&c, t); ro_gauss(&c, t, 0, 1); ro_channels(&c, t, 0, 1); ro_observe(&c, t); }
+    for (int t = 0; t < done; ++t) { ro_stream_step(&c, t); ro_gauss(&c, t, 0, 1); ro_channels(&c, t, 0, 1); ro_observe(&c, t, 0, 1); }
   }
   if (done > 0) {                                  /* commit state `done` to the caller's arrays */
-    const ro_state* f = &c.st[done & 1];
+    const ro_state* f = &c.st[done % ns];
     const ro_slot* sl = &c.ring[(done - 1) % RO_RING];
     memcpy(a->keys, c.mt, sizeof(c.mt)); *a->mtpos = c.mtpos;
     memcpy(a->xy, sl->xy, (size_t)n * 2 * sizeof(double));

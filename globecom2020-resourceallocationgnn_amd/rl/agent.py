@@ -401,46 +401,49 @@ class Agent(object):
     def _native_rollout_ok(self):
         """ONE simulator on the native library and the gfx950 engine: the whole rollout is one library call (v2xsim_rollout)"""
         return (os.environ.get("V2X_RL_NATIVE_ROLLOUT", "1") != "0" and native_sim.available() and hasattr(self.env, 'native_rollout')
-                and self.env._one_call_step() and self._rollout_closure() is not None)
+                and self.env._one_call_step() and self._rollout_closure(1) is not None)
 
-    def _rollout_closure(self):
-        """The predict of the native rollout: page-locked buffers for ONE graph (the kernels read the observation over the bus,
-        the library copies Q back: GnnEngine.forward_to_host's path) behind a v2x_forward_closure, and the address of
+    def _rollout_closure(self, graphs=1):
+        """The predict of the native rollout for `graphs` graphs at once: page-locked buffers (the kernels read the observations over
+        the bus, the library copies Q back: GnnEngine.forward_to_host's path) behind a v2x_forward_closure, and the address of
         v2x_forward_call.  A brain without the C ABI (tests) may provide `rollout_predict_callback(xe, col, q)` instead."""
-        io = getattr(self, '_native_io', None)
-        if io is not None:
+        cache = self.__dict__.setdefault('_native_io', {})
+        io = cache.get(graphs)
+        if io is not None or graphs in cache:
             return io
         n, C = self.num_D2D, self.num_CH
         ne = n * (n - 2)
         custom = getattr(self.brain, 'rollout_predict_callback', None)
         if custom is not None:
             import ctypes
-            xe, col, q = np.zeros((n, 16), np.float32), np.zeros(max(ne, 1), np.int32), np.zeros((n, C), np.float32)
+            xe, col, q = np.zeros((graphs * n, 16), np.float32), np.zeros(graphs * max(ne, 1), np.int32), np.zeros((graphs * n, C), np.float32)
             cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(lambda _ctx: int(custom(xe, col, q) or 0))
-            io = self._native_io = {"xe": xe, "col": col, "q": q, "cb": cb, "fn": ctypes.cast(cb, ctypes.c_void_p).value, "ctx": None}
+            io = cache[graphs] = {"xe": xe, "col": col, "q": q, "cb": cb, "fn": ctypes.cast(cb, ctypes.c_void_p).value, "ctx": None}
             return io
         engine = getattr(getattr(self.brain, 'model', None), 'engine', None)
         rep = self.device_replay
+        cache[graphs] = None
         if engine is None or rep is None or not hasattr(engine, '_lib') or not hasattr(engine._lib, 'v2x_forward_call'):
             return None
         import ctypes
         from .. import lib as _lib
         torch = rep.torch
-        pins = {"xe": torch.empty((n, 16), dtype=torch.float32).pin_memory(), "col": torch.empty(max(ne, 1), dtype=torch.int32).pin_memory(),
-                "q": torch.empty((n, C), dtype=torch.float32).pin_memory()}
+        pins = {"xe": torch.empty((graphs * n, 16), dtype=torch.float32).pin_memory(),
+                "col": torch.empty(graphs * max(ne, 1), dtype=torch.int32).pin_memory(),
+                "q": torch.empty((graphs * n, C), dtype=torch.float32).pin_memory()}
         if os.environ.get("V2X_RL_ZERO_COPY", "1") == "0" or any(engine._lib.v2x_device_addressable(pins[k_].data_ptr()) != 1 for k_ in ("xe", "col")):
             return None                                        # no unified addressing: the per-transition path copies
         if rep.n_edges is None:
             rep.n_edges = ne
-        rp = rep.row_ptr(1)
+        rp = rep.row_ptr(graphs)
         cl = _lib.ForwardClosure()
         cl.m = engine._h
-        cl.b.n_graphs, cl.b.n_rows, cl.b.n_edges, cl.b.max_nodes, cl.b.max_edges, cl.b.on_device = 1, n, ne, n, ne, 1
+        cl.b.n_graphs, cl.b.n_rows, cl.b.n_edges, cl.b.max_nodes, cl.b.max_edges, cl.b.on_device = graphs, graphs * n, graphs * ne, n, ne, 1
         cl.b.xe, cl.b.row_ptr, cl.b.col_idx = pins["xe"].data_ptr(), rp.data_ptr(), pins["col"].data_ptr()
         cl.q_out, cl.q_on_device = pins["q"].data_ptr(), 0
-        io = self._native_io = {"pins": pins, "rp": rp, "closure": cl, "engine": engine,
-                                "xe": pins["xe"].numpy(), "col": pins["col"].numpy(), "q": pins["q"].numpy(),
-                                "fn": ctypes.cast(engine._lib.v2x_forward_call, ctypes.c_void_p).value, "ctx": ctypes.addressof(cl)}
+        io = cache[graphs] = {"pins": pins, "rp": rp, "closure": cl, "engine": engine,
+                              "xe": pins["xe"].numpy(), "col": pins["col"].numpy(), "q": pins["q"].numpy(),
+                              "fn": ctypes.cast(engine._lib.v2x_forward_call, ctypes.c_void_p).value, "ctx": ctypes.addressof(cl)}
         return io
 
     def _rollout_one_simulator(self, num_transitions):
@@ -448,18 +451,27 @@ class Agent(object):
         transitions, a B = 1 predict for every greedy one, BS_brain.py:409-553) with the simulator step cut over the library's
         threads and computed while the predict is in flight.  Same epsilon draws, same random actions, same Q-values, same
         stored transitions as _packed_iteration called num_transitions times (tests/test_rl_batched_env.py)."""
-        env, rep, io = self.env, self.device_replay, self._rollout_closure()
+        env, rep = self.env, self.device_replay
+        # ONE predict for all transitions of the rollout (their observations do not depend on the actions, the network does not
+        # change before the replay): V2X_RL_ROLLOUT_BATCH_PREDICT=0 scores transition by transition, a B = 1 predict each
+        batch = os.environ.get("V2X_RL_ROLLOUT_BATCH_PREDICT", "1") != "0"
         n = self.num_D2D
         rewards = np.zeros(num_transitions)
         steps = self.num_Episodes * 0.8 * self.num_Train_Step * self.num_transition
         per_step = (MAX_EPSILON - MIN_EPSILON) / steps
         done = 0
         while done < num_transitions:
+            todo = num_transitions - done
+            io = self._rollout_closure(todo) if batch else None
+            use_batch = io is not None
+            if io is None:
+                io = self._rollout_closure(1)
             if "closure" in io:
                 io["closure"].stream = io["engine"]._stream()
-            out = env.native_rollout(num_transitions - done, self.num_CH,
+            out = env.native_rollout(todo, self.num_CH,
                                      dict(eps_max=MAX_EPSILON, eps_min=MIN_EPSILON, eps_per_step=per_step, eps_steps=steps, step_no0=self.num_step,
-                                          predict=io["fn"], predict_ctx=io["ctx"], xe_pin=io["xe"], col_pin=io["col"], q_pin=io["q"]))
+                                          predict=io["fn"], predict_ctx=io["ctx"], xe_pin=io["xe"], col_pin=io["col"], q_pin=io["q"],
+                                          batch_predict=use_batch))
             k = out["done"]
             if k > 0:
                 self.epsilon = out["eps_last"]

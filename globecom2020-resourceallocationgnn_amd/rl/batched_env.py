@@ -88,8 +88,8 @@ class BatchedEnviron(object):
             # parked for 25-50 ms a few times per hundred steps (csrc/v2xsim.c).  V2X_SIM_THREADS overrides.
             cap = int(os.environ.get("V2X_SIM_THREADS", "0")) or min(16, max(1, _usable_cpus() - 1))
             # (ONE simulator: its steps are cut over a team of threads inside v2xsim_rollout -- the caller, a stream thread and
-            #  up to 6 workers -- instead of environments over the pool)
-            native_sim.set_threads(max(1, min(self.E if self.E > 1 else 8, cap)))
+            #  up to 10 workers -- instead of environments over the pool)
+            native_sim.set_threads(max(1, min(self.E if self.E > 1 else 12, cap)))
             if not self._shared:                               # the streams' MT19937 states, where the library can advance them
                 self._mt_keys = np.empty((self.E, 624), np.uint32)
                 self._mt_pos = np.zeros(self.E, np.int32)
@@ -547,7 +547,8 @@ class BatchedEnviron(object):
         reference's own loop shape, Agent.generate_d2d_transition with 50 transitions before every replay (BS_brain.py:409-553,
         :818-832).  policy: eps_max, eps_min, eps_per_step, eps_steps, step_no0 (the epsilon schedule as the agent evaluates it),
         predict / predict_ctx (addresses of a C callback `int (*)(void*)` and its closure: scores the graph in xe_pin / col_pin
-        into q_pin), xe_pin [n, 16] float32, col_pin [n (n-2)] int32, q_pin [n, n_actions] float32.  Epsilon draws and random
+        into q_pin), xe_pin [n, 16] float32, col_pin [n (n-2)] int32, q_pin [n, n_actions] float32; batch_predict: the callback
+        scores all T graphs in ONE call (the buffers hold T graphs; see include/v2xsim.h).  Epsilon draws and random
         actions are taken from numpy's process-wide generator exactly as np.random.random() / np.random.randint would.
         -> dict(done, rc, xe, xe_next, col, mask, regular, action, v2v_rate [done, n, 1], v2i_rate [done, m], eps_last, n_greedy);
         the simulator stands at the state after `done` transitions (done < T: transition `done` needs the caller's general path --
@@ -596,10 +597,14 @@ class BatchedEnviron(object):
         a.eps_max, a.eps_min, a.eps_per_step = float(policy["eps_max"]), float(policy["eps_min"]), float(policy["eps_per_step"])
         a.eps_steps, a.step_no0 = float(policy["eps_steps"]), int(policy["step_no0"])
         a.predict, a.predict_ctx = policy.get("predict"), policy.get("predict_ctx")
+        # batch_predict: ONE predict for all T observations (they do not depend on the actions: include/v2xsim.h); the pinned
+        # buffers then hold T graphs.  Not for a graph with a link that is its own receiver (every greedy transition would end the call).
+        a.batch_predict = 1 if (policy.get("batch_predict") and bool(np.all(ob[5]))) else 0
+        g_ = int(T) if a.batch_predict else 1
         pins = [policy.get(k_) for k_ in ("xe_pin", "col_pin", "q_pin")]
         if a.predict:
-            if (pins[0].dtype != np.float32 or pins[0].size < n * 16 or pins[1].dtype != np.int32 or pins[1].size < max(ne, 1)
-                    or pins[2].dtype != np.float32 or pins[2].size < n * n_actions):
+            if (pins[0].dtype != np.float32 or pins[0].size < g_ * n * 16 or pins[1].dtype != np.int32 or pins[1].size < g_ * max(ne, 1)
+                    or pins[2].dtype != np.float32 or pins[2].size < g_ * n * n_actions):
                 raise ValueError("native_rollout: xe_pin / col_pin / q_pin have the wrong type or size")
             a.xe_pin, a.col_pin, a.q_pin = (t.ctypes.data for t in pins)
         a.t_xe, a.t_xe_next, a.t_col, a.t_mask = (out[k_].ctypes.data for k_ in ("xe", "xe_next", "col", "mask"))

@@ -80,7 +80,7 @@ class AdvanceArgs(C.Structure):
 
 class RolloutArgs(C.Structure):
     """v2xsim_rollout_args of include/v2xsim.h (same order)"""
-    _fields_ = ([(k, C.c_int32) for k in ("n", "rb", "n_lanes", "T", "n_actions", "pad_")]
+    _fields_ = ([(k, C.c_int32) for k in ("n", "rb", "n_lanes", "T", "n_actions", "batch_predict")]
                 + [(k, C.c_double) for k in ("timestep", "width", "height")]
                 + [(k, C.c_void_p) for k in ("up", "down", "left", "right", "vel", "dest")]
                 + [(k, C.c_double) for k in ("p_v2v", "p_v2i", "veh_gain", "veh_nf", "sig2", "bs_gain", "bs_nf")]

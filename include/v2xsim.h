@@ -80,10 +80,16 @@ int v2xsim_advance_wait(int ticket);
  * them; the t_* arrays receive the T transitions.  Returns T; -1 bad sizes; -2 no memory; -3 another rollout is running;
  * -4 - t: transition t wanted a predict on a graph with a link that is its own receiver (regular == 0) or predict is null;
  * -1000 - t: the predict of transition t failed.  After an early return the environment stands at the state after the transitions
- * that were completed (t of them), numpy's stream after the failed transition's epsilon draw.                                */
+ * that were completed (t of them), numpy's stream after the failed transition's epsilon draw.
+ * batch_predict = 1: nothing in a simulator step depends on the actions and the network does not change inside a rollout, so the
+ * T observations are all known before any action is: the team computes the T states while the caller takes the policy draws (a
+ * greedy transition draws nothing but its epsilon), then `predict` is called ONCE for all T graphs (xe_pin [T][n][16], col_pin
+ * [T][n (n-2)], q_pin [T][n][n_actions]; a graph's Q-values do not depend on the batch around it), then argmax / rates / records
+ * transition by transition.  Same transitions, same streams; a failing batch predict counts as a failure of the first greedy
+ * transition.                                                                                                              */
 typedef int (*v2xsim_predict_fn)(void* ctx);
 typedef struct {
-  int32_t n, rb, n_lanes, T, n_actions, pad_;
+  int32_t n, rb, n_lanes, T, n_actions, batch_predict;
   double timestep, width, height;
   const double *up, *down, *left, *right;
   const double* vel; const int64_t* dest;

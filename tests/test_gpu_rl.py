@@ -424,11 +424,12 @@ def test_forward_to_host_refuses_pageable_host_memory():
     eng.close()
 
 
-@pytest.mark.parametrize("n_veh,feat,batch", [(4, 16, 64), (20, 64, 96)])
-def test_native_rollout_of_one_simulator_is_the_per_transition_rollout_bitwise(n_veh, feat, batch, monkeypatch):
+@pytest.mark.parametrize("n_veh,feat,batch,batch_predict", [(4, 16, 64, True), (20, 64, 96, True), (20, 64, 96, False)])
+def test_native_rollout_of_one_simulator_is_the_per_transition_rollout_bitwise(n_veh, feat, batch, batch_predict, monkeypatch):
     """the reference's loop shape (ONE simulator, 50 sequential transitions with a B = 1 predict each,
     BS_brain.py:409-553, :818-832) as one library call per rollout (v2xsim_rollout; the predict is v2x_forward_call on pinned
-    buffers; the simulator step is computed by a team of threads while the predict is in flight) against the same agent with
+    buffers; the simulator step is computed by a team of threads while the predict is in flight -- or, batch_predict, ALL 50
+    observations first and one predict of 50 graphs: they do not depend on the actions) against the same agent with
     V2X_RL_NATIVE_ROLLOUT=0 (one _packed_iteration per transition): rewards, the bytes of the replay memory, losses, Q
     statistics, weights, both random streams -- bit for bit over two episodes (a reset in between)."""
     from v2xgnn.rl import Agent, RL_Config, native_sim
@@ -440,6 +441,7 @@ def test_native_rollout_of_one_simulator_is_the_per_transition_rollout_bitwise(n
         random.seed(41)
         np.random.seed(41)
         monkeypatch.setenv("V2X_RL_NATIVE_ROLLOUT", "1" if native else "0")
+        monkeypatch.setenv("V2X_RL_ROLLOUT_BATCH_PREDICT", "1" if batch_predict else "0")
         native_sim.set_threads(6 if native else 1)
         env = start_env_batched(n_veh, 1, 41, lookahead=not native)
         cfg = RL_Config()
@@ -455,8 +457,8 @@ def test_native_rollout_of_one_simulator_is_the_per_transition_rollout_bitwise(n
     env_n, ag_n, loss_n, rew_n, qm_n, w_n, mem_n, np_n = run(True)
     env_p, ag_p, loss_p, rew_p, qm_p, w_p, mem_p, np_p = run(False)
     native_sim.set_threads(1)
-    assert getattr(ag_n, "_native_io", None) is not None and "closure" in ag_n._native_io
-    assert getattr(ag_p, "_native_io", None) is None
+    assert getattr(ag_n, "_native_io", None) and all("closure" in io for io in ag_n._native_io.values())
+    assert (50 in ag_n._native_io) == batch_predict and not getattr(ag_p, "_native_io", None)
     assert ag_n.num_step == ag_p.num_step == 2 * 8 * 50 and ag_n.epsilon == ag_p.epsilon
     assert np.array_equal(rew_n, rew_p)
     for a, b in zip(mem_n, mem_p):

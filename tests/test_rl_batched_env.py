@@ -564,8 +564,9 @@ def test_two_host_threads_stepping_two_simulators():
                 assert np.array_equal(a, b), (rep, s)
 
 
-@pytest.mark.parametrize("threads,n", [(1, 20), (6, 20), (4, 8), (12, 12)])
-def test_native_rollout_is_T_single_steps(threads, n):
+@pytest.mark.parametrize("threads,n,batch", [(1, 20, False), (6, 20, False), (4, 8, False), (12, 12, False), (1, 20, True), (6, 20, True),
+                                             (12, 12, True)])
+def test_native_rollout_is_T_single_steps(threads, n, batch):
     """v2xsim_rollout (the reference's loop shape -- ONE simulator, T sequential transitions with a B = 1 predict
     each, BS_brain.py:409-553 -- as one library call with the simulator step cut over a team of threads that works ahead of the
     caller): transitions, rates, the simulator's every array, its MT19937 stream AND numpy's process-wide stream (epsilon draws,
@@ -614,16 +615,20 @@ def test_native_rollout_is_T_single_steps(threads, n):
     native_sim.set_threads(threads)
     env = make()
     np.random.seed(99)
-    xe_pin, col_pin, q_pin = np.zeros((n, 16), np.float32), np.zeros(ne, np.int32), np.zeros((n, C), np.float32)
+    G = T if batch else 1                                    # batch: ONE predict call for all T observations
+    xe_pin, col_pin, q_pin = np.zeros((G * n, 16), np.float32), np.zeros(G * ne, np.int32), np.zeros((G * n, C), np.float32)
+    n_calls = [0]
 
     def predict(_ctx):
-        q_pin[:] = fake_q(xe_pin, col_pin)
+        n_calls[0] += 1
+        for g_ in range(G):
+            q_pin[g_ * n:(g_ + 1) * n] = fake_q(xe_pin[g_ * n:(g_ + 1) * n], col_pin[g_ * ne:(g_ + 1) * ne])
         return 0
     cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(predict)
     out = env.native_rollout(T, C, dict(pol, predict=ctypes.cast(cb, ctypes.c_void_p).value, predict_ctx=None,
-                                        xe_pin=xe_pin, col_pin=col_pin, q_pin=q_pin))
+                                        xe_pin=xe_pin, col_pin=col_pin, q_pin=q_pin, batch_predict=batch))
     native_sim.set_threads(1)
-    assert out["done"] == T and out["n_greedy"] == n_greedy
+    assert out["done"] == T and out["n_greedy"] == n_greedy and n_calls[0] == (1 if batch else n_greedy)
     for k, o in (("xe", "xe"), ("xe_next", "xe_next"), ("col", "col"), ("mask", "mask"), ("action", "action"), ("v2v", "v2v_rate"), ("v2i", "v2i_rate")):
         assert np.array_equal(np.stack(rec[k]), out[o]), k
     got_np = np.random.get_state()
@@ -645,17 +650,27 @@ def test_native_rollout_is_T_single_steps(threads, n):
 
     def flaky(_ctx):
         calls[0] += 1
-        if calls[0] == 3:
+        if calls[0] == (1 if batch else 3):
             return 1
-        q_pin[:] = fake_q(xe_pin, col_pin)
+        q_pin[:n] = fake_q(xe_pin[:n], col_pin[:ne])
         return 0
     cb2 = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)(flaky)
     native_sim.set_threads(threads)
     out2 = env2.native_rollout(T, C, dict(pol, eps_max=0.3, predict=ctypes.cast(cb2, ctypes.c_void_p).value, predict_ctx=None,
-                                          xe_pin=xe_pin, col_pin=col_pin, q_pin=q_pin))
+                                          xe_pin=xe_pin, col_pin=col_pin, q_pin=q_pin, batch_predict=batch))
+    np_after = np.random.get_state()
     native_sim.set_threads(1)
     assert out2["rc"] <= -1000 and 0 <= out2["done"] < T and out2["done"] == -1000 - out2["rc"]
     for t in range(out2["done"]):
         ref2.act(out2["action"][t][None, :, None])
     for k in ("pos", "V2V_channels_with_fastfading", "_mt_keys", "_mt_pos"):
         assert np.array_equal(np.asarray(getattr(env2, k)), np.asarray(getattr(ref2, k))), k
+    # numpy's stream: after the failed transition's epsilon draw (the draws of the completed transitions + that one)
+    np.random.seed(7)
+    for t in range(out2["done"] + 1):
+        step_no = pol["step_no0"] + t
+        eps = 0.3 - pol["eps_per_step"] * step_no if step_no < pol["eps_steps"] else pol["eps_min"]
+        if np.random.random() < eps:
+            assert t < out2["done"]
+            np.random.randint(0, C, size=(n, 1))
+    assert np.random.get_state()[2] == np_after[2] and np.array_equal(np.random.get_state()[1], np_after[1])

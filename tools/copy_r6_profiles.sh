@@ -1,7 +1,7 @@
 # gpurun_out/r6f (tools/gpu_r6_final.sh, merged back from the GPU box) -> the tracked summaries under profiles/
 O=gpurun_out/r6f; P=profiles
 cp $O/bench.json $P/r06_bench.json
-for f in b1024 b2048 b512 b1024_dense0_in_mlp b2048_dense0_in_mlp b512_dense0_in_mlp b4096_dense0_as_roles b65536 cfg4 cfg5 layerwise shared cfg0_episode_envs10 cfg2loop_envs50_run1 cfg2loop_envs50_run2 cfg2loop_envs50_run3 cfg2loop_env1_run1 cfg2loop_env1_run2 cfg2loop_env1_run3 cfg2loop_env1_per_transition cfg2loop_envs50_4000steps; do cp $O/bench_$f.json $P/r06_bench_$f.json; done
+for f in b1024 b2048 b512 b1024_dense0_in_mlp b2048_dense0_in_mlp b512_dense0_in_mlp b4096_dense0_as_roles b65536 cfg4 cfg5 layerwise shared cfg0_episode_envs10 cfg2loop_envs50_run1 cfg2loop_envs50_run2 cfg2loop_envs50_run3 cfg2loop_env1_run1 cfg2loop_env1_run2 cfg2loop_env1_run3 cfg2loop_env1_per_transition cfg2loop_env1_b1_predicts cfg2loop_envs50_4000steps; do cp $O/bench_$f.json $P/r06_bench_$f.json; done
 cp $O/kernel_stats.txt $P/r06_kernel_stats.txt; cp $O/kernel_stats_cfg4.txt $P/r06_kernel_stats_cfg4.txt; cp $O/kernel_stats_cfg5.txt $P/r06_kernel_stats_cfg5.txt
 for g in 2 4 8; do cp $O/kernel_stats_share$g.txt $P/r06_kernel_stats_share$g.txt; cp $O/mfma_share$g.txt $P/r06_pmc_share$g.txt; done
 cp $O/stalls.txt $P/r06_stalls.txt

@@ -57,7 +57,8 @@ python bench.py --workload cfg0 --envs 10 > $O/bench_cfg0_episode_envs10.json 2>
 for i in 1 2 3; do python bench.py --workload cfg2loop --envs 50 --episodes 5 > $O/bench_cfg2loop_envs50_run$i.json 2>/dev/null; done
 for i in 1 2 3; do python bench.py --workload cfg2loop --envs 1 --episodes 2 > $O/bench_cfg2loop_env1_run$i.json 2>/dev/null; done
 V2X_RL_NATIVE_ROLLOUT=0 python bench.py --workload cfg2loop --envs 1 --episodes 2 > $O/bench_cfg2loop_env1_per_transition.json 2>/dev/null
-for T in 3 4 6 8 12; do echo "V2X_SIM_THREADS=$T: $(V2X_SIM_THREADS=$T python bench.py --workload cfg2loop --envs 1 --episodes 2 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["config"]["split"])')"; done > $O/loop_env1_threads.txt
+V2X_RL_ROLLOUT_BATCH_PREDICT=0 python bench.py --workload cfg2loop --envs 1 --episodes 2 > $O/bench_cfg2loop_env1_b1_predicts.json 2>/dev/null
+for T in 3 4 6 8 10 12; do echo "V2X_SIM_THREADS=$T: $(V2X_SIM_THREADS=$T python bench.py --workload cfg2loop --envs 1 --episodes 2 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["ms_per_step"], d["config"]["split"])')"; done > $O/loop_env1_threads.txt
 python bench.py --workload cfg2loop --envs 50 --episodes 200 > $O/bench_cfg2loop_envs50_4000steps.json 2>/dev/null
 python tools/predict_latency.py 2>&1 | grep -v amdgpu.ids > $O/predict_latency.txt
 python tools/dropin_profile.py 2>&1 | grep -v amdgpu.ids > $O/dropin_profile.txt

@@ -398,6 +398,40 @@ static inline uint32_t mt_next(uint32_t* mt, int32_t* pos) {
   y ^= y >> 18;
   return y;
 }
+/* The next `count` doubles of a stream in bulk: the state array is consumed block by block -- tempering and the
+ * (a >> 5, b >> 6) -> double conversion are loops over arrays the compiler vectorises -- instead of one call, one position check
+ * and one scalar tempering per 32-bit output (26 us per 3780 doubles: the sequential part of a 20-link simulator step).  Same
+ * outputs in the same order as `count` calls of mt_double. */
+static void mt_fill_doubles(uint32_t* mt, int32_t* pos, double* out, int count) {
+  uint32_t tmp[1248];
+  int done = 0;
+  while (done < count) {
+    const int want = count - done < 624 ? count - done : 624;     /* doubles of this round: <= 1248 outputs */
+    int got = 0;
+    const int need = 2 * want;
+    while (got < need) {
+      if (*pos >= 624) { mt_reload(mt); *pos = 0; }
+      int take = 624 - *pos;
+      if (take > need - got) take = need - got;
+      const uint32_t* src = mt + *pos;
+      for (int i = 0; i < take; ++i) {
+        uint32_t y = src[i];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        tmp[got + i] = y;
+      }
+      got += take;
+      *pos += take;
+    }
+    for (int i = 0; i < want; ++i) {
+      const uint32_t a = tmp[2 * i] >> 5, b = tmp[2 * i + 1] >> 6;
+      out[done + i] = (a * 67108864.0 + b) / 9007199254740992.0;
+    }
+    done += want;
+  }
+}
 /* out[e][0..n_u) = the next n_u doubles of stream e */
 typedef struct { uint32_t* keys; int32_t* pos; double* out; int n_u; } uniforms_ctx;
 static void uniforms_one(int e, void* q) {
@@ -405,10 +439,7 @@ static void uniforms_one(int e, void* q) {
   uint32_t* mt = c->keys + (int64_t)e * 624;
   int32_t p = c->pos[e];
   double* o = c->out + (int64_t)e * c->n_u;
-  for (int k = 0; k < c->n_u; ++k) {
-    const uint32_t a = mt_next(mt, &p) >> 5, b = mt_next(mt, &p) >> 6;
-    o[k] = (a * 67108864.0 + b) / 9007199254740992.0;
-  }
+  mt_fill_doubles(mt, &p, o, c->n_u);
   c->pos[e] = p;
 }
 void v2xsim_mt_uniforms(int E, uint32_t* keys, int32_t* pos, double* out, int n_u) {
@@ -566,7 +597,7 @@ static void advance_one(int e, void* q) {
   const double* ve = a->vel + (int64_t)e * n;
   positions_env(n, mt, &p, xy, dirs, ve, a->timestep, a->n_lanes, a->up, a->down, a->left, a->right, a->width, a->height);
   double* u = a->scratch + (int64_t)e * 2 * n_u;
-  for (int k = 0; k < n_u; ++k) u[k] = mt_double(mt, &p);
+  mt_fill_doubles(mt, &p, u, n_u);
   a->mtpos[e] = p;
   double* fv = a->v2v_ff + (int64_t)e * n * n * rb;
   double* fi = a->v2i_ff + (int64_t)e * n * rb;
@@ -646,7 +677,7 @@ static void ro_stream_step(ro_ctx* c, int k) {
   memcpy(s->xy, xy_prev, (size_t)n * 2 * sizeof(double));
   memcpy(s->dirs, d_prev, (size_t)n);
   positions_env(n, c->mt, &c->mtpos, s->xy, s->dirs, a->vel, a->timestep, a->n_lanes, a->up, a->down, a->left, a->right, a->width, a->height);
-  for (int i = 0; i < c->n_u; ++i) s->u[i] = mt_double(c->mt, &c->mtpos);
+  mt_fill_doubles(c->mt, &c->mtpos, s->u, c->n_u);
 }
 /* worker `w` of `K`, the three phases of step k (channels_env / interference_env / observe_env cut by index ranges) */
 static void ro_gauss(ro_ctx* c, int k, int w, int K) {

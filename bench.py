@@ -991,6 +991,20 @@ def other_workloads(args, ctx):
     # the key says which loop: 50 simulators stepped as arrays, or the reference's shape (one simulator, 50 sequential transitions)
     guarded("cfg2loop_envs50", lambda: dqn_loop(50, 5))
     guarded("cfg2loop_env1", lambda: dqn_loop(1, 2))
+
+    def env1_b1():
+        # the same one-simulator loop with a B = 1 predict for every greedy transition (the default scores the rollout's 50
+        # observations -- which do not depend on the actions -- with ONE predict; identical transitions either way)
+        had = os.environ.get("V2X_RL_ROLLOUT_BATCH_PREDICT")
+        os.environ["V2X_RL_ROLLOUT_BATCH_PREDICT"] = "0"
+        try:
+            return dqn_loop(1, 2)
+        finally:
+            if had is None:
+                del os.environ["V2X_RL_ROLLOUT_BATCH_PREDICT"]
+            else:
+                os.environ["V2X_RL_ROLLOUT_BATCH_PREDICT"] = had
+    guarded("cfg2loop_env1_b1_predicts", env1_b1)
     return out
 
 
@@ -1021,6 +1035,7 @@ def summary(out, others, dropin, cpu):
           "cfg5_cpu": cpu_of("cfg5"),
           "per_edge_ms": get("per_edge_gather", "ms_per_step"),
           "cfg2loop_envs50_ms": get("cfg2loop_envs50", "ms_per_train_step", 3), "cfg2loop_env1_ms": get("cfg2loop_env1", "ms_per_train_step", 3),
+          "cfg2loop_env1_b1_predicts_ms": get("cfg2loop_env1_b1_predicts", "ms_per_train_step", 3),
           "dropin_ms": (dropin or {}).get("replay_triple_ms"), "predict_one_us": (dropin or {}).get("predict_one_step_us")}
     return sm
 

@@ -326,10 +326,10 @@ def cpu_baseline(N, F, L, share, B, budget_s=30.0, full=False):
     return {"value": main_leg["graphs_per_s"], "unit": "graph-instances/s", "usable_cpus": usable, "workers": int(main_leg["threads"]),
             "cores": int(min(main_leg["threads"], usable)), "kind": "port",
             "cpu_model": cpu_model(), "host_cores": host_cores,
-            "sample": "median of %d fit steps of B=%d (N=%d,F=%d,L=%d,%s weights) after 1 warm-up, numpy fp32 CSR oracle "
-                      "(leg C2, %d worker(s)); a CPU restatement of the reference math, not Keras/TF1; legs: C0 = the reference's "
-                      "formulation (dense kron adjacency) N=4 F=16 B=512, C1 = the same at N=20 F=64 B=256, C2 = compact CSR at the benchmark's size"
-                      % (main_leg["steps"], main_leg["batch"], N, F, L, "shared" if share else "per-node", main_leg["threads"]),
+            "sample": ("median of %d fit steps of B=%d (N=%d,F=%d,L=%d,%s weights), numpy fp32 CSR oracle (leg C2, %d worker(s)); a CPU "
+                       "restatement, not Keras/TF1" % (main_leg["steps"], main_leg["batch"], N, F, L, "shared" if share else "per-node", main_leg["threads"]))
+                      + ("; legs: C0 = the reference's formulation (dense kron adjacency) N=4 F=16 B=512, C1 = the same at N=20 F=64 B=256, "
+                         "C2 = compact CSR at the benchmark's size" if full else ""),
             "legs": legs}
 
 
@@ -982,6 +982,9 @@ def other_workloads(args, ctx):
         with torch.cuda.stream(torch.cuda.Stream()):
             r = rl_episode(20, 64, 4096, 0.5, 20, 1001, use_graph=True, envs=envs, episodes=episodes)
         r["simulators"], r["episodes"] = max(envs, 1), episodes
+        if not args.other_kernels:
+            for k_ in ("wall_s", "train_steps_per_s", "rollout_s", "replay_s", "env_steps"):
+                r.pop(k_, None)
         if args.other_kernels:
             r["workload"] = ("BASELINE.json configs[2] on one GPU: %d episodes x 20 train steps x (50 rollout transitions on %s + 1 replay "
                              "of batch 4096), 20 links, feat_dim 64; one agent, two-step warm-up episode outside the timed region"
@@ -1093,8 +1096,7 @@ def main():
     if rank == 0:
         out["cpu_baseline"] = cpu
         if "kernels" in out:
-            out["kernels_note"] = ("HIP events around eager launches of an instrumented pass (roofline.avg_launch_us comes from it); their sum "
-                                   "exceeds ms_per_step, which is the hipGraph replay of the same launches; rocprofv3 averages: profiles/")
+            out["kernels_note"] = "HIP events, eager launches; their sum exceeds the replayed step (ms_per_step); rocprofv3: profiles/"
         if dropin is not None:
             out["dropin_ref_config"] = dropin
             if not args.other_kernels:

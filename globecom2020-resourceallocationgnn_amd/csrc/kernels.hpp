@@ -1676,10 +1676,26 @@ __global__ __launch_bounds__(256) void k_reduce_adam(AdamArgs a) {
         int l = 0;
         while (l + 1 < a.n_layers && i >= a.layer_end4[l]) ++l;
         const int ns = a.layer_slabs[l];
-        for (int c = grp; c < ns; c += G) {
-          const float4 t = reinterpret_cast<const float4*>(a.slab + c * a.slab_stride)[i];
+        // four slabs in flight and four running sums (one load, one dependent add at a time made the column's sum a chain of ns
+        // memory round trips); fixed order: (s0 + s1) + (s2 + s3) with s_u = slabs grp + u G, grp + (u + 4) G, ...
+        float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f), g2 = g1, g3 = g1;
+        int c = grp;
+        for (; c + 3 * G < ns; c += 4 * G) {
+          const float4 t0 = reinterpret_cast<const float4*>(a.slab + (int64_t)c * a.slab_stride)[i];
+          const float4 t1 = reinterpret_cast<const float4*>(a.slab + (int64_t)(c + G) * a.slab_stride)[i];
+          const float4 t2 = reinterpret_cast<const float4*>(a.slab + (int64_t)(c + 2 * G) * a.slab_stride)[i];
+          const float4 t3 = reinterpret_cast<const float4*>(a.slab + (int64_t)(c + 3 * G) * a.slab_stride)[i];
+          g.x += t0.x; g.y += t0.y; g.z += t0.z; g.w += t0.w;
+          g1.x += t1.x; g1.y += t1.y; g1.z += t1.z; g1.w += t1.w;
+          g2.x += t2.x; g2.y += t2.y; g2.z += t2.z; g2.w += t2.w;
+          g3.x += t3.x; g3.y += t3.y; g3.z += t3.z; g3.w += t3.w;
+        }
+        for (; c < ns; c += G) {
+          const float4 t = reinterpret_cast<const float4*>(a.slab + (int64_t)c * a.slab_stride)[i];
           g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w;
         }
+        g.x = (g.x + g1.x) + (g2.x + g3.x); g.y = (g.y + g1.y) + (g2.y + g3.y);
+        g.z = (g.z + g1.z) + (g2.z + g3.z); g.w = (g.w + g1.w) + (g2.w + g3.w);
         // a layer with no slabs had its gradient written straight into the gradient buffer (wide path, one row split)
         if (ns == 0 && grp == 0) g = reinterpret_cast<const float4*>(a.grad_direct)[i];
         direct = ns == 0 && a.grad == a.grad_direct;       // already where it belongs: no copy
@@ -1799,7 +1815,7 @@ __global__ __launch_bounds__(256) void k_gather_rows_multi(GatherJobs jobs, cons
 constexpr int QS_PARTS = 8;
 __global__ __launch_bounds__(256) void k_q_stats(const float* y, int B, int N, int C, double* out, double* part, unsigned* cnt) {
   __shared__ double s_all[256], s_max[256];
-  __shared__ unsigned s_last;
+  unsigned s_last;
   const int k = blockIdx.x, pz = blockIdx.y;
   const int b0 = (int)((int64_t)B * pz / QS_PARTS), b1 = (int)((int64_t)B * (pz + 1) / QS_PARTS);
   double a = 0.0, m = 0.0;
@@ -1817,22 +1833,21 @@ __global__ __launch_bounds__(256) void k_q_stats(const float* y, int B, int N, i
     if ((int)threadIdx.x < st) { s_all[threadIdx.x] += s_all[threadIdx.x + st]; s_max[threadIdx.x] += s_max[threadIdx.x + st]; }
     __syncthreads();
   }
+  // (agent-scope atomics, as in k_reduce_adam's loss role: the parts cross XCD L2s)
   if (threadIdx.x == 0) {
-    part[((int64_t)k * QS_PARTS + pz) * 2] = s_all[0];
-    part[((int64_t)k * QS_PARTS + pz) * 2 + 1] = s_max[0];
-    __threadfence();
-    s_last = atomicAdd(cnt + k, 1u) == QS_PARTS - 1 ? 1u : 0u;
-  }
-  __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    __threadfence();
-    double ta = 0.0, tm = 0.0;
-    for (int q = 0; q < QS_PARTS; ++q) {
-      ta += __builtin_nontemporal_load(part + ((int64_t)k * QS_PARTS + q) * 2);
-      tm += __builtin_nontemporal_load(part + ((int64_t)k * QS_PARTS + q) * 2 + 1);
+    __hip_atomic_store(part + ((int64_t)k * QS_PARTS + pz) * 2, s_all[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(part + ((int64_t)k * QS_PARTS + pz) * 2 + 1, s_max[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ticket = __hip_atomic_fetch_add(cnt + k, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = ticket == QS_PARTS - 1 ? 1u : 0u;
+    if (s_last) {
+      double ta = 0.0, tm = 0.0;
+      for (int q = 0; q < QS_PARTS; ++q) {
+        ta += __hip_atomic_load(part + ((int64_t)k * QS_PARTS + q) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tm += __hip_atomic_load(part + ((int64_t)k * QS_PARTS + q) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      out[k] = ta; out[N + k] = tm;
+      __hip_atomic_store(cnt + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-armed for the next launch
     }
-    out[k] = ta; out[N + k] = tm;
-    cnt[k] = 0u;                                                  // re-armed for the next launch
   }
 }
 

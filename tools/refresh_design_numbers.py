@@ -36,5 +36,14 @@ sub(r"\| 4 \| 0\.152 → %s \|" % num, "| 4 | 0.152 → %.4f |" % ms('b1024'))
 sub(r"\| 8 \| 0\.121 → %s \|" % num, "| 8 | 0.121 → %.4f |" % ms('b512'))
 sub(r"%s ms \(305 k graphs/s\) / %s ms" % (num, num), "%.2f ms (305 k graphs/s) / %.3f ms" % (ms('cfg4'), ms('cfg5')))
 sub(r"shared weights %s ms; batch 65,536 %s ms" % (num, num), "shared weights %.4f ms; batch 65,536 %.2f ms" % (ms('shared'), ms('b65536')))
+l1 = [ms('cfg2loop_env1_run%d' % i) for i in (1, 2, 3)]
+sub(r"\*\*[0-9.]+-9\.7 → [0-9.]+-[0-9.]+ ms per train step\*\*", "**%.1f-9.7 → %.1f-%.1f ms per train step**" % (min(9.1, ms('cfg2loop_env1_per_transition')), min(l1), max(l1)))
+sub(r"with a B = 1 predict per greedy transition [0-9.]+-3\.6 ms", "with a B = 1 predict per greedy transition %.1f-3.6 ms" % ms('cfg2loop_env1_b1_predicts'))
+thr = open('profiles/r06_loop_env1_threads.txt').read().strip().splitlines()
+sub(r"by team size \(`profiles/r06_loop_env1_threads\.txt`\): [^\n]*?\.\n", "by team size (`profiles/r06_loop_env1_threads.txt`): " + "; ".join(
+    "%s threads %.2f ms" % (l.split(':')[0].split('=')[1], float(l.split(':')[1].split()[0])) for l in thr) + ".\n")
+sub(r"\*\*[0-9.]+ / [0-9.]+ / [0-9.]+\*\* ms per train step \(0\.84-1\.13 across the day's boxes; round 5: 0\.97-1\.12\); 4000 train steps [0-9.]+\.",
+    "**%s** ms per train step (0.84-1.13 across the day's boxes; round 5: 0.97-1.12); 4000 train steps %.2f." % (
+        " / ".join("%.2f" % ms('cfg2loop_envs50_run%d' % i) for i in (1, 2, 3)), ms('cfg2loop_envs50_4000steps')))
 open('DESIGN.md', 'w').write(s)
 print("headline %.4f ms, shares %.4f / %.4f / %.4f, cfg4 %.2f, cfg5 %.3f" % (d['ms_per_step'], ms('b512'), ms('b1024'), ms('b2048'), ms('cfg4'), ms('cfg5')))

@@ -660,6 +660,8 @@ typedef struct {
   double *si, *sv;                                 /* shadowing, updated in place by the workers */
   double* gw[RO_MAXW];                             /* batch mode: a private Gaussian scratch per worker [n_u] */
   int batch;
+  const ro_state* s0;                              /* state 0 (the caller's arrays), for the team's record phase */
+  _Atomic int records_go, records_done;            /* batch mode: n_ok + 1 once the actions are known; workers that finished */
   _Atomic int stream_done, main_pos, workers_done, bar, stop;
   _Atomic int steps_of[RO_MAXW];                   /* batch mode: steps worker w has finished (the stream thread's ring follows the slowest) */
 } ro_ctx;
@@ -791,6 +793,7 @@ static void ro_barrier(ro_ctx* c, int* phase) {    /* among the K workers */
   atomic_fetch_add_explicit(&c->bar, 1, memory_order_acq_rel);
   ro_spin(&c->bar, *phase * c->K);
 }
+static void ro_record(const v2xsim_rollout_args* a, int t, const ro_state* cur, const int64_t* act, double* side);
 static void ro_worker(ro_ctx* c, int w) {
   int phase = 0;
   if (c->batch) {                                  /* all steps on the own ranges, ONE barrier, then the observation rows of all states */
@@ -803,6 +806,16 @@ static void ro_worker(ro_ctx* c, int w) {
     for (int k = 0; k < c->T; ++k) ro_observe(c, k, w, c->K);
     ro_barrier(c, &phase);
     if (w == 0) atomic_store_explicit(&c->workers_done, c->T, memory_order_release);
+    /* the caller takes the predict and the argmax; then every worker the rates + records of its transitions */
+    while (atomic_load_explicit(&c->records_go, memory_order_acquire) == 0) __builtin_ia32_pause();
+    const int n_ok = atomic_load_explicit(&c->records_go, memory_order_acquire) - 1;
+    const v2xsim_rollout_args* a = c->a;
+    for (int t = w; t < n_ok; t += c->K) {
+      const ro_state* cur = t == 0 ? c->s0 : &c->st[t % c->ns];
+      ro_record(a, t, cur, a->t_action + (int64_t)t * c->n, t == n_ok - 1 ? 0 : c->gw[w]);
+      memcpy(a->t_xe_next + (int64_t)t * c->n * 16, c->st[(t + 1) % c->ns].xe, (size_t)c->n * 16 * sizeof(float));
+    }
+    atomic_fetch_add_explicit(&c->records_done, 1, memory_order_acq_rel);
     return;
   }
   for (int k = 0; k < c->T; ++k) {
@@ -935,12 +948,13 @@ static void ro_argmax(const v2xsim_rollout_args* a, const float* q, int64_t* act
     act[i] = best;
   }
 }
-/* rates on the channels of state t + the transition's record (everything but xe_next) */
-static void ro_record(const v2xsim_rollout_args* a, int t, const ro_state* cur, const int64_t* act) {
+/* rates on the channels of state t + the transition's record (everything but xe_next).  side: [2 rb + n] doubles for
+ * v2xsim_reward's side outputs (interference, with noise, per link), or null = the caller's arrays (the LAST transition's are kept) */
+static void ro_record(const v2xsim_rollout_args* a, int t, const ro_state* cur, const int64_t* act, double* side) {
   const int n = a->n, rb = a->rb, ne = n * (n - 2), m = rb < n ? rb : n;
   reward_ctx r = { n, rb, act, a->dest, cur->v2v_ff, cur->v2i_ff, cur->v2i_abs, a->p_v2v, a->p_v2i, a->veh_gain, a->bs_gain, a->bs_nf,
-                   a->veh_nf, a->sig2, a->t_v2v_rate + (int64_t)t * n, a->t_v2i_rate + (int64_t)t * m, a->interference, a->v2i_interf,
-                   a->v2v_interf };
+                   a->veh_nf, a->sig2, a->t_v2v_rate + (int64_t)t * n, a->t_v2i_rate + (int64_t)t * m, side ? side : a->interference,
+                   side ? side + rb : a->v2i_interf, side ? side + 2 * rb : a->v2v_interf };
   reward_one(0, &r);
   memcpy(a->t_xe + (int64_t)t * n * 16, cur->xe, (size_t)n * 16 * sizeof(float));
   memcpy(a->t_col + (int64_t)t * ne, cur->col, (size_t)ne * sizeof(int32_t));
@@ -1054,8 +1068,15 @@ int v2xsim_rollout(v2xsim_rollout_args* a) {
     for (int t = 0; t < n_ok; ++t) {
       int64_t* act = a->t_action + (int64_t)t * n;
       if (!explores[t]) ro_argmax(a, a->q_pin + (int64_t)t * n * a->n_actions, act);
-      ro_record(a, t, RO_STATE(t), act);
-      memcpy(a->t_xe_next + (int64_t)t * n * 16, c.st[(t + 1) % ns].xe, (size_t)n * 16 * sizeof(float));
+      if (!team) {
+        ro_record(a, t, RO_STATE(t), act, 0);
+        memcpy(a->t_xe_next + (int64_t)t * n * 16, c.st[(t + 1) % ns].xe, (size_t)n * 16 * sizeof(float));
+      }
+    }
+    if (team) {                                    /* rates + records of the transitions on the team (t = w, w + K, ...): ~6 us of pow / log2 each */
+      c.s0 = &s0;
+      atomic_store_explicit(&c.records_go, n_ok + 1, memory_order_release);
+      ro_spin(&c.records_done, c.K);
     }
     if (n_ok < T) {                                /* numpy's stream: where the failed transition's epsilon draw left it */
       memcpy(a->np_key, np_key0, sizeof(np_key0));
@@ -1083,7 +1104,7 @@ int v2xsim_rollout(v2xsim_rollout_args* a) {
         ro_argmax(a, a->q_pin, act);
         ++*a->n_greedy;
       }
-      ro_record(a, t, cur, act);                   /* rates on the channels of state t (compute_reward_with_channel_selection) */
+      ro_record(a, t, cur, act, 0);                /* rates on the channels of state t (compute_reward_with_channel_selection) */
       ro_spin(&c.workers_done, t + 1);             /* state t + 1 */
       memcpy(a->t_xe_next + (int64_t)t * n * 16, c.st[(t + 1) % ns].xe, (size_t)n * 16 * sizeof(float));
     }

@@ -1081,6 +1081,10 @@ struct WgradArgs {
   // a role that covers only PART of the layer's K rows (Dense-0 cut in two, WG_KIND_DENSE0A / B): padded K row of its first
   // segment; the bias gradient is written by the role with bias_too set
   int k_off, no_bias;
+  // k_wgrad MODE 4: the next `chain` roles of the launch have no workgroups of their own -- this role's workgroup runs them after
+  // its own body, for the same (chunk, slot): the light Dense 1..3 roles behind the Dense-0 halves, whose workgroups are the
+  // lightest of the grid (25 + 8 and 20 + 15 accumulator tiles against a graph layer's 36 + its share of the embed layer)
+  int chain, pad_;
 };
 
 constexpr int WG_TR = 16;        // rows per MFMA block (chunk sizes are multiples of it)
@@ -1498,7 +1502,8 @@ enum { WG_KIND_GNN = 0, WG_KIND_EMBED = 1, WG_KIND_DENSE0 = 2, WG_KIND_DENSE1 = 
        WG_KIND_DENSE0A = 10, WG_KIND_DENSE0A_F = 11, WG_KIND_DENSE0B = 12, WG_KIND_DENSE0B_F = 13 };
 
 // MODE 0: the GNN stages, 1: the Dense layers, 2: both families in one launch (roles ordered heaviest first),
-// 3: the GNN stages + Dense-0 in two halves (small batches: kernels_mlpwg.hpp WG0 = false leaves dz1 for it)
+// 3: the GNN stages + Dense-0 in two halves (small batches: kernels_mlpwg.hpp WG0 = false leaves dz1 for it),
+// 4: 3 + Dense 1..3 (smaller batches still: kernels_mlpstream.hpp)
 template <int F, int MODE>
 __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1533,7 +1538,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
     if (a.kind == WG_KIND_EMBED) { wgrad_body<XE, F, 0, F, 3>(a, smem, bx_, slot_); return; }
     if (a.kind == WG_KIND_EMBED_NONBR) { wgrad_body<XE, F, 0, F, 3, true>(a, smem, bx_, slot_); return; }
   }
-  if constexpr (MODE == 3) {
+  if constexpr (MODE == 3 || MODE == 4) {
     // (a half's block is 100 / 80 MFMAs, 1.2-1.4 us: with one block of loads in flight -- DEPTH 2 -- a wave waits 3.6 us per
     //  block for memory, measured at the 512- / 1024-graph shares; three in flight next to 100 accumulators still fit)
     if (a.kind == WG_KIND_DENSE0A) wgrad_body<F, XE, 0, H1, V2X_WG_DEPTH_D0>(a, smem, bx_, slot_);
@@ -1541,6 +1546,18 @@ __global__ __launch_bounds__(256, 1) void k_wgrad(WgradMulti mu) {
     if constexpr (F == 64) {
       if (a.kind == WG_KIND_DENSE0A_F) wgrad_body<F, XE, 0, H1, V2X_WG_DEPTH_D0, false, 0, true>(a, smem, bx_, slot_);
       else if (a.kind == WG_KIND_DENSE0B_F) wgrad_body<F, 0, 0, H1, V2X_WG_DEPTH_D0, false, 0, true>(a, smem, bx_, slot_);
+    }
+  }
+  if constexpr (MODE == 4) {              // + Dense 1..3 (kernels_mlpstream.hpp leaves their operands in memory), chained behind the halves
+    const int n_chain = a.chain;          // (workgroup-uniform)
+    for (int c = 1; c <= n_chain; ++c) {
+      __syncthreads();                    // (the previous body's accumulator exchange is done with the LDS)
+      CWords cw = kw + (role + c) * NW;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) dstw[i] = cw[i];
+      if (a.kind == WG_KIND_DENSE1) wgrad_body<H1, 0, 0, H2P>(a, smem, bx_, slot_);
+      else if (a.kind == WG_KIND_DENSE2) wgrad_body<H2P, 0, 0, H3P>(a, smem, bx_, slot_);
+      else if (a.kind == WG_KIND_DENSE3) wgrad_body<H3P, 0, 0, CP>(a, smem, bx_, slot_);
     }
   }
   if constexpr (MODE == 1 || MODE == 2) {

@@ -7,6 +7,7 @@
 #include "kernels_fused.hpp"
 #include "kernels_fused_split.hpp"
 #include "kernels_mlpwg.hpp"
+#include "kernels_mlpstream.hpp"
 #include "kernels_small.hpp"
 #include "kernels_ragged.hpp"
 #include "kernels_ragged_small.hpp"
@@ -119,6 +120,8 @@ struct v2x_model {
   std::map<GraphKey, GraphEntry> graphs;
   bool capturing = false;
   // wide path, single-GPU training: the layers' weight gradients are collected and launched as ONE grid (wide_wgrad_flush)
+  float* mlp_img = nullptr;                     // padded images of the Dense layers per slot in global memory (kernels_mlpstream.hpp)
+  bool mlp_stream_now = false;                  // inside a backward pass whose MLP is k_mlp_stream: ALL Dense weight gradients are roles of k_wgrad
   bool dense0_out_now = false;                  // inside a backward pass whose MLP launch leaves Dense-0's weight gradient to k_wgrad
   // inside a DQN replay step whose MLP launch forms the targets itself (MlpArgs::tq): replaced entries, actions, where y goes
   const float* dqn_tq = nullptr; float* dqn_y = nullptr;
@@ -241,6 +244,7 @@ void set_attrs_f() {
   allow_big_lds((const void*)k_wgrad<F, 0>);
   allow_big_lds((const void*)k_wgrad<F, 1>);
   allow_big_lds((const void*)k_wgrad<F, 2>);
+  if (F == 64) { allow_big_lds((const void*)k_wgrad<64, 4>); allow_big_lds((const void*)k_mlp_image<64>); }
 }
 
 template <int F>
@@ -1107,12 +1111,15 @@ int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti
   dim3 grid(nc, x.grid_y, n_roles);
   {                                     // unequal chunk counts: a packed 1-D grid of the real workgroups (kernels.hpp WgradMulti)
     bool uneven = false;
-    for (int i = 0; i < n_roles; ++i) uneven = uneven || mu.w[i].n_chunks != nc;
+    for (int i = 0; i < n_roles; ++i) uneven = uneven || mu.w[i].n_chunks != nc || mu.w[i].chain > 0;
     mu.packed = uneven ? 1 : 0;
-    int at = 0;
+    int at = 0, follow = 0;                 // (the `chain` roles behind a role are run by ITS workgroups: none of their own)
     for (int i = 0; i <= WG_MAX_ROLES; ++i) {
       mu.wg_begin[i] = at;
-      if (i < n_roles) at += mu.w[i].n_chunks * x.grid_y;
+      if (i < n_roles) {
+        if (follow > 0) --follow;
+        else { at += mu.w[i].n_chunks * x.grid_y; follow = mu.w[i].chain; }
+      }
     }
     if (uneven) grid = dim3(at, 1, 1);
   }
@@ -1124,7 +1131,11 @@ int launch_wgrad_multi(v2x_model* m, hipStream_t st, const IdxMap& x, WgradMulti
   }
 #define V2X_WG_CASE(FF)                                                              \
   if (m->F == FF) {                                                                  \
-    if (halves) { auto k = k_wgrad<FF, 3>; LAUNCH(m, name, k, grid, lds, st, mu); }    \
+    if (halves && dense) {                                                           \
+      if constexpr (FF == 64) { auto k = k_wgrad<64, 4>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
+      else FAIL(m, V2X_ESTATE, "wgrad: Dense roles next to the Dense-0 halves need feat_dim 64");  \
+    }                                                                                \
+    else if (halves) { auto k = k_wgrad<FF, 3>; LAUNCH(m, name, k, grid, lds, st, mu); }    \
     else if (dense && gnn) { auto k = k_wgrad<FF, 2>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
     else if (dense) { auto k = k_wgrad<FF, 1>; LAUNCH(m, name, k, grid, lds, st, mu); }  \
     else { auto k = k_wgrad<FF, 0>; LAUNCH(m, name, k, grid, lds, st, mu); }           \
@@ -1267,14 +1278,29 @@ int wgrad_gnn_all(v2x_model* m, hipStream_t st, const IdxMap& x, const DevBatch&
       WgSeg sa[2] = {WgSeg{m->h[L], F, F, 0, 0}, WgSeg{d.xe, XE, XE, F, 0}};
       CHK(wgrad_role(m, m->dense[0], groups ? WG_KIND_DENSE0A_F : WG_KIND_DENSE0A, x, total, sa, 2, m->dz1, H1, mu.w[n], rows_d));
       mu.w[n].frag_groups = groups; mu.w[n].kp = F + XE;
-      ++n;
+      const int first_half = n++;
+      // (k_mlp_stream: Dense 1..3 from the rows it left -- z1..z3, dz2, dz3, dq -- as roles WITHOUT workgroups of their own, run by
+      //  the halves' workgroups behind their own bodies, WgradArgs::chain: as roles of their own in 512-row chunks they made the
+      //  launch 35 us instead of 21.6 at the 512-graph share)
+      if (m->mlp_stream_now) {
+        WgSeg s2[1] = {WgSeg{m->z2, H2, H2, 0, 1}};
+        CHK(wgrad_role(m, m->dense[2], WG_KIND_DENSE2, x, total, s2, 1, m->dz3, H3, mu.w[n++], rows_d));
+        WgSeg s3[1] = {WgSeg{m->z3, H3, H3, 0, 1}};
+        CHK(wgrad_role(m, m->dense[3], WG_KIND_DENSE3, x, total, s3, 1, m->dq, m->C, mu.w[n++], rows_d));
+        mu.w[first_half].chain = 2;
+      }
       WgSeg sb[1] = {WgSeg{m->a[L], F, F, 0, 0}};
       CHK(wgrad_role(m, m->dense[0], groups ? WG_KIND_DENSE0B_F : WG_KIND_DENSE0B, x, total, sb, 1, m->dz1, H1, mu.w[n], rows_d));
       mu.w[n].frag_groups = groups; mu.w[n].kp = F; mu.w[n].k_off = F + XE; mu.w[n].no_bias = 1;
-      ++n;
+      const int second_half = n++;
+      if (m->mlp_stream_now) {
+        WgSeg s1[1] = {WgSeg{m->z1, H1, H1, 0, 0}};
+        CHK(wgrad_role(m, m->dense[1], WG_KIND_DENSE1, x, total, s1, 1, m->dz2, H2, mu.w[n++], rows_d));
+        mu.w[second_half].chain = 1;
+      }
     }
     m->gnn[0].n_slabs = m->gnn[1].n_slabs;                     // every stage role writes its columns of every embed slab
-    return launch_wgrad_multi(m, st, x, mu, n, d0 ? "k_wgrad_gnn_d0" : "k_wgrad_gnn");
+    return launch_wgrad_multi(m, st, x, mu, n, m->mlp_stream_now ? "k_wgrad_gnn_d0123" : (d0 ? "k_wgrad_gnn_d0" : "k_wgrad_gnn"));
   }
   if (m->dense0_out_now) FAIL(m, V2X_ESTATE, "wgrad: Dense-0 was left to a launch that cannot take it");
   int n = 0, s_first = m->L;
@@ -1530,7 +1556,7 @@ int launch_pack(v2x_model* m, hipStream_t st) {
   return V2X_OK;
 }
 
-#define LAUNCH_T(m, kname, kern, grid, threads, lds, stream, args)                        \
+#define LAUNCH_T(m, kname, kern, grid, threads, lds, stream, ...)                         \
   do {                                                                                  \
     ProfRec _r;                                                                         \
     const bool _p = (m) && (m)->prof && !(m)->capturing;                                \
@@ -1539,7 +1565,7 @@ int launch_pack(v2x_model* m, hipStream_t st) {
       hipEventCreate(&_r.ev0); hipEventCreate(&_r.ev1);                                     \
       hipEventRecord(_r.ev0, stream);                                                     \
     }                                                                                   \
-    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, args);                   \
+    hipLaunchKernelGGL(kern, grid, dim3(threads), lds, stream, __VA_ARGS__);            \
     if (_p) { hipEventRecord(_r.ev1, stream); (m)->prof_recs.push_back(_r); }             \
     hipError_t _e = hipGetLastError();                                                  \
     if (_e != hipSuccess) FAIL(m, V2X_EHIP, "launch %s failed: %s", kname, hipGetErrorString(_e)); \
@@ -1811,6 +1837,28 @@ int launch_ragged_bwd(v2x_model* m, hipStream_t st, const DevBatch& d) {
   FAIL(m, V2X_EINVAL, "ragged backward: unsupported feat_dim %d", m->F);
 }
 
+// OPT-IN (V2X_MLP_STREAM=1; measured slower, profiles/r06_mlp_stream_ab.txt): the decision MLP as one wave per (slot, tile) with its
+// weights streamed from L2 (kernels_mlpstream.hpp), ALL four Dense weight gradients as roles of the graph layers' launch -- wherever
+// Dense-0's weight gradient may ride (dense0_rides).  At the 512- / 1024- / 2048-graph shares the MLP launch itself goes 23.6 -> 19.1,
+// 35.3 -> 33.0, 48.2 -> 50.9 us (every wave of a slot streams the same 135 KB in the same order: 4.5-6.9 TB/s over the chip, 1.6-1.9x
+// the MFMA time even at 2.5 waves per SIMD), the Dense 1..3 roles chained behind the Dense-0 halves add 10-27 us to the
+// weight-gradient launch (three more operand pipelines and accumulator exchanges per workgroup) and the image 13.6 us per step
+// (it could ride on k_reduce_adam's scatter): 0.1284 / 0.1696 / 0.2274 ms per step against 0.1128 / 0.1445 / 0.1870.
+bool mlp_stream_rides(const v2x_model* m, const DevBatch& d, const IdxMap& x) {
+  if (env_int("V2X_MLP_STREAM", 0) != 1) return false;             // (read per call: the tests switch it inside one process)
+  if (!m->mlp_img || m->dqn_tq || m->S != m->N || m->L + 5 > WG_MAX_ROLES) return false;
+  return env_int("V2X_MLP_WG0", -1) != 1 && dense0_rides(m, d, x);
+}
+
+int launch_mlp_stream(v2x_model* m, hipStream_t st, const MlpArgs& a, int n_slots) {
+  // the images follow the parameters: rebuilt from the flat buffer in front of every use (1.5 MB, one workgroup per slot)
+  { auto k = k_mlp_image<64>; LAUNCH_T(m, "k_mlp_image", k, dim3(n_slots), 256, (size_t)MlpLds<64>::TOTAL * 4, st, a, m->mlp_img); }
+  const int T = (a.n_idx + 15) / 16, units = T * n_slots;
+  if (a.frag_groups > 0) { auto k = k_mlp_stream<64, true>; LAUNCH_T(m, "k_mlp_stream", k, dim3(units), 64, 0, st, a, (const float*)m->mlp_img, T, units); }
+  else { auto k = k_mlp_stream<64, false>; LAUNCH_T(m, "k_mlp_stream", k, dim3(units), 64, 0, st, a, (const float*)m->mlp_img, T, units); }
+  return V2X_OK;
+}
+
 int run_forward(v2x_model* m, hipStream_t st, const DevBatch& d, Range r, bool with_mlp = true) {
   const int F = m->F, L = m->L;
   const IdxMap x = idx_map(m, d, r);
@@ -1902,7 +1950,10 @@ int run_backward(v2x_model* m, hipStream_t st, hipStream_t sw, const DevBatch& d
   // (the weight-gradient launch below must be the merged one of wgrad_gnn_all: one stream, no per-stage split)
   m->dense0_out_now = mlp_wg && !two && r.g0 == 0 && r.ng == d.B && dense0_rides(m, d, x);
   struct D0Guard { v2x_model* m; ~D0Guard() { m->dense0_out_now = false; } } d0_guard{m};
-  if (mlp_wg) CHK(launch_mlp_train_wg(m, st, a, !m->dense0_out_now));
+  m->mlp_stream_now = m->dense0_out_now && mlp_stream_rides(m, d, x);
+  struct MsGuard { v2x_model* m; ~MsGuard() { m->mlp_stream_now = false; } } ms_guard{m};
+  if (m->mlp_stream_now) CHK(launch_mlp_stream(m, st, a, x.grid_y));
+  else if (mlp_wg) CHK(launch_mlp_train_wg(m, st, a, !m->dense0_out_now));
   else if (mlp_fused_training(m)) CHK(launch_mlp_train(m, st, a));
   else CHK(launch_mlp(m, st, a, true));
   const bool merged = !mlp_wg && !two && wgrad_all_fits(m) && env_int("V2X_WG_SPLIT", 0) == 0;
@@ -2033,7 +2084,7 @@ GraphKey make_key(int kind, const DevBatch& d, const void* y, int n_global) {
 int max_slabs(const v2x_model* m, int n_idx, int n_slots) {
   int chunk, nc = 1;
   const int mr = m->L >= 1 ? merged_wg_rows(m, n_idx, n_slots) : 0;
-  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), env_int("V2X_WG_CHUNK_EMBED", 1024), 768, 896, mr > 0 ? mr : 1024})
+  for (int rows : {env_int("V2X_WG_CHUNK_GNN", 1024), env_int("V2X_WG_CHUNK_DENSE", 1024), env_int("V2X_WG_CHUNK_EMBED", 1024), env_int("V2X_WG_CHUNK_D123", 512), 768, 896, mr > 0 ? mr : 1024})
     if (rows > 0) nc = std::max(nc, role_chunks(n_idx, n_slots, 1000, 1000, &chunk, rows));     // (a switch set to 0 = its default)
   if (is_wide(m)) nc = std::max(nc, wide_splits(n_idx, 1, n_slots));     // the fewest tiles (one) split most
   else nc = std::max(nc, mlp_wg_split(n_idx, n_slots).n_slabs);         // k_mlp_train_wg: one slab per workgroup and slot
@@ -2160,6 +2211,7 @@ int v2x_create(const v2x_config* cfg, v2x_model** out) {
     if (dev_alloc(m, &m->pk_fwd, (size_t)m->S * fwd0 + (size_t)m->L * m->S * fwd) || dev_alloc(m, &m->pk_bwd, (size_t)m->L * m->S * bwd))
       return fail("allocation");
     m->pk_stale = true;             // first forward packs whatever the parameters are by then
+    if (m->F == 64 && !m->cfg.variable_graphs && dev_alloc(m, &m->mlp_img, (size_t)m->S * mlp_image_floats<64>())) return fail("allocation");
   }
   if ((m->pk_fwd || m->cfg.variable_graphs) && env_int("V2X_FUSED_TS", 0)) {
     if (dev_alloc(m, &m->ts_buf, 4 * 8 * 64)) return fail("allocation");
@@ -2188,7 +2240,7 @@ void v2x_destroy(v2x_model* m) {
   for (auto& kv : m->graphs) hipGraphExecDestroy(kv.second.exec);
   for (auto& r : m->prof_recs) { hipEventDestroy(r.ev0); hipEventDestroy(r.ev1); }
   float* ptrs[] = {m->params, m->grads, m->mom, m->vel, m->z1, m->z2, m->z3, m->q, m->dq, m->dz1, m->dz2, m->dz3,
-                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part, m->pk_fwd, m->pk_bwd, m->adam_scal};
+                   m->gha, m->rowloss, m->loss_dev, m->slab, m->zero_buf, m->loss_part, m->pk_fwd, m->pk_bwd, m->adam_scal, m->mlp_img};
   for (float* p : m->dpre) if (p) hipFree(p);
   if (m->gate_bits) hipFree(m->gate_bits);
   if (m->nbmask) hipFree(m->nbmask);
@@ -2844,7 +2896,7 @@ int v2x_path_info(v2x_model* m, const v2x_batch* b, char* out, int cap) {
   // the graph layers' weight-gradient launch (dense0_rides)
   const bool d0 = mlp_wg_path(m) && !m->cfg.variable_graphs && dense0_rides(m, d, idx_map(m, d, Range{0, d.B}));
   snprintf(out, cap, "graph_layers=%s aggregation=%s mlp=%s handoff=%s dense0_dw=%s", gl, agg,
-           mlp_wg_path(m) ? "train_wg" : (mlp_fused_training(m) ? "train" : "fwd+bwd"),
+           (d0 && mlp_stream_rides(m, d, idx_map(m, d, Range{0, d.B}))) ? "stream" : (mlp_wg_path(m) ? "train_wg" : (mlp_fused_training(m) ? "train" : "fwd+bwd")),
            frag_layout(m, d, Range{0, d.B}) ? "fragment-major" : "row-major",
            d0 ? "k_wgrad" : (mlp_wg_path(m) ? "k_mlp_train_wg" : (is_wide(m) ? "k_wide_wgrad" : "k_wgrad")));
   return V2X_OK;

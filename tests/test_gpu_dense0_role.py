@@ -2,7 +2,8 @@
 global batch).  At <= 2 tiles per wave k_mlp_train_wg leaves dW0 to k_wgrad (kernels_mlpwg.hpp WG0 = false writes the gated
 dz1 rows; kernels.hpp WG_KIND_DENSE0 / WG_KIND_DENSE0_FRAG reads h_L | x | a_L, the latter from the fragment-major hand-over
 of the fused graph-layer kernels).  Both forms against each other and against the float64 oracle (TF autodiff of the
-K.dot of /root/reference/BS_brain.py:176 under fit, :218-223)."""
+K.dot of /root/reference/BS_brain.py:176 under fit, :218-223).  Also the opt-in streamed MLP (kernels_mlpstream.hpp, V2X_MLP_STREAM=1:
+one wave per (slot, tile), all four Dense weight gradients as roles of k_wgrad; measured slower, profiles/r06_mlp_stream_ab.txt)."""
 import os
 
 import numpy as np
@@ -32,12 +33,13 @@ class _env(object):
                 os.environ[k] = v
 
 
-def _grads(spec, weights, pb, y, wg0, n_global=None, **create_env):
-    """(path_info, q, loss, flat gradient, names of the launches) of one forward_backward with V2X_MLP_WG0 = wg0"""
+def _grads(spec, weights, pb, y, wg0, n_global=None, stream=0, **create_env):
+    """(path_info, q, loss, flat gradient, names of the launches) of one forward_backward with V2X_MLP_WG0 = wg0 (and the streamed
+    MLP of kernels_mlpstream.hpp forced on / off)"""
     with _env(V2X_FUSED_COMPL=0, **create_env):
         eng = GnnEngine(spec)
     eng.set_weights(weights)
-    with _env(V2X_MLP_WG0=wg0):
+    with _env(V2X_MLP_WG0=wg0, V2X_MLP_STREAM=stream):
         info = eng.path_info(pb)
         q = eng.forward(pb)
         eng.profile(True)
@@ -105,6 +107,20 @@ def test_dense0_role_equals_in_kernel_gradient_and_oracle(N, F, L, B, share, han
     assert_close(loss_out, ref['loss'], 2e-4, 1e-6, "loss")
     assert_grads_match_oracle(lo, P, ref, "Dense-0 as a k_wgrad role")
     assert_grads_match_oracle(li, P, ref, "Dense-0 in k_mlp_train_wg")
+    # ... and the streamed MLP (kernels_mlpstream.hpp: one wave per (slot, tile), ALL Dense weight gradients as roles of k_wgrad):
+    # the same forward, loss and data gradients bit for bit, every weight gradient up to the order of its sum over rows
+    info_s, q_s, loss_s, g_s, names_s = _grads(spec, weights, pb, y, 0, stream=1)
+    if can and not share and L + 5 <= 8:
+        assert info_s["mlp"] == "stream" and {"k_mlp_stream", "k_wgrad_gnn_d0123"} <= names_s, (info_s, names_s)
+        assert "k_mlp_train_wg123" not in names_s and "k_mlp_train_wg" not in names_s, names_s
+    else:
+        assert info_s["mlp"] == "train_wg" and "k_mlp_stream" not in names_s, (info_s, names_s)
+    assert np.array_equal(q_in, q_s) and np.array_equal(loss_in, loss_s)
+    ls = v2xgnn.flat_to_keras_list(spec, g_s)
+    for i, (a, b) in enumerate(zip(li, ls)):
+        scale = max(np.abs(a).max(), 1e-30)
+        assert np.abs(a - b).max() <= 2e-5 * scale, (i, shapes[i], np.abs(a - b).max(), scale)
+    assert_grads_match_oracle(ls, P, ref, "the streamed MLP")
 
 
 def test_dense0_role_is_chosen_by_batch_size_and_replays_as_a_graph():

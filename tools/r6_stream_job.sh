@@ -1,0 +1,10 @@
+# round 6: k_mlp_stream at the shares -- parity tests that run it, then the share steps with and without it
+O=gpurun_out/r6s; mkdir -p $O
+python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_dense0_role.py tests/test_gpu_fused.py -x -q -p no:cacheprovider 2>&1 | tail -15 > $O/tests.txt
+tail -5 $O/tests.txt
+F="--no-cpu-baseline --no-dropin --no-other-workloads --no-fast-path --min-seconds 0.3"
+for G in ${GS:-8 4 2}; do
+  for S in 0 1; do
+    echo "shard-of $G V2X_MLP_STREAM=$S: $(V2X_MLP_STREAM=$S bash tools/quick_bench.sh $F --shard-of $G)"
+  done
+done | tee $O/shares.txt

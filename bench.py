@@ -407,7 +407,7 @@ def main_rl(args):
     steps, episodes = 20, max(1, args.episodes)
     ctx = torch.cuda.stream(torch.cuda.Stream())
     with ctx:
-        gpu = rl_episode(links, feat, batch, gamma, steps, 1001, use_graph=True, envs=args.envs, episodes=episodes)
+        gpu = rl_episode(links, feat, batch, gamma, steps, 1001, use_graph=not args.no_graph and args.launch != "eager", envs=args.envs, episodes=episodes)
     cpu = None
     if args.workload == "cfg0" and not args.no_cpu_baseline:
         from oracle.engine import OracleEngine
@@ -549,7 +549,11 @@ def build_parser():
     ap.add_argument("--feat", type=int, default=64)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--share-weights", action="store_true", help="one shared weight set instead of the reference's per-node sets")
-    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay (= --launch eager)")
+    ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                    help="how a fit step reaches the GPU: one hipGraph replay + the Adam launch, or five eager launches; auto (default) "
+                         "times 200 steps of each after the warm-up and keeps the faster (round 6: on ROCm 7.2 a graph replay costs "
+                         "3.6-5 us per step more than the eager launches it replaces whenever the host runs ahead of the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in boundary leg (dict API at the reference's configuration)")
@@ -588,7 +592,7 @@ class Ctx(object):
         self.world, self.rank, self.local, self.dist, self.force_dp = world, rank, local, dist, force_dp
 
 
-def make_engine(spec, ctx, args, edge_gather):
+def make_engine(spec, ctx, args, edge_gather, no_graph=None):
     """edge_gather: the fused graph-layer kernels run the general edge-index gather / segment sum of AggLayer.call
     (V2X_FUSED_COMPL=0 is read when the model is created) instead of the complement rewriting.  The complement engine also
     keeps whole-tile workgroups (V2X_FUSED_SPLIT=0): the split-tile kernels that the library picks for the shares of the
@@ -599,7 +603,7 @@ def make_engine(spec, ctx, args, edge_gather):
     if had is None:
         os.environ[key] = val
     try:
-        return GnnEngine(spec, device=ctx.local, use_graph=not args.no_graph)
+        return GnnEngine(spec, device=ctx.local, use_graph=not (args.no_graph if no_graph is None else no_graph))
     finally:
         if had is None:
             del os.environ[key]
@@ -622,7 +626,8 @@ def run_workload(args, ctx, light=False):
     # runs it; the complement rewriting (valid for any adjacency, profitable for complete-minus-few graphs) is the fast path
     # timed beside it.  An explicit V2X_FUSED_COMPL in the environment is respected (one engine, no second pass).
     explicit = os.environ.get("V2X_FUSED_COMPL") is not None
-    eng = make_engine(spec, ctx, args, edge_gather=not explicit)
+    launch = "eager" if args.no_graph else getattr(args, "launch", "auto")
+    eng = make_engine(spec, ctx, args, edge_gather=not explicit, no_graph=launch == "eager")
     wrng = np.random.default_rng(1001)             # identical weights on every rank
     shapes = v2xgnn.keras_list_shapes(spec)
     eng.set_weights([np.zeros(s, np.float32) if len(s) == 1 else
@@ -717,6 +722,39 @@ def run_workload(args, ctx, light=False):
     stream = torch.cuda.Stream(device=local)
     path = eng.path_info(db)
     E = pb.n_edges
+
+    # ---- launch form (--launch auto): the same steps as ONE hipGraph replay + the Adam launch and as five eager launches, 200 steps
+    # each; the faster one runs the timed region (every rank takes the decision of the slowest rank's clocks)
+    launch_probe = None
+    if launch == "auto":
+        eng_e = make_engine(spec, ctx, args, edge_gather=not explicit, no_graph=True)
+        eng_e.copy_weights_from(eng)
+        tr_e = DataParallelTrainer(eng_e, force=ctx.force_dp) if use_dp else None
+
+        def probe(step, n=200):
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - tp) / n
+        with torch.cuda.stream(stream):
+            t_g = probe(stepper(eng, trainer, db, yd, n_denom))
+            t_e = probe(stepper(eng_e, tr_e, db, yd, n_denom))
+        if dist is not None:
+            t = torch.tensor([t_g, t_e], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_g, t_e = float(t[0].item()), float(t[1].item())
+        launch_probe = {"hipGraph replay": round(t_g, 4), "eager": round(t_e, 4)}
+        if t_e < t_g:
+            eng.close()
+            eng, trainer, launch = eng_e, tr_e, "eager"
+        else:
+            eng_e.close()
+            launch = "graph"
+    args = argparse.Namespace(**dict(vars(args), no_graph=launch == "eager"))      # (the fast-path engine below follows the choice)
 
     # ---- per-kernel roofline: an instrumented (eager, HIP events around every launch) pass of the same steps, BEFORE the
     # timed region so that the timed region is the last and longest stretch of GPU work of the run
@@ -857,7 +895,7 @@ def run_workload(args, ctx, light=False):
                                        else ("one all-reduce per gradient bucket, overlapped with the backward phases" if trainer.overlap
                                              else "one all-reduce of the flat gradient"))),
                           "lib_sha256": lib_sha256(),
-                          "launch": "eager" if args.no_graph else "hipGraph replay",
+                          "launch": "eager" if launch == "eager" else "hipGraph replay", "launch_probe_ms": launch_probe,
                           "parallelism": "dp%d" % world},
                "roofline": roofline, "cpu_baseline": None}
         if kernels is not None:
@@ -940,7 +978,8 @@ def other_workloads(args, ctx):
         rf = r.get("roofline") or {}
         d = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
              "graphs_per_gpu": r["config"]["graphs_per_gpu"], "graph_layers": r["config"]["kernel_path"].get("graph_layers"),
-             "aggregation": r["aggregation"], "dominant_kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"),
+             "aggregation": r["aggregation"], "launch": r["config"]["launch"],
+             "dominant_kernel": rf.get("kernel"), "bound": rf.get("bound"), "frac": rf.get("frac"),
              "step_hbm_frac": rf.get("step_hbm_frac"), "step_mfma_frac": rf.get("step_mfma_frac")}
         if args.other_kernels:            # the long form: workload prose, the whole path, HIP-event times of every kernel
             d.update({"workload": r["config"]["workload"], "kernel_path": r["config"]["kernel_path"],
@@ -1025,7 +1064,9 @@ def summary(out, others, dropin, cpu):
     def cpu_of(key):
         v = ((o.get(key) or {}).get("cpu_baseline") or {}).get("value")
         return None if v is None else round(float(v), 1)
-    sm = {"ms": out["ms_per_step"], "frac": (out.get("roofline") or {}).get("frac"),
+    lp = (out.get("config") or {}).get("launch_probe_ms") or {}
+    sm = {"ms": out["ms_per_step"], "graph_replay_ms": lp.get("hipGraph replay"), "eager_ms": lp.get("eager"),
+          "frac": (out.get("roofline") or {}).get("frac"),
           "step_mfma_frac": (out.get("roofline") or {}).get("step_mfma_frac"),
           "fast_path_ms": (out.get("fast_path") or {}).get("ms_per_step"),
           "cpu": None if cpu is None else cpu["value"], "cpu_workers": None if cpu is None else cpu["workers"],

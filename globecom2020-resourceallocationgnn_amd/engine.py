@@ -71,7 +71,9 @@ def _batch_struct(b):
 class GnnEngine(object):
     """use_graph: forward / fit steps are captured once per (batch pointers, sizes) as a hipGraph and replayed.
     Capture needs a NON-default stream: calls made while torch's current stream is the default one run eagerly
-    (`with torch.cuda.stream(torch.cuda.Stream()): ...` enables the graphs)."""
+    (`with torch.cuda.stream(torch.cuda.Stream()): ...` enables the graphs).  Off by default: a replay saves host calls, not GPU time --
+    on ROCm 7.2 one hipGraphLaunch costs 3.6-6 us per fit step MORE than the launches it replaces when the host runs ahead of the GPU
+    (profiles/r06_launch_form.txt); it pays for host-bound loops."""
 
     def __init__(self, spec: GnnSpec, device=0, use_graph=False, lr=1e-3, beta_1=0.5, beta_2=0.999,
                  epsilon=1e-7):

@@ -153,6 +153,7 @@ def test_bench_two_ranks_on_one_gpu(scaling, batch, global_batch, per_gpu):
     assert (res["metric"] == BASELINE_METRIC) == (global_batch == 4096)
     assert res["config"]["aggregation"] in ("complement", "edge-bitset-walk", "edge-gather")
     assert abs(res["value"] - global_batch * 5 / (res["ms_per_step"] * 5e-3)) / res["value"] < 1e-3
+    assert res["config"]["launch"] in ("eager", "hipGraph replay") and set(res["config"]["launch_probe_ms"]) == {"hipGraph replay", "eager"}
 
 
 def test_bench_starts_its_own_ranks():

@@ -326,6 +326,16 @@ def test_rccl_path_single_rank(tmp_path):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and res["config"]["global_batch"] == 256
+    # the launch form of the timed region (--launch auto): both were probed, the faster one is named
+    assert res["config"]["launch"] in ("eager", "hipGraph replay"), res["config"]["launch"]
+    probe = res["config"]["launch_probe_ms"]
+    assert set(probe) == {"hipGraph replay", "eager"} and all(v > 0 for v in probe.values()), probe
+    assert (res["config"]["launch"] == "eager") == (probe["eager"] < probe["hipGraph replay"]), (res["config"]["launch"], probe)
+    for forced, name in (("graph", "hipGraph replay"), ("eager", "eager")):
+        out = subprocess.run(cmd + ["--launch", forced], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        r2 = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert r2["config"]["launch"] == name and r2["config"]["launch_probe_ms"] is None, r2["config"]
 
 
 def test_ragged_large_batch_loss_is_split_reduced():

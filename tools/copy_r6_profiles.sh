@@ -6,7 +6,7 @@ cp $O/kernel_stats.txt $P/r06_kernel_stats.txt; cp $O/kernel_stats_cfg4.txt $P/r
 for g in 2 4 8; do cp $O/kernel_stats_share$g.txt $P/r06_kernel_stats_share$g.txt; cp $O/mfma_share$g.txt $P/r06_pmc_share$g.txt; done
 cp $O/stalls.txt $P/r06_stalls.txt
 cp $O/roofline.md $P/r06_roofline.md; cp $O/roofline_cfg4.md $P/r06_roofline_configs3.md; cp $O/roofline_cfg5.md $P/r06_roofline_configs4.md
-for f in dropin_profile dp_host_overhead dp_host_overhead_b512 predict_latency gputests lib_sha mlpwg_phases_b512 wgrad_roles_b512 soak_split rl_loop_kernels cpu_quota ragged_phases loop_env1_threads; do cp $O/$f.txt $P/r06_$f.txt; done
+for f in dropin_profile dp_host_overhead predict_latency gputests lib_sha mlpwg_phases_b512 wgrad_roles_b512 soak_split rl_loop_kernels cpu_quota ragged_phases loop_env1_threads; do cp $O/$f.txt $P/r06_$f.txt; done
 cp $O/fetch_cfg4.txt $P/r06_pmc_fetch_cfg4.txt; cp $O/write_cfg4.txt $P/r06_pmc_write_cfg4.txt; cp $O/fetch_cfg5.txt $P/r06_pmc_fetch_cfg5.txt; cp $O/write_cfg5.txt $P/r06_pmc_write_cfg5.txt
 cp $O/hbm_traffic.json $P/hbm_traffic.json
 # the written analyses of round 6 follow the tables they refer to

@@ -23,7 +23,7 @@ rng = np.random.default_rng(1001)
 x, e, adj, y = bench.synth_batch(rng, B, N)
 stream = torch.cuda.Stream()
 with torch.cuda.stream(stream):
-    eng = GnnEngine(GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L), use_graph=True)
+    eng = GnnEngine(GnnSpec(n_nodes=N, feat_dim=F, n_mp_layers=L), use_graph=os.environ.get("DP_GRAPH", "0") == "1")       # DP_GRAPH=1: the phases as hipGraph replays (round 5's form)
     db = eng.to_device(PackedBatch.from_dense(x, e, adj))
     yd = torch.from_numpy(y).cuda()
     n = 30 if wide else 300
